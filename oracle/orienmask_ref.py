@@ -1,0 +1,341 @@
+"""CPU oracle for the OrienMask inference hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; the product (``orienmask_amd``) never does and fails loudly when its
+HIP library is missing.
+
+It restates, in torch-CPU / numpy fp32 arithmetic, what the reference computes on the
+path ``OrienMaskYOLOFPNPlus.forward`` + ``OrienMaskYOLOPostProcess.__call__``.  Each
+function cites the reference lines it follows.  The convolution / batch-norm /
+interpolate / sigmoid / exp / sort / topk primitives live in PyTorch (a third-party
+dependency of the reference, unpinned in /root/reference/requirements.txt:2); the oracle
+calls the same torch CPU primitives at the same call sites and in the same memory
+layouts, which is what makes it bit-identical to the reference run in this container.
+
+Pinning: ``tools/gen_golden.py`` imports the real reference from /root/reference (this
+container only) and writes ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks
+this oracle against every one of them.  The reference itself ships no tests or golden
+vectors for this path, so those fixtures are the pin.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# --------------------------------------------------------------------------------------
+# forward
+# --------------------------------------------------------------------------------------
+
+
+def _cbl(sd, name, x, stride=1):
+    """conv(bias=False) -> BatchNorm2d(eval, eps=1e-5) -> LeakyReLU(0.1).
+    /root/reference/model/base.py:104-137 (ConvBNRelu), :278-279 (conv_bn_leaky)."""
+    w = sd[name + ".conv_block.0.weight"]
+    x = F.conv2d(x, w, None, stride, w.shape[-1] // 2)
+    p = name + ".conv_block.1."
+    x = F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"],
+                     sd[p + "bias"], False, 0.1, 1e-5)
+    return F.leaky_relu(x, 0.1)
+
+
+def _plain(sd, name, x):
+    """Final 1x1 conv of a head: bias, no BN, no activation.
+    /root/reference/model/orienmask_yolo_fpnplus.py:60,71."""
+    return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"])
+
+
+def _stage(sd, idx, x, nblocks):
+    """One DarkNet stage: stride-2 3x3 then nblocks of x + conv3x3(conv1x1(x)).
+    /root/reference/model/backbone/darknet.py:6-15,41-45."""
+    p = "backbone.conv%d" % idx
+    x = _cbl(sd, p + ".0", x, stride=2)
+    for j in range(1, nblocks + 1):
+        y = _cbl(sd, "%s.%d.conv.0" % (p, j), x)
+        y = _cbl(sd, "%s.%d.conv.1" % (p, j), y)
+        x = x + y
+    return x
+
+
+def backbone(sd, x):
+    """DarkNet53.forward, /root/reference/model/backbone/darknet.py:47-54."""
+    x = _cbl(sd, "backbone.conv1", x)
+    x = _stage(sd, 2, x, 1)
+    x4 = _stage(sd, 3, x, 2)
+    x8 = _stage(sd, 4, x4, 8)
+    x16 = _stage(sd, 5, x8, 8)
+    x32 = _stage(sd, 6, x16, 4)
+    return x32, x16, x8, x4
+
+
+def _seq(sd, prefix, x, n):
+    for i in range(n):
+        x = _cbl(sd, "%s.%d" % (prefix, i), x)
+    return x
+
+
+def _up(x, s):
+    """NearestUpsample, /root/reference/model/base.py:95-101."""
+    return F.interpolate(x, scale_factor=s, mode="nearest")
+
+
+def forward(sd, x, num_anchors=3, return_features=False):
+    """OrienMaskYOLOFPNPlus.forward, /root/reference/model/orienmask_yolo_fpnplus.py:74-90.
+    Concat order: upsampled route first, backbone feature second (:78-79); skips 32,16,8,4 (:85-86)."""
+    with torch.no_grad():
+        x32, x16, x8, x4 = backbone(sd, x)
+        n32 = _seq(sd, "neck32", x32, 5)
+        n16 = _seq(sd, "neck16", torch.cat([_up(_cbl(sd, "route32.0", n32), 2), x16], 1), 5)
+        n8 = _seq(sd, "neck8", torch.cat([_up(_cbl(sd, "route16.0", n16), 2), x8], 1), 5)
+        b32 = _plain(sd, "bbox_head32.1", _cbl(sd, "bbox_head32.0", n32))
+        b16 = _plain(sd, "bbox_head16.1", _cbl(sd, "bbox_head16.0", n16))
+        b8 = _plain(sd, "bbox_head8.1", _cbl(sd, "bbox_head8.0", n8))
+        cat4 = torch.cat([_up(_cbl(sd, "skip32.0", n32), 8), _up(_cbl(sd, "skip16.0", n16), 4),
+                          _up(_cbl(sd, "skip8.0", n8), 2), _cbl(sd, "skip4", x4)], 1)
+        o = _seq(sd, "orien_head", _seq(sd, "neck4", cat4, 5), 5)
+        o = _plain(sd, "orien_head.5", o)
+        o32, o16, o8 = torch.split(o, num_anchors * 2, dim=1)
+    out = ((b32, o32), (b16, o16), (b8, o8))
+    if return_features:
+        return out, dict(x32=x32, x16=x16, x8=x8, x4=x4, neck32=n32, neck16=n16, neck8=n8, oriens=o)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# NMS
+# --------------------------------------------------------------------------------------
+
+_nms_lib = None
+
+
+def _load_nms_lib():
+    global _nms_lib
+    if _nms_lib is None:
+        path = os.path.join(_HERE, "libnms_ref.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/libnms_ref.so not built; run `make -C oracle` or __graft_entry__.build()")
+        lib = ctypes.CDLL(path)
+        lib.nms_ref_f32.restype = ctypes.c_int
+        lib.nms_ref_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+        _nms_lib = lib
+    return _nms_lib
+
+
+def nms_cpu(dets, threshold):
+    """nms_cpu_kernel<float>, /root/reference/eval/src/nms_cpu.cpp:4-63, through the C
+    restatement oracle/nms_ref.c.  dets [n,5] (cx,cy,w,h,score) float32; returns int64
+    keep indices in ASCENDING original-index order (nms_cpu.cpp:62).  The descending
+    score order comes from torch.sort, as at nms_cpu.cpp:24."""
+    dets = dets.detach().to(torch.float32).contiguous()
+    n = dets.shape[0]
+    if n == 0:
+        return torch.zeros(0, dtype=torch.long)
+    order = torch.sort(dets[:, 4].contiguous(), 0, descending=True)[1].contiguous()
+    keep_flag = np.zeros(n, dtype=np.uint8)
+    lib = _load_nms_lib()
+    lib.nms_ref_f32(dets.numpy().ctypes.data, order.numpy().ctypes.data, n, ctypes.c_float(threshold),
+                    keep_flag.ctypes.data)
+    return torch.from_numpy(np.nonzero(keep_flag)[0].astype(np.int64))
+
+
+def nms_numpy(dets, threshold, order=None):
+    """Same algorithm in numpy float32 (no C); used to cross-check nms_ref.c in tests."""
+    d = np.asarray(dets, dtype=np.float32)
+    n = d.shape[0]
+    if n == 0:
+        return np.zeros(0, dtype=np.int64)
+    half = np.float32(2.0)
+    x1 = d[:, 0] - d[:, 2] / half; y1 = d[:, 1] - d[:, 3] / half
+    x2 = d[:, 0] + d[:, 2] / half; y2 = d[:, 1] + d[:, 3] / half
+    areas = (x2 - x1) * (y2 - y1)
+    if order is None:
+        order = torch.sort(torch.from_numpy(d[:, 4].copy()), 0, descending=True)[1].numpy()
+    sup = np.zeros(n, dtype=bool)
+    thr = np.float32(threshold)
+    for pi in range(n):
+        i = order[pi]
+        if sup[i]:
+            continue
+        js = order[pi + 1:]
+        js = js[~sup[js]]
+        if js.size == 0:
+            continue
+        w = np.maximum(np.float32(0), np.minimum(x2[i], x2[js]) - np.maximum(x1[i], x1[js]))
+        h = np.maximum(np.float32(0), np.minimum(y2[i], y2[js]) - np.maximum(y1[i], y1[js]))
+        inter = w * h
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ovr = inter / (areas[i] + areas[js] - inter)
+        sup[js[ovr >= thr]] = True
+    return np.nonzero(~sup)[0].astype(np.int64)
+
+
+def batched_nms(dets, cats, threshold=0.5, normalized=True):
+    """batched_nms, /root/reference/eval/function.py:77-103: boxes of class c are shifted
+    by c * (1.5 + 0.5) in x and y so that different classes never overlap."""
+    if dets.shape[0] == 0:
+        keep = torch.zeros(0, dtype=torch.long)
+    else:
+        if normalized:
+            max_coordinate = 1.5
+        else:
+            max_coordinate = dets[:, :2].max() + dets[:, 2:4].max() / 2
+        shifted = dets.clone()
+        shifted[:, :2] += cats.float().view(-1, 1) * (max_coordinate + 0.5)
+        keep = nms_cpu(shifted, threshold)
+    return dets[keep], cats[keep], keep
+
+
+# --------------------------------------------------------------------------------------
+# postprocess
+# --------------------------------------------------------------------------------------
+
+
+class PostProcessOracle:
+    """OrienMaskYOLOPostProcess, /root/reference/eval/orienmask_yolo_postprocess.py:8-166."""
+
+    def __init__(self, grid_size, image_size, anchors, anchor_mask, num_classes, conf_thresh=0.05,
+                 nms_thresh=0.5, nms_pre=400, nms_post=100, orien_thresh=0.3):
+        self.grids = [(int(g[0]), int(g[1])) for g in grid_size]          # (nH, nW) per scale
+        if isinstance(image_size, int):
+            image_size = (image_size, image_size)
+        self.img_h, self.img_w = int(image_size[0]), int(image_size[1])
+        self.anchor_mask = [list(m) for m in anchor_mask]
+        self.num_classes = num_classes
+        self.conf_thresh = conf_thresh
+        self.nms_thresh = nms_thresh
+        self.nms_pre = nms_pre
+        self.nms_post = nms_post
+        self.orien_thresh = orien_thresh
+        # constant tables, postprocess.py:17-27
+        pix = torch.tensor(anchors, dtype=torch.float32)
+        self.norm_anchors = torch.empty_like(pix)
+        self.norm_anchors[:, 0] = pix[:, 0] / self.img_w
+        self.norm_anchors[:, 1] = pix[:, 1] / self.img_h
+        self.grid_anchors = self.norm_anchors.clone()
+        self.grid_sizes = self.norm_anchors.clone()
+        for m, (nh, nw) in zip(self.anchor_mask, self.grids):
+            self.grid_anchors[m, 0] *= nw
+            self.grid_anchors[m, 1] *= nh
+            self.grid_sizes[m, 0] = nw
+            self.grid_sizes[m, 1] = nh
+        # base_xy, postprocess.py:38-45
+        self.base_xy = torch.zeros(pix.shape[0], 2, self.img_h, self.img_w)
+        gxs, gys, aidx = [], [], []
+        for m, (nh, nw) in zip(self.anchor_mask, self.grids):
+            by = torch.arange(self.img_h, dtype=torch.float) / self.img_h * nh
+            bx = torch.arange(self.img_w, dtype=torch.float) / self.img_w * nw
+            self.base_xy[m] = torch.stack([bx.view(1, -1).expand(self.img_h, self.img_w),
+                                           by.view(-1, 1).expand(self.img_h, self.img_w)], 0)
+            na = len(m)
+            gy = torch.arange(nh, dtype=torch.float).view(1, nh, 1).expand(na, nh, nw).contiguous()
+            gx = torch.arange(nw, dtype=torch.float).view(1, 1, nw).expand(na, nh, nw).contiguous()
+            gxs.append(gx); gys.append(gy)
+            aidx.append(torch.tensor(m).view(na, 1, 1).expand(na, nh, nw).contiguous())
+        self.gx, self.gy = gxs, gys
+        self.flat_anchor_idx = torch.cat([a.reshape(-1) for a in aidx])          # postprocess.py:59-61
+
+    def decode_scale(self, raw, i):
+        """get_boxes, postprocess.py:126-139.  raw: [A, 5+C, nH, nW] of one image."""
+        nh, nw = self.grids[i]
+        na = len(self.anchor_mask[i])
+        t = raw.reshape(na, -1, nh, nw).permute(0, 2, 3, 1).contiguous()      # postprocess.py:86
+        obj = t[..., 4].sigmoid().view(-1)
+        cls = t[..., 5:].sigmoid().view(-1, self.num_classes)
+        conf = cls * obj.unsqueeze(-1)
+        anc = self.norm_anchors[self.anchor_mask[i]]
+        aw, ah = anc[:, 0:1], anc[:, 1:2]
+        coord = t[..., 0:4]
+        coord[..., 0] = (coord[..., 0].sigmoid() + self.gx[i]) / nw
+        coord[..., 1] = (coord[..., 1].sigmoid() + self.gy[i]) / nh
+        coord[..., 2] = coord[..., 2].exp() * aw.view(-1, 1, 1)
+        coord[..., 3] = coord[..., 3].exp() * ah.view(-1, 1, 1)
+        return coord.reshape(-1, 4), conf
+
+    def candidates(self, predict, b):
+        """Decode + threshold + top-nms_pre for image b: postprocess.py:78-114.
+        Returns coord[n,4], conf[n], cls[n], anchor_idx[n], flat candidate index[n]."""
+        coords, confs = [], []
+        for i in range(len(self.grids)):
+            c, f = self.decode_scale(predict[i][0][b], i)
+            coords.append(c); confs.append(f)
+        coord = torch.cat(coords, 0)
+        conf = torch.cat(confs, 0)
+        sel, cls = torch.nonzero(conf > self.conf_thresh, as_tuple=True)       # :102, row-major
+        sel = sel.view(-1); cls = cls.view(-1)
+        score = conf[sel, cls]
+        if sel.numel() > self.nms_pre:                                          # :107-110
+            score, top = score.topk(self.nms_pre)
+            sel = sel[top]; cls = cls[top]
+        return coord[sel], score, cls, self.flat_anchor_idx[sel], sel
+
+    def orien_field(self, predict, b):
+        """Upsampled orientation planes turned into pointed-to grid positions:
+        postprocess.py:69-72 (bilinear x4), :92 (anchor placement), :141-144 (get_orien_grid)."""
+        field = torch.zeros_like(self.base_xy)
+        for i, m in enumerate(self.anchor_mask):
+            up = F.interpolate(predict[i][1][b:b + 1], scale_factor=4.0, mode="bilinear", align_corners=False)[0]
+            field[m] = up.view(len(m), 2, self.img_h, self.img_w)
+        p = field * self.grid_anchors.view(-1, 2, 1, 1) / 2
+        p += self.base_xy
+        return p
+
+    def finish(self, coord, score, cls, anchor_idx, field):
+        """multi_class_nms, postprocess.py:146-166."""
+        dets = torch.cat([coord, score.unsqueeze(-1)], 1)
+        dets, cats, keep = batched_nms(dets, cls, self.nms_thresh)
+        if keep.numel() > self.nms_post:
+            _, top = dets[:, -1].topk(self.nms_post)
+            dets = dets[top]; cats = cats[top]; keep = keep[top]
+        a = anchor_idx[keep]
+        gsx = self.grid_sizes[a, 0]; gsy = self.grid_sizes[a, 1]
+        xc = (gsx * dets[:, 0]).view(-1, 1, 1)
+        yc = (gsy * dets[:, 1]).view(-1, 1, 1)
+        dw = dets[:, 2].view(-1, 1, 1); dh = dets[:, 3].view(-1, 1, 1)
+        masks = ((torch.abs(field[a, 0] - xc) < self.orien_thresh * dw * gsx.view(-1, 1, 1)) &
+                 (torch.abs(field[a, 1] - yc) < self.orien_thresh * dh * gsy.view(-1, 1, 1)))
+        return {"bbox": dets, "mask": masks, "cls": cats, "keep": keep, "anchor": a}
+
+    def __call__(self, predict):
+        """apply, postprocess.py:66-124.  predict = 3 x (bbox[B,A*(5+C),nH,nW], orien[B,2A,H/4,W/4])."""
+        out = []
+        with torch.no_grad():
+            predict = [(p[0].detach().float().cpu(), p[1].detach().float().cpu()) for p in predict]
+            for b in range(predict[0][0].shape[0]):
+                coord, score, cls, aidx, sel = self.candidates(predict, b)
+                res = self.finish(coord, score, cls, aidx, self.orien_field(predict, b))
+                res["n_candidates"] = int(sel.numel())
+                out.append(res)
+        return out
+
+
+def bilinear_x4_restated(plane):
+    """Bilinear x4, align_corners=False, exactly as the HIP mask kernel evaluates it (numpy):
+    src = (d + 0.5) * 0.25 - 0.5 clamped at 0, i0 = floor(src), i1 = min(i0 + 1, n - 1),
+    row(y) = fma(v[y][x0], wx0, v[y][x1] * wx1);  out = fma(row(y0), wy0, row(y1) * wy1).
+    Call site in the reference: postprocess.py:69-72 (F.interpolate).  The fma placement is
+    the one torch 2.10's CPU kernel compiles to (found by search; bit-identical in this
+    container), so the kernel's upsample can be compared with torch bit for bit."""
+    p = np.asarray(plane, dtype=np.float32)
+    h, w = p.shape
+
+    def taps(n):
+        d = np.arange(n * 4, dtype=np.float32)
+        src = np.maximum((d + np.float32(0.5)) * np.float32(0.25) - np.float32(0.5), np.float32(0))
+        i0 = np.floor(src).astype(np.int64)
+        i1 = np.minimum(i0 + 1, n - 1)
+        l1 = (src - i0.astype(np.float32)).astype(np.float32)
+        return i0, i1, (np.float32(1) - l1).astype(np.float32), l1
+
+    def fma(a, b, c):     # exact product in float64, one rounding to float32
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+    y0, y1, wy0, wy1 = taps(h)
+    x0, x1, wx0, wx1 = taps(w)
+    wx0b = np.broadcast_to(wx0[None, :], (4 * h, 4 * w)); wx1b = np.broadcast_to(wx1[None, :], (4 * h, 4 * w))
+    wy0b = np.broadcast_to(wy0[:, None], (4 * h, 4 * w)); wy1b = np.broadcast_to(wy1[:, None], (4 * h, 4 * w))
+    top = fma(p[y0][:, x0], wx0b, (p[y0][:, x1] * wx1b).astype(np.float32))
+    bot = fma(p[y1][:, x0], wx0b, (p[y1][:, x1] * wx1b).astype(np.float32))
+    return fma(top, wy0b, (bot * wy1b).astype(np.float32))

@@ -1,0 +1,160 @@
+"""Build-owned, platform-stable synthetic weights and inputs.
+
+There is no checkpoint and no COCO on the build or GPU boxes, so every bench and
+parity run uses seeded synthetic data. The generators use numpy's PCG64 stream
+only (never ``torch.manual_seed``) so that this container and the GPU box
+regenerate identical bytes.
+
+Shapes follow the reference's 524-key state_dict
+(/root/reference/model/orienmask_yolo_fpnplus.py:9-72); the value distributions are
+ours, chosen so that activations stay O(1) through the 75-conv-deep path and BatchNorm
+is far from identity (a folded-BN bug cannot hide).
+"""
+import numpy as np
+import torch
+
+from .arch import fpnplus_convs, state_dict_entries, is_residual_tail
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(int(seed)))
+
+
+def synth_state_dict(seed=0, num_anchors=3, num_classes=80, obj_bias=0.0, head_gain=1.0,
+                     coord_gain=0.3, orien_gain=0.2):
+    """Seeded reference-format state_dict (CPU float32 tensors, 524 keys).
+
+    A random-weight network's head outputs vary far more across channels than across
+    positions, so the final 1x1 convs get per-role gains: head_gain on the objectness and
+    class rows (spreads the logits over positions), coord_gain on the tx/ty/tw/th rows
+    (keeps exp(tw) sane) and orien_gain on the orientation head (keeps masks non-empty).
+    obj_bias shifts the objectness logits: with head_gain=4, about -10 passes tens of
+    thousands of pairs, -18 a few hundred, -24 none.
+    """
+    rng = _rng(seed)
+    sd = {}
+    for spec in fpnplus_convs(num_anchors, num_classes):
+        fan_in = spec.cin * spec.ksize * spec.ksize
+        for key, shape, role in state_dict_entries(spec):
+            if role == "conv_w":
+                std = np.sqrt(2.0 / fan_in)
+                v = rng.standard_normal(shape, dtype=np.float32) * np.float32(std)
+                if not spec.bn:
+                    gain = np.full((spec.cout, 1, 1, 1), orien_gain / np.sqrt(2.0), dtype=np.float32)
+                    if spec.name.startswith("bbox_head"):
+                        gain[:] = head_gain / np.sqrt(2.0)
+                        for a in range(num_anchors):
+                            gain[a * (5 + num_classes):a * (5 + num_classes) + 4] = coord_gain / np.sqrt(2.0)
+                    v = v * gain
+            elif role == "bn_gamma":
+                lo, hi = (0.1, 0.25) if is_residual_tail(spec) else (0.7, 1.3)
+                v = rng.uniform(lo, hi, shape).astype(np.float32)
+            elif role == "bn_beta":
+                v = (rng.standard_normal(shape) * 0.1).astype(np.float32)
+            elif role == "bn_mean":
+                v = (rng.standard_normal(shape) * 0.1).astype(np.float32)
+            elif role == "bn_var":
+                v = rng.uniform(0.6, 1.6, shape).astype(np.float32)
+            elif role == "bn_count":
+                sd[key] = torch.tensor(1, dtype=torch.long)
+                continue
+            elif role == "conv_b":
+                v = (rng.standard_normal(shape) * 0.1).astype(np.float32)
+                if spec.name.startswith("bbox_head") and obj_bias != 0.0:
+                    per_anchor = 5 + num_classes
+                    v[4::per_anchor] += np.float32(obj_bias)
+            else:  # pragma: no cover
+                raise AssertionError(role)
+            sd[key] = torch.from_numpy(np.ascontiguousarray(v))
+    return sd
+
+
+def synth_image_batch(seed, batch, height=544, width=544):
+    """[B,3,H,W] float32 in [0,1): what FastCOCOTransform hands the model
+    (/root/reference/config/base.py:158-164, Normalize std=255)."""
+    rng = _rng(seed)
+    x = rng.random((batch, 3, height, width), dtype=np.float32)
+    return torch.from_numpy(x)
+
+
+def synth_heads(seed, batch, grid_sizes, num_anchors=3, num_classes=80, regime="mixed",
+                orien_scale=4):
+    """Seeded head tensors in the model's output format, for postprocess-only tests.
+
+    Returns ((bbox32, orien32), (bbox16, orien16), (bbox8, orien8)) with
+    bbox_s [B, A*(5+C), nH_s, nW_s] and orien_s [B, A*2, H/4, W/4], shaped like
+    /root/reference/model/orienmask_yolo_fpnplus.py:88-90.
+
+    regime: 'dense'       - every (candidate, class) pair passes conf_thresh (worst case)
+            'mixed'       - well over nms_pre pairs pass (top-k branch), NMS suppresses many
+            'clustered'   - over nms_pre pairs pass but they sit in ~60 tight clusters, so fewer
+                            than nms_post survive NMS
+            'sparse'      - fewer than nms_pre pairs pass, fewer than nms_post survive NMS
+            'sparse_many' - fewer than nms_pre pairs pass, more than nms_post survive NMS
+            'empty'       - nothing passes (K = 0)
+    The orientation maps are smooth fields pointing roughly at random centres so that
+    masks are blobs rather than noise.
+    """
+    rng = _rng(seed)
+    per_anchor = 5 + num_classes
+    total = sum(num_anchors * nh * nw for nh, nw in grid_sizes)
+    target_active = {"dense": 0, "mixed": 700, "clustered": 60, "sparse": 55, "sparse_many": 260,
+                     "empty": 0}[regime]
+    target_active = min(target_active, total // 3)
+    out = []
+    oh = grid_sizes[-1][0] * 8 // orien_scale
+    ow = grid_sizes[-1][1] * 8 // orien_scale
+    for (nh, nw) in grid_sizes:
+        bbox = rng.standard_normal((batch, num_anchors, per_anchor, nh, nw), dtype=np.float32)
+        bbox[:, :, 2:4] *= 0.5
+        if regime == "dense":
+            bbox[:, :, 4] *= 2.0
+            bbox[:, :, 5:] *= 1.5
+        else:
+            bbox[:, :, 4] = bbox[:, :, 4] * 0.5 - 14.0
+            bbox[:, :, 5:] = bbox[:, :, 5:] * 0.5 - 10.0
+            n_here = int(round(target_active * (num_anchors * nh * nw) / total))
+            for b in range(batch):
+                for _ in range(n_here):
+                    a = int(rng.integers(num_anchors)); y = int(rng.integers(nh)); x = int(rng.integers(nw))
+                    c = int(rng.integers(num_classes))
+                    ob = 1.0 + 1.5 * rng.standard_normal(); cl = 1.0 + 1.5 * rng.standard_normal()
+                    bbox[b, a, 4, y, x] = ob
+                    bbox[b, a, 5 + c, y, x] = cl
+                    if rng.random() < 0.3 and regime != "clustered":   # a second class on the same box
+                        bbox[b, a, 5 + int(rng.integers(num_classes)), y, x] = cl - 1.0
+                    if regime == "clustered":
+                        # a 3x3 block of cells all voting for one box: centres pulled towards
+                        # the middle cell, same class, same size -> NMS keeps about one each
+                        bbox[b, a, 4, y, x] = ob = 2.0 + abs(ob)
+                        bbox[b, a, 5 + c, y, x] = cl = 2.0 + abs(cl)
+                        bbox[b, a, 2:4, y, x] = 1.2
+                        for dy in (-1, 0, 1):
+                            for dx in (-1, 0, 1):
+                                yy, xx = y + dy, x + dx
+                                if not (0 <= yy < nh and 0 <= xx < nw):
+                                    continue
+                                if dy or dx:
+                                    bbox[b, a, :, yy, xx] = bbox[b, a, :, y, x]
+                                    bbox[b, a, 4, yy, xx] = ob - 0.2 * (abs(dy) + abs(dx)) - 0.1 * rng.random()
+                                bbox[b, a, 0, yy, xx] = -3.0 * dx
+                                bbox[b, a, 1, yy, xx] = -3.0 * dy
+                    if regime == "mixed" and rng.random() < 0.6 and x + 1 < nw:
+                        # a near-duplicate in the neighbouring cell: same class, same size,
+                        # centre pulled back towards the original so the IoU is high
+                        bbox[b, a, :, y, x + 1] = bbox[b, a, :, y, x]
+                        bbox[b, a, 0, y, x] = 2.0; bbox[b, a, 0, y, x + 1] = -2.0
+                        bbox[b, a, 2:4, y, x] = 0.7; bbox[b, a, 2:4, y, x + 1] = 0.7
+                        bbox[b, a, 4, y, x + 1] = ob - 0.5
+        ys = (np.arange(oh, dtype=np.float32) + 0.5) / oh
+        xs = (np.arange(ow, dtype=np.float32) + 0.5) / ow
+        orien = np.empty((batch, num_anchors, 2, oh, ow), dtype=np.float32)
+        for b in range(batch):
+            for a in range(num_anchors):
+                cx, cy = rng.random(2)
+                s = 2.0 + 6.0 * rng.random()
+                orien[b, a, 0] = (cx - xs)[None, :] * s + 0.3 * rng.standard_normal((oh, ow), dtype=np.float32)
+                orien[b, a, 1] = (cy - ys)[:, None] * s + 0.3 * rng.standard_normal((oh, ow), dtype=np.float32)
+        out.append((torch.from_numpy(bbox.reshape(batch, num_anchors * per_anchor, nh, nw).copy()),
+                    torch.from_numpy(orien.reshape(batch, num_anchors * 2, oh, ow).copy())))
+    return tuple(out)

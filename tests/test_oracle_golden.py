@@ -1,0 +1,104 @@
+"""CPU: pin the oracle against fixtures generated from the real reference.
+
+tests/golden/*.npz were written by tools/gen_golden.py, which imports /root/reference (model,
+postprocess, and the reference's own nms_cpu.cpp compiled into oracle/_ref).  Nothing here
+reads /root/reference.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_files, post_cfg
+from oracle import orienmask_ref as R
+from orienmask_amd import synth
+
+
+def unpack_masks(packed, shape):
+    shape = tuple(int(s) for s in shape)
+    if shape[0] == 0:
+        return np.zeros(shape, dtype=bool)
+    bits = np.unpackbits(packed, axis=1)[:, :shape[1] * shape[2]]
+    return bits.reshape(shape).astype(bool)
+
+
+def _post_oracle(size):
+    pc = post_cfg(size)
+    return R.PostProcessOracle(pc["grid_size"], pc["image_size"], pc["anchors"], pc["anchor_mask"], pc["num_classes"],
+                               conf_thresh=pc["conf_thresh"], nms_thresh=0.5, nms_pre=pc["nms_pre"],
+                               nms_post=pc["nms_post"], orien_thresh=pc["orien_thresh"]), pc
+
+
+def test_nms_known_answers():
+    kat = np.load(os.path.join(GOLDEN, "nms_kat.npz"))
+    names = sorted(k[:-5] for k in kat.files if k.endswith("_keep"))
+    assert len(names) >= 12
+    for name in names:
+        dets = torch.from_numpy(kat[name + "_dets"]); cats = torch.from_numpy(kat[name + "_cats"])
+        thr = float(kat[name + "_thr"])
+        _, _, keep = R.batched_nms(dets, cats, thr)
+        assert keep.numpy().tolist() == kat[name + "_keep"].tolist(), name
+        plain = R.nms_cpu(dets, thr)
+        assert plain.numpy().tolist() == kat[name + "_keep_plain"].tolist(), name
+        # the numpy restatement agrees with the C one
+        assert R.nms_numpy(dets.numpy(), thr).tolist() == plain.numpy().tolist(), name
+
+
+@pytest.mark.parametrize("fname", golden_files("post_"))
+def test_postprocess_matches_reference_bit_exact(fname):
+    g = np.load(os.path.join(GOLDEN, fname))
+    size = tuple(int(v) for v in g["size"]); batch = int(g["batch"])
+    post, pc = _post_oracle(size)
+    heads = synth.synth_heads(int(g["seed"]), batch, pc["grid_size"], regime=str(g["regime"]))
+    res = post(heads)
+    assert len(res) == batch
+    for b, r in enumerate(res):
+        assert np.array_equal(r["bbox"].numpy(), g["bbox%d" % b]), (fname, b)
+        assert np.array_equal(r["cls"].numpy(), g["cls%d" % b]), (fname, b)
+        want = unpack_masks(g["mask%d" % b], g["maskshape%d" % b])
+        assert np.array_equal(r["mask"].numpy(), want), (fname, b)
+
+
+@pytest.mark.parametrize("fname", golden_files("fwd_"))
+def test_forward_matches_reference(fname):
+    g = np.load(os.path.join(GOLDEN, fname))
+    size = tuple(int(v) for v in g["size"]); batch = int(g["batch"])
+    if size[0] > 200 and os.environ.get("OM_FAST_TESTS"):
+        pytest.skip("544x544 CPU forward skipped under OM_FAST_TESTS")
+    sd = synth.synth_state_dict(int(g["wseed"]), obj_bias=float(g["obj_bias"]), head_gain=float(g["head_gain"]))
+    x = synth.synth_image_batch(int(g["xseed"]), batch, size[0], size[1])
+    out, feats = R.forward(sd, x, return_features=True)
+    tensors = dict(bbox32=out[0][0], bbox16=out[1][0], bbox8=out[2][0],
+                   oriens=torch.cat([out[0][1], out[1][1], out[2][1]], 1),
+                   x32=feats["x32"], x16=feats["x16"], x8=feats["x8"], x4=feats["x4"])
+    for k, t in tensors.items():
+        assert list(t.shape) == g[k + "_shape"].tolist(), k
+        flat = t.reshape(-1)
+        samp = flat[torch.from_numpy(g[k + "_idx"])].numpy()
+        # same torch CPU primitives, same layouts -> identical bits
+        assert np.array_equal(samp, g[k + "_samples"]), k
+        assert abs(flat.double().sum().item() - g[k + "_sum"][0]) <= 1e-9 * max(1.0, g[k + "_sum"][1]), k
+        if k in g.files:
+            assert np.array_equal(t.numpy(), g[k]), k
+    post, _ = _post_oracle(size)
+    for b, r in enumerate(post(out)):
+        assert np.array_equal(r["bbox"].numpy(), g["bbox_det%d" % b])
+        assert np.array_equal(r["cls"].numpy(), g["cls_det%d" % b])
+        assert np.array_equal(r["mask"].numpy(), unpack_masks(g["mask%d" % b], g["maskshape%d" % b]))
+
+
+def test_bilinear_restatement_matches_torch():
+    """The HIP mask kernel's evaluation order vs F.interpolate: bit-identical with this torch
+    build's CPU kernel; never more than a few ulps on any other."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    p = rng.standard_normal((24, 40), dtype=np.float32)
+    want = torch.nn.functional.interpolate(torch.from_numpy(p)[None, None], scale_factor=4.0, mode="bilinear",
+                                           align_corners=False)[0, 0].numpy()
+    got = R.bilinear_x4_restated(p)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= 4 * np.finfo(np.float32).eps * np.max(np.abs(p))
+    mism = int((got != want).sum())
+    if mism:
+        import warnings
+        warnings.warn("bilinear restatement differs from torch in %d of %d pixels (<= 4 ulp)" % (mism, want.size))

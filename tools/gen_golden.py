@@ -1,0 +1,184 @@
+"""Generate tests/golden/*.npz by running the REAL reference from /root/reference.
+
+Runs ONLY in the build container (the reference does not exist on the GPU box and never
+travels).  The fixtures are data: seeds, inputs and the reference's outputs.  Weights and
+head tensors are regenerated from seeds by orienmask_amd.synth, so the files stay small.
+
+Recipe: never write bytecode into /root/reference; stub the
+reference's unavailable imports (torchsummary, pycocotools); inject the reference's own
+nms_cpu.cpp, compiled by oracle/build_ref.py, as eval.nms_cpu; eval.nms_cuda is an empty
+stub that CPU tensors never reach.
+
+    python tools/gen_golden.py            # writes tests/golden/
+"""
+import functools
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from orienmask_amd import synth  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+ANCHORS_YOLOV4 = [[12, 16], [19, 36], [40, 28], [36, 75], [76, 55], [72, 146], [142, 110], [192, 243], [459, 401]]
+ANCHOR_MASK = [[6, 7, 8], [3, 4, 5], [0, 1, 2]]
+
+
+def import_reference():
+    for name in ("torchsummary", "pycocotools", "pycocotools.mask", "pycocotools.coco", "pycocotools.cocoeval"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["pycocotools.coco"].COCO = object
+    sys.modules["pycocotools.cocoeval"].COCOeval = object
+    sys.path.insert(0, os.path.join(REPO, "oracle", "_ref"))
+    import nms_cpu_ref
+    sys.modules["eval.nms_cpu"] = nms_cpu_ref
+    sys.modules["eval.nms_cuda"] = types.ModuleType("eval.nms_cuda")
+    sys.path.insert(0, "/root/reference")
+    import config as ref_config
+    import model as ref_model
+    import eval as ref_eval
+    import eval.function as ref_function
+    ref_eval.nms_cpu = nms_cpu_ref
+    return ref_config, ref_model, ref_eval, ref_function
+
+
+def pack_masks(m):
+    m = np.asarray(m, dtype=np.uint8)
+    return np.packbits(m.reshape(m.shape[0], int(np.prod(m.shape[1:]))), axis=1)
+
+
+def digest(t, nsamp=64):
+    a = t.detach().cpu().double().reshape(-1)
+    idx = torch.linspace(0, a.numel() - 1, nsamp).long()
+    return np.array([a.sum().item(), a.abs().sum().item()]), a[idx].float().numpy(), idx.numpy()
+
+
+def post_cfg(size_hw):
+    h, w = size_hw
+    return dict(grid_size=[[h // 32, w // 32], [h // 16, w // 16], [h // 8, w // 8]], image_size=[h, w],
+                anchors=ANCHORS_YOLOV4, anchor_mask=ANCHOR_MASK, num_classes=80, conf_thresh=0.005,
+                nms_pre=400, nms_post=100, orien_thresh=0.3)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    cfg, rmodel, reval, rfunc = import_reference()
+    torch.set_num_threads(8)
+
+    # ---------------------------------------------------------------- G4: NMS known answers
+    nms_cases = {}
+    rng = np.random.Generator(np.random.PCG64(77))
+
+    def run_nms(name, dets, cats, thr=0.5):
+        d = torch.from_numpy(np.asarray(dets, dtype=np.float32).reshape(-1, 5))
+        c = torch.from_numpy(np.asarray(cats, dtype=np.int64).reshape(-1))
+        kd, kc, keep = rfunc.batched_nms(d, c, threshold=thr)
+        nms_cases[name + "_dets"] = d.numpy(); nms_cases[name + "_cats"] = c.numpy()
+        nms_cases[name + "_thr"] = np.float32(thr); nms_cases[name + "_keep"] = keep.numpy()
+        # plain (un-batched) nms on the same boxes through the native entry point
+        nms_cases[name + "_keep_plain"] = sys.modules["eval.nms_cpu"].nms(d, thr).numpy() if d.shape[0] else np.zeros(0, np.int64)
+
+    run_nms("empty", np.zeros((0, 5)), np.zeros(0))
+    run_nms("single", [[0.5, 0.5, 0.2, 0.2, 0.9]], [3])
+    # IoU exactly 0.5: boxes (0,0,2,1)-(1,0,2,1) shifted by 2/3 ... use w=3: overlap 2 of union 4
+    run_nms("iou_half", [[1.5, 0.5, 3.0, 1.0, 0.9], [2.5, 0.5, 3.0, 1.0, 0.8], [8.0, 0.5, 3.0, 1.0, 0.7]], [0, 0, 0])
+    run_nms("iou_half_strict", [[1.5, 0.5, 3.0, 1.0, 0.9], [2.5, 0.5, 3.0, 1.0, 0.8]], [0, 0], thr=0.5000001)
+    run_nms("cross_class", [[0.5, 0.5, 0.4, 0.4, 0.9], [0.5, 0.5, 0.4, 0.4, 0.8], [0.52, 0.5, 0.4, 0.4, 0.7]], [1, 2, 1])
+    run_nms("score_ties", [[0.5, 0.5, 0.4, 0.4, 0.5], [0.51, 0.5, 0.4, 0.4, 0.5], [0.9, 0.9, 0.1, 0.1, 0.5],
+                           [0.52, 0.5, 0.4, 0.4, 0.5]], [0, 0, 0, 0])
+    for n in (63, 64, 65, 200, 400):
+        ctr = rng.random((n, 2)) * 0.8 + 0.1
+        wh = rng.random((n, 2)) * 0.25 + 0.03
+        sc = rng.random((n, 1))
+        run_nms("rand%d" % n, np.concatenate([ctr, wh, sc], 1), rng.integers(0, 4, n))
+    # clustered: many near-duplicates
+    base = rng.random((20, 4)) * np.array([0.6, 0.6, 0.2, 0.2]) + np.array([0.2, 0.2, 0.1, 0.1])
+    dup = np.repeat(base, 15, 0) + rng.standard_normal((300, 4)) * 0.01
+    run_nms("clustered300", np.concatenate([dup, rng.random((300, 1))], 1), rng.integers(0, 2, 300))
+    np.savez_compressed(os.path.join(OUT, "nms_kat.npz"), **nms_cases)
+    print("nms_kat: %d cases" % (len([k for k in nms_cases if k.endswith("_keep")])))
+
+    # ---------------------------------------------------------------- G3: postprocess on synthetic heads
+    post_cases = [
+        ("p544_mixed_b2", (544, 544), 2, "mixed", 11),
+        ("p544_dense_b1", (544, 544), 1, "dense", 12),
+        ("p544_clustered_b1", (544, 544), 1, "clustered", 13),
+        ("p544_sparse_b2", (544, 544), 2, "sparse", 14),
+        ("p544_sparse_many_b1", (544, 544), 1, "sparse_many", 15),
+        ("p544_empty_b1", (544, 544), 1, "empty", 16),
+        ("p96_mixed_b3", (96, 96), 3, "mixed", 17),
+        ("p96_dense_b2", (96, 96), 2, "dense", 18),
+        ("p96_clustered_b2", (96, 96), 2, "clustered", 19),
+        ("p160x128_mixed_b2", (160, 128), 2, "mixed", 20),
+        ("p160x128_sparse_b2", (160, 128), 2, "sparse", 21),
+        ("p160x128_sparse_many_b2", (160, 128), 2, "sparse_many", 22),
+    ]
+    for name, size, batch, regime, seed in post_cases:
+        pc = post_cfg(size)
+        post = reval.OrienMaskYOLOPostProcess(nms_func=functools.partial(rfunc.batched_nms, threshold=0.5), **pc)
+        heads = synth.synth_heads(seed, batch, pc["grid_size"], regime=regime)
+        with torch.no_grad():
+            res = post(heads)
+        rec = dict(size=np.array(size), batch=np.int64(batch), seed=np.int64(seed), regime=np.array(regime))
+        for b, r in enumerate(res):
+            rec["bbox%d" % b] = r["bbox"].numpy()
+            rec["cls%d" % b] = r["cls"].numpy()
+            rec["mask%d" % b] = pack_masks(r["mask"].numpy())
+            rec["maskshape%d" % b] = np.array(r["mask"].shape)
+        np.savez_compressed(os.path.join(OUT, "post_%s.npz" % name), **rec)
+        print(name, [int(r["bbox"].shape[0]) for r in res],
+              "%.0f KB" % (os.path.getsize(os.path.join(OUT, "post_%s.npz" % name)) / 1024))
+
+    # ---------------------------------------------------------------- G1/G2/G5: forward (+ end to end)
+    mcfg = dict(cfg.orienmask_yolo_coco_544_anchor4_fpn_plus_infer["model"])
+    mcfg.pop("type"); mcfg["pretrained"] = None
+    net = rmodel.OrienMaskYOLOFPNPlus(**mcfg).eval()
+    fwd_cases = [
+        ("f96_b2", 1, (96, 96), 2, 21, -22.0),
+        ("f160x128_b1", 2, (160, 128), 1, 22, -16.0),
+        ("f544_b1", 3, (544, 544), 1, 23, -16.0),
+    ]
+    for name, wseed, size, batch, xseed, obj_bias in fwd_cases:
+        sd = synth.synth_state_dict(wseed, obj_bias=obj_bias, head_gain=4.0)
+        missing = net.load_state_dict(sd, strict=True)       # proves the 524 keys line up
+        x = synth.synth_image_batch(xseed, batch, size[0], size[1])
+        with torch.no_grad():
+            feats = {}
+            x32, x16, x8, x4 = net.backbone(x)
+            feats.update(x32=x32, x16=x16, x8=x8, x4=x4)
+            out = net(x)
+        rec = dict(size=np.array(size), batch=np.int64(batch), wseed=np.int64(wseed), xseed=np.int64(xseed),
+                   obj_bias=np.float32(obj_bias), head_gain=np.float32(4.0))
+        tensors = dict(bbox32=out[0][0], bbox16=out[1][0], bbox8=out[2][0],
+                       oriens=torch.cat([out[0][1], out[1][1], out[2][1]], 1), **feats)
+        full = size[0] <= 160
+        for k, t in tensors.items():
+            s, samp, idx = digest(t)
+            rec[k + "_sum"] = s; rec[k + "_samples"] = samp; rec[k + "_idx"] = idx
+            rec[k + "_shape"] = np.array(t.shape); rec[k + "_absmax"] = np.float32(t.abs().max().item())
+            if full and k in ("bbox32", "bbox16", "bbox8", "oriens"):
+                rec[k] = t.numpy()
+        # end to end through the reference postprocess
+        pc = post_cfg(size)
+        post = reval.OrienMaskYOLOPostProcess(nms_func=functools.partial(rfunc.batched_nms, threshold=0.5), **pc)
+        with torch.no_grad():
+            res = post(out)
+        for b, r in enumerate(res):
+            rec["bbox_det%d" % b] = r["bbox"].numpy(); rec["cls_det%d" % b] = r["cls"].numpy()
+            rec["mask%d" % b] = pack_masks(r["mask"].numpy()); rec["maskshape%d" % b] = np.array(r["mask"].shape)
+        np.savez_compressed(os.path.join(OUT, "fwd_%s.npz" % name), **rec)
+        print(name, {k: float(rec[k + "_absmax"]) for k in ("x4", "x32", "bbox32", "bbox8", "oriens")},
+              [int(r["bbox"].shape[0]) for r in res],
+              "%.0f KB" % (os.path.getsize(os.path.join(OUT, "fwd_%s.npz" % name)) / 1024))
+
+
+if __name__ == "__main__":
+    main()
