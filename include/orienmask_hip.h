@@ -1,0 +1,126 @@
+/* orienmask_hip.h -- C ABI of the MI355X (gfx950) OrienMask inference hot path.
+ *
+ * One shared library, liborienmask_hip.so, plain pointers and sizes only (no torch types).
+ * Every device buffer is allocated by the caller (the Python host passes
+ * torch-ROCm tensor.data_ptr()); the library never allocates device memory on the hot path
+ * and launches only on the stream it is handed.  All functions return 0 on success or a
+ * negative OM_E* code; om_last_error() holds the message (thread-local).  No exceptions
+ * cross this boundary.
+ *
+ * What each entry point replaces in the reference (/root/reference):
+ *   om_model_* / om_forward        OrienMaskYOLOFPNPlus.__init__/forward
+ *                                  model/orienmask_yolo_fpnplus.py:9-90 (+ model/base.py:104-137,
+ *                                  model/backbone/darknet.py:6-54), i.e. what trainer/tester.py:39-40
+ *                                  and infer.py:154-155 call as `model(image)`
+ *   om_postprocess                 OrienMaskYOLOPostProcess.apply
+ *                                  eval/orienmask_yolo_postprocess.py:66-166, called at
+ *                                  trainer/tester.py:43-44 and infer.py:156
+ *   om_nms                         the pybind export `nms(dets[n,5], threshold) -> keep`
+ *                                  eval/src/nms_cpu.cpp:65-75 / eval/src/nms_cuda.cpp:8-17, called
+ *                                  from eval/function.py:69-72,98-101
+ *   om_conv2d                      one ConvBNRelu (model/base.py:104-137); exported so parity tests
+ *                                  can check a single layer against torch
+ */
+#ifndef ORIENMASK_HIP_H
+#define ORIENMASK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OM_VERSION 100          /* 0.1.0 */
+
+#define OM_OK 0
+#define OM_EINVAL (-1)          /* bad argument (null pointer, shape not supported) */
+#define OM_ESTATE (-2)          /* call order (forward before load_weights, ...) */
+#define OM_ENOMEM (-3)          /* caller-provided workspace too small */
+#define OM_EHIP (-4)            /* a HIP runtime call failed; see om_last_error() */
+
+#define OM_MAX_SCALES 3
+#define OM_MAX_ANCHORS 9
+
+typedef struct om_model om_model;
+typedef void* om_stream;        /* a hipStream_t (torch.cuda.current_stream().cuda_stream) */
+
+/* Layout of one convolution inside the packed weight blob (all offsets in floats).
+ * weights: [cout_pad][ksize*ksize][cin] (OHWI, rows >= cout zero);  scale/shift: [cout_pad]
+ * y = conv(x) * scale + shift, then LeakyReLU(0.1) if leaky (BatchNorm folded by the host). */
+typedef struct om_layer_info {
+    char name[64];              /* reference module prefix, e.g. "backbone.conv4.3.conv.1" */
+    int32_t cin, cout, cout_pad, ksize, stride;
+    int32_t has_bn;             /* 1: conv(bias=False)+BN+leaky;  0: conv(bias=True) only */
+    int32_t leaky;
+    int64_t w_off, scale_off, shift_off;
+} om_layer_info;
+
+/* Constants of OrienMaskYOLOPostProcess.__init__ (eval/orienmask_yolo_postprocess.py:9-37). */
+typedef struct om_post_cfg {
+    int32_t num_scales;                         /* 3 */
+    int32_t grid_h[OM_MAX_SCALES], grid_w[OM_MAX_SCALES];   /* coarse -> fine, e.g. 17,34,68 */
+    int32_t image_h, image_w;                   /* 544, 544; orientation maps are image/4 */
+    int32_t anchors_per_scale;                  /* 3 */
+    float anchor_w[OM_MAX_ANCHORS], anchor_h[OM_MAX_ANCHORS];    /* pixels, index = anchor id */
+    int32_t anchor_mask[OM_MAX_SCALES][3];      /* anchor ids used by each scale */
+    int32_t num_classes;                        /* 80 */
+    float conf_thresh;                          /* 0.005 */
+    float nms_thresh;                           /* 0.5, suppress when IoU >= thresh */
+    int32_t nms_pre, nms_post;                  /* 400, 100 */
+    float orien_thresh;                         /* 0.3 */
+    int32_t bbox_pix_stride;                    /* floats between pixels of the NHWC bbox heads
+                                                   (256 for om_forward's outputs) */
+} om_post_cfg;
+
+int om_version(void);
+const char* om_last_error(void);
+
+/* ---- model ------------------------------------------------------------------------------- */
+int om_model_create(om_model** out, int num_anchors, int num_classes);
+void om_model_destroy(om_model* m);
+int om_model_num_layers(const om_model* m);
+int om_model_layer_info(const om_model* m, int index, om_layer_info* info);
+size_t om_model_weight_floats(const om_model* m);
+/* packed_dev: device pointer to the blob described by om_model_layer_info; it must stay alive
+ * (and unchanged) for as long as om_forward is called.  dtype: 0 = float32. */
+int om_model_load_weights(om_model* m, const void* packed_dev, size_t bytes, int dtype);
+
+size_t om_forward_workspace_bytes(const om_model* m, int B, int H, int W);
+/* x: [B,3,H,W] float32 NCHW, H and W multiples of 32.
+ * bbox32/16/8: [B, H/s, W/s, 256] float32 NHWC, channels [0, A*(5+C)) valid  (the caller views
+ *              them as [B, A*(5+C), H/s, W/s] with strides)
+ * oriens:      [B, 6*A, H/4, W/4] float32 NCHW contiguous */
+int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, float* bbox16, float* bbox8,
+               float* oriens, void* workspace, size_t ws_bytes, om_stream stream);
+
+/* ---- one convolution (unit-test entry) ----------------------------------------------------- */
+/* in: [B,H,W,cin] NHWC (pixel stride in_pix_stride floats); w/scale/shift as in om_layer_info;
+ * res: optional [B,Ho,Wo,cout] NHWC added after the activation; out: [B,Ho,Wo,cout] NHWC. */
+int om_conv2d(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* w,
+              const float* scale, const float* shift, int cout, int ksize, int stride, int leaky,
+              const float* res, int res_pix_stride, float* out, int out_pix_stride, om_stream stream);
+/* first layer: in [B,3,H,W] NCHW -> out [B,H,W,cout] NHWC, 3x3 stride 1. */
+int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale,
+                   const float* shift, int cout, float* out, om_stream stream);
+
+/* ---- postprocess -------------------------------------------------------------------------- */
+size_t om_postprocess_workspace_bytes(const om_post_cfg* cfg, int B);
+/* out_bbox [B,nms_post,5] (cx,cy,w,h normalised, score); out_cls [B,nms_post] int64;
+ * out_mask [B,nms_post,image_h,image_w] uint8 0/1 (rows >= out_count[b] are left untouched);
+ * out_count [B] int32; out_keep [B,nms_post] int32 position of each detection in the
+ * pre-NMS candidate list, may be NULL.  oriens as written by om_forward. */
+int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbox16, const float* bbox8,
+                   const float* oriens, int B, float* out_bbox, int64_t* out_cls, uint8_t* out_mask,
+                   int32_t* out_count, int32_t* out_keep, void* workspace, size_t ws_bytes, om_stream stream);
+
+/* ---- NMS (CPU-backend semantics of the reference: IoU >= thresh suppresses, corners from
+ *      cx +- w/2, keep returned in ascending input order; n <= 1024) ------------------------ */
+size_t om_nms_workspace_bytes(int n);
+int om_nms(const float* dets, int n, float thresh, int64_t* keep, int32_t* n_keep, void* workspace,
+           size_t ws_bytes, om_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORIENMASK_HIP_H */

@@ -1,0 +1,91 @@
+// First layer of DarkNet-53 for gfx950: 3x3 stride-1 conv 3 -> 32, BN + LeakyReLU fused,
+// reading the user's NCHW image and writing NHWC.
+//
+// Reference: backbone.conv1 = conv_bn_leaky(3, 32, 3, padding=1)
+// (/root/reference/model/backbone/darknet.py:20, /root/reference/model/base.py:104-137).
+//
+// K = 27 is too short for the matrix cores and the layer is HBM-bound (reads 12 B, writes
+// 128 B per pixel), so it runs on the vector ALUs:
+//   * workgroup = 32 x 8 output pixels; the 3 x 10 x 34 input patch (zero padded) is staged
+//     in LDS once, coalesced along x from the NCHW planes;
+//   * thread = (pixel column, 4 output channels); its 27 x 4 weights live in registers;
+//   * the 8 channel-quads of a pixel are 8 neighbouring lanes, so one wave store writes
+//     8 pixels x 128 B = 1 KiB contiguous NHWC.
+#include "om_common.h"
+
+namespace om {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int STEM_TX = 32, STEM_TY = 8, STEM_CO = 32;
+
+__global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, float* __restrict__ out,
+                                                        int H, int W) {
+    __shared__ float patch[3][STEM_TY + 2][STEM_TX + 2];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * STEM_TX, y0 = blockIdx.y * STEM_TY, b = blockIdx.z;
+    const float* img = in + (size_t)b * 3 * H * W;
+    for (int e = tid; e < 3 * (STEM_TY + 2) * (STEM_TX + 2); e += 256) {
+        const int c = e / ((STEM_TY + 2) * (STEM_TX + 2));
+        const int r = e - c * (STEM_TY + 2) * (STEM_TX + 2);
+        const int py = r / (STEM_TX + 2), px = r - py * (STEM_TX + 2);
+        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        float v = 0.f;
+        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = img[((size_t)c * H + gy) * W + gx];
+        patch[c][py][px] = v;
+    }
+    const int quad = tid & 7, px = tid >> 3;
+    // weights [cout][tap=(kh*3+kw)][ci=3] -> this thread's 4 output channels
+    f32x4 wr[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        wr[t][0] = w[(quad * 4 + 0) * 27 + t];
+        wr[t][1] = w[(quad * 4 + 1) * 27 + t];
+        wr[t][2] = w[(quad * 4 + 2) * 27 + t];
+        wr[t][3] = w[(quad * 4 + 3) * 27 + t];
+    }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + quad * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + quad * 4);
+    __syncthreads();
+#pragma unroll 2
+    for (int ty = 0; ty < STEM_TY; ++ty) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float v = patch[ci][ty + kh][px + kw];
+                    const f32x4 ww = wr[(kh * 3 + kw) * 3 + ci];
+                    acc[0] = fmaf(v, ww[0], acc[0]);
+                    acc[1] = fmaf(v, ww[1], acc[1]);
+                    acc[2] = fmaf(v, ww[2], acc[2]);
+                    acc[3] = fmaf(v, ww[3], acc[3]);
+                }
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = fmaf(acc[k], sc[k], sh[k]);
+            o[k] = v > 0.f ? v : v * 0.1f;
+        }
+        const int gy = y0 + ty, gx = x0 + px;
+        if (gy < H && gx < W)
+            *reinterpret_cast<f32x4*>(out + (((size_t)b * H + gy) * W + gx) * STEM_CO + quad * 4) = o;
+    }
+}
+
+int launch_conv_stem(const float* in_nchw, int B, int H, int W, const float* w, const float* scale,
+                     const float* shift, int cout, float* out_nhwc, hipStream_t stream) {
+    OM_REQUIRE(in_nchw && w && scale && shift && out_nhwc, OM_EINVAL, "stem: null pointer");
+    OM_REQUIRE(cout == STEM_CO, OM_EINVAL, "stem: cout=%d, only 32 supported", cout);
+    OM_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0, OM_EINVAL, "stem: bad shape B=%d H=%d W=%d", B, H, W);
+    dim3 grid((W + STEM_TX - 1) / STEM_TX, (H + STEM_TY - 1) / STEM_TY, B);
+    hipLaunchKernelGGL(conv_stem_kernel, grid, dim3(256), 0, stream, in_nchw, w, scale, shift, out_nhwc, H, W);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
+}  // namespace om

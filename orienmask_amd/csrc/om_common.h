@@ -1,0 +1,58 @@
+// Internal helpers shared by the host-side translation units of liborienmask_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/orienmask_hip.h"
+
+namespace om {
+
+void set_error(const char* fmt, ...);
+
+#define OM_CHECK_HIP(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            om::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return OM_EHIP;                                                             \
+        }                                                                               \
+    } while (0)
+
+#define OM_REQUIRE(cond, code, ...)                                                     \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            om::set_error(__VA_ARGS__);                                                 \
+            return (code);                                                              \
+        }                                                                               \
+    } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// One fused convolution launch.  Pointers already include any channel offset of a view
+// into a wider (concatenated) buffer; *_pix_stride is the float distance between pixels.
+struct ConvArgs {
+    const float* in;        // NHWC view [B,H,W,cin]
+    const float* w;         // [cout_pad][ks*ks][cin]
+    const float* scale;     // [cout_pad]
+    const float* shift;     // [cout_pad]
+    const float* res;       // optional NHWC view [B,Ho,Wo,cout], added after the activation
+    float* out;
+    int B, H, W, cin, in_pix_stride;
+    int Ho, Wo, cout, cout_pad;
+    int ks, stride;
+    int leaky;
+    int res_pix_stride;
+    int out_pix_stride;     // NHWC modes
+    int out_mode;           // 0: NHWC   1: NHWC, each output replicated up x up (nearest upsample)
+                            // 2: NCHW contiguous [B,cout,Ho,Wo]
+    int up;
+};
+
+int launch_conv_igemm(const ConvArgs& a, hipStream_t stream);
+int launch_conv_stem(const float* in_nchw, int B, int H, int W, const float* w, const float* scale,
+                     const float* shift, int cout, float* out_nhwc, hipStream_t stream);
+
+}  // namespace om

@@ -1,0 +1,308 @@
+// Host side of liborienmask_hip.so: the OrienMaskYOLOFPNPlus inference graph as a list of fused
+// convolution launches over NHWC buffers carved from one caller-provided workspace.
+//
+// The graph restates /root/reference/model/orienmask_yolo_fpnplus.py:9-90 and
+// /root/reference/model/backbone/darknet.py:18-54 (built here from the channel/stride rules,
+// not translated): DarkNet-53 stages 1/2/8/8/4, four 5-conv necks, two up-sampling routes,
+// three 2-conv box heads, four skip projections and the 6-conv orientation head.
+//
+// MI355X-first decisions:
+//   * every tensor is NHWC; torch.cat never runs: each concat is ONE buffer and its producers
+//     write their channel slice (route/skip outputs are written already nearest-upsampled,
+//     reference model/base.py:95-101); consumers read strided views;
+//   * residual adds, BatchNorm and LeakyReLU live in the conv epilogue (conv_igemm.hip);
+//   * the three box heads are written NHWC with a 256-float pixel stride (what the decode kernel
+//     wants), the orientation head NCHW (what the mask kernel wants);
+//   * no allocation, no synchronisation: ~90 launches on the caller's stream.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "om_common.h"
+
+namespace om {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+enum : int { BUF_INPUT = -1, BUF_BBOX32 = -2, BUF_BBOX16 = -3, BUF_BBOX8 = -4, BUF_ORIENS = -5 };
+constexpr int HEAD_PIX_STRIDE = 256;
+
+struct BufDef {
+    int div;    // spatial size = image / div
+    int C;      // floats per pixel
+};
+
+struct View {
+    int buf;
+    int ch_off;
+};
+
+struct LayerDef {
+    om_layer_info info;
+    View in, out, res;
+    bool has_res = false;
+    bool stem = false;
+    int in_div = 1;      // spatial divisor of the input
+    int out_mode = 0, up = 1;
+};
+
+}  // namespace om
+
+struct om_model {
+    int num_anchors = 0, num_classes = 0;
+    std::vector<om::BufDef> bufs;
+    std::vector<om::LayerDef> layers;
+    size_t weight_floats = 0;
+    const float* weights = nullptr;
+
+    int new_buf(int div, int C) {
+        bufs.push_back({div, C});
+        return (int)bufs.size() - 1;
+    }
+    int pix_stride(int buf) const { return buf >= 0 ? bufs[buf].C : om::HEAD_PIX_STRIDE; }
+
+    // Appends one convolution and reserves its slice of the weight blob.
+    void add(const std::string& name, int cin, int cout, int ks, int stride, bool bn, om::View in, int in_div,
+             om::View out, const om::View* res = nullptr, int out_mode = 0, int up = 1, bool stem = false) {
+        om::LayerDef L;
+        std::memset(&L.info, 0, sizeof(L.info));
+        std::snprintf(L.info.name, sizeof(L.info.name), "%s", name.c_str());
+        L.info.cin = cin; L.info.cout = cout; L.info.cout_pad = om::round_up(cout, 32);
+        L.info.ksize = ks; L.info.stride = stride; L.info.has_bn = bn ? 1 : 0; L.info.leaky = bn ? 1 : 0;
+        L.info.w_off = (int64_t)weight_floats;
+        weight_floats += (size_t)L.info.cout_pad * ks * ks * cin;
+        weight_floats = om::align_up(weight_floats, 4);
+        L.info.scale_off = (int64_t)weight_floats; weight_floats += L.info.cout_pad;
+        L.info.shift_off = (int64_t)weight_floats; weight_floats += L.info.cout_pad;
+        L.in = in; L.out = out; L.in_div = in_div; L.out_mode = out_mode; L.up = up; L.stem = stem;
+        if (res) { L.res = *res; L.has_res = true; }
+        layers.push_back(L);
+    }
+
+    // conv1x1 / conv3x3 (+BN+leaky) into a fresh buffer; returns the output view
+    om::View cbl(const std::string& name, om::View in, int cin, int cout, int ks, int div) {
+        om::View o{new_buf(div, cout), 0};
+        add(name, cin, cout, ks, 1, true, in, div, o);
+        return o;
+    }
+
+    om::View neck(const std::string& prefix, om::View in, int cin, int cout, int div) {
+        om::View v = cbl(prefix + ".0", in, cin, cout, 1, div);
+        v = cbl(prefix + ".1", v, cout, cout * 2, 3, div);
+        v = cbl(prefix + ".2", v, cout * 2, cout, 1, div);
+        v = cbl(prefix + ".3", v, cout, cout * 2, 3, div);
+        return cbl(prefix + ".4", v, cout * 2, cout, 1, div);
+    }
+
+    void build() {
+        using om::View;
+        const int A = num_anchors;
+        // concat buffers: [route | backbone feature], [skip32 | skip16 | skip8 | skip4]
+        const int cat16 = new_buf(16, 256 + 512);
+        const int cat8 = new_buf(8, 128 + 256);
+        const int cat4 = new_buf(4, 4 * 64);
+
+        // ---- DarkNet-53
+        View cur{new_buf(1, 32), 0};
+        add("backbone.conv1", 3, 32, 3, 1, true, View{om::BUF_INPUT, 0}, 1, cur, nullptr, 0, 1, true);
+        const int nblocks[7] = {0, 0, 1, 2, 8, 8, 4};
+        int ch = 32, div = 1;
+        View x4{}, x8{}, x16{}, x32{};
+        for (int idx = 2; idx <= 6; ++idx) {
+            const std::string stage = "backbone.conv" + std::to_string(idx);
+            View down{new_buf(div * 2, ch * 2), 0};
+            add(stage + ".0", ch, ch * 2, 3, 2, true, cur, div, down);
+            div *= 2;
+            cur = down;
+            for (int j = 1; j <= nblocks[idx]; ++j) {
+                const std::string blk = stage + "." + std::to_string(j) + ".conv.";
+                View mid = cbl(blk + "0", cur, ch * 2, ch, 1, div);
+                View dst{};
+                const bool last = j == nblocks[idx];
+                if (last && idx == 4) dst = View{cat8, 128};
+                else if (last && idx == 5) dst = View{cat16, 256};
+                else dst = View{new_buf(div, ch * 2), 0};
+                add(blk + "1", ch, ch * 2, 3, 1, true, mid, div, dst, &cur);
+                cur = dst;
+            }
+            if (idx == 3) x4 = cur;
+            if (idx == 4) x8 = cur;
+            if (idx == 5) x16 = cur;
+            if (idx == 6) x32 = cur;
+            ch *= 2;
+        }
+        (void)x8; (void)x16;
+
+        // ---- necks and routes (fpnplus.py:77-79)
+        View n32 = neck("neck32", x32, 1024, 512, 32);
+        add("route32.0", 512, 256, 1, 1, true, n32, 32, View{cat16, 0}, nullptr, 1, 2);
+        View n16 = neck("neck16", View{cat16, 0}, 768, 256, 16);
+        add("route16.0", 256, 128, 1, 1, true, n16, 16, View{cat8, 0}, nullptr, 1, 2);
+        View n8 = neck("neck8", View{cat8, 0}, 384, 128, 8);
+
+        // ---- box heads (fpnplus.py:81-83)
+        const int bbox_dim = A * (5 + num_classes);
+        struct { const char* name; View in; int c; int div; int out; } heads[3] = {
+            {"bbox_head32", n32, 512, 32, om::BUF_BBOX32},
+            {"bbox_head16", n16, 256, 16, om::BUF_BBOX16},
+            {"bbox_head8", n8, 128, 8, om::BUF_BBOX8}};
+        for (auto& h : heads) {
+            View t = cbl(std::string(h.name) + ".0", h.in, h.c, h.c * 2, 3, h.div);
+            add(std::string(h.name) + ".1", h.c * 2, bbox_dim, 1, 1, false, t, h.div, View{h.out, 0});
+        }
+
+        // ---- orientation branch (fpnplus.py:85-88)
+        add("skip32.0", 512, 64, 1, 1, true, n32, 32, View{cat4, 0}, nullptr, 1, 8);
+        add("skip16.0", 256, 64, 1, 1, true, n16, 16, View{cat4, 64}, nullptr, 1, 4);
+        add("skip8.0", 128, 64, 1, 1, true, n8, 8, View{cat4, 128}, nullptr, 1, 2);
+        add("skip4", 128, 64, 1, 1, true, x4, 4, View{cat4, 192});
+        View o = neck("neck4", View{cat4, 0}, 256, 128, 4);
+        o = cbl("orien_head.0", o, 128, 256, 3, 4);
+        o = cbl("orien_head.1", o, 256, 128, 1, 4);
+        o = cbl("orien_head.2", o, 128, 256, 3, 4);
+        o = cbl("orien_head.3", o, 256, 128, 1, 4);
+        o = cbl("orien_head.4", o, 128, 256, 3, 4);
+        add("orien_head.5", 256, A * 6, 1, 1, false, o, 4, View{om::BUF_ORIENS, 0}, nullptr, 2, 1);
+    }
+
+    size_t buf_floats(int i, int B, int H, int W) const {
+        return (size_t)B * (H / bufs[i].div) * (W / bufs[i].div) * bufs[i].C;
+    }
+};
+
+extern "C" {
+
+int om_version(void) { return OM_VERSION; }
+const char* om_last_error(void) { return om::g_err; }
+
+int om_model_create(om_model** out, int num_anchors, int num_classes) {
+    OM_REQUIRE(out, OM_EINVAL, "om_model_create: out is null");
+    OM_REQUIRE(num_anchors >= 1 && num_anchors <= 3 && num_classes >= 1 &&
+                   num_anchors * (5 + num_classes) <= om::HEAD_PIX_STRIDE,
+               OM_EINVAL, "om_model_create: unsupported head (anchors=%d classes=%d)", num_anchors, num_classes);
+    om_model* m = new om_model();
+    m->num_anchors = num_anchors;
+    m->num_classes = num_classes;
+    m->build();
+    *out = m;
+    return OM_OK;
+}
+
+void om_model_destroy(om_model* m) { delete m; }
+
+int om_model_num_layers(const om_model* m) { return m ? (int)m->layers.size() : OM_EINVAL; }
+
+int om_model_layer_info(const om_model* m, int index, om_layer_info* info) {
+    OM_REQUIRE(m && info, OM_EINVAL, "om_model_layer_info: null argument");
+    OM_REQUIRE(index >= 0 && index < (int)m->layers.size(), OM_EINVAL, "om_model_layer_info: index %d", index);
+    *info = m->layers[index].info;
+    return OM_OK;
+}
+
+size_t om_model_weight_floats(const om_model* m) { return m ? m->weight_floats : 0; }
+
+int om_model_load_weights(om_model* m, const void* packed_dev, size_t bytes, int dtype) {
+    OM_REQUIRE(m && packed_dev, OM_EINVAL, "om_model_load_weights: null argument");
+    OM_REQUIRE(dtype == 0, OM_EINVAL, "om_model_load_weights: dtype %d not supported (0 = float32)", dtype);
+    OM_REQUIRE(bytes == m->weight_floats * sizeof(float), OM_EINVAL,
+               "om_model_load_weights: blob is %zu bytes, the graph needs %zu", bytes, m->weight_floats * sizeof(float));
+    OM_REQUIRE((reinterpret_cast<uintptr_t>(packed_dev) & 15) == 0, OM_EINVAL, "om_model_load_weights: blob not 16-byte aligned");
+    m->weights = static_cast<const float*>(packed_dev);
+    return OM_OK;
+}
+
+size_t om_forward_workspace_bytes(const om_model* m, int B, int H, int W) {
+    if (!m || B <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32) return 0;
+    size_t total = 0;
+    for (size_t i = 0; i < m->bufs.size(); ++i) total += om::align_up(m->buf_floats((int)i, B, H, W) * sizeof(float), 256);
+    return total;
+}
+
+int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, float* bbox16, float* bbox8,
+               float* oriens, void* workspace, size_t ws_bytes, om_stream stream_) {
+    OM_REQUIRE(m && x && bbox32 && bbox16 && bbox8 && oriens && workspace, OM_EINVAL, "om_forward: null argument");
+    OM_REQUIRE(m->weights, OM_ESTATE, "om_forward: call om_model_load_weights first");
+    OM_REQUIRE(B > 0 && H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, OM_EINVAL,
+               "om_forward: B=%d H=%d W=%d (H and W must be positive multiples of 32)", B, H, W);
+    OM_REQUIRE(ws_bytes >= om_forward_workspace_bytes(m, B, H, W), OM_ENOMEM,
+               "om_forward: workspace %zu bytes < %zu needed", ws_bytes, om_forward_workspace_bytes(m, B, H, W));
+    OM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, OM_EINVAL, "om_forward: workspace not 256-byte aligned");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+
+    std::vector<float*> base(m->bufs.size());
+    {
+        char* p = static_cast<char*>(workspace);
+        for (size_t i = 0; i < m->bufs.size(); ++i) {
+            base[i] = reinterpret_cast<float*>(p);
+            p += om::align_up(m->buf_floats((int)i, B, H, W) * sizeof(float), 256);
+        }
+    }
+    auto ptr_of = [&](const om::View& v) -> float* {
+        switch (v.buf) {
+            case om::BUF_BBOX32: return bbox32;
+            case om::BUF_BBOX16: return bbox16;
+            case om::BUF_BBOX8: return bbox8;
+            case om::BUF_ORIENS: return oriens;
+            default: return base[v.buf] + v.ch_off;
+        }
+    };
+
+    for (const om::LayerDef& L : m->layers) {
+        const om_layer_info& li = L.info;
+        const float* w = m->weights + li.w_off;
+        const float* scale = m->weights + li.scale_off;
+        const float* shift = m->weights + li.shift_off;
+        const int Hin = H / L.in_div, Win = W / L.in_div;
+        if (L.stem) {
+            int rc = om::launch_conv_stem(x, B, Hin, Win, w, scale, shift, li.cout, ptr_of(L.out), stream);
+            if (rc != OM_OK) return rc;
+            continue;
+        }
+        om::ConvArgs a;
+        a.in = ptr_of(L.in); a.w = w; a.scale = scale; a.shift = shift;
+        a.res = L.has_res ? ptr_of(L.res) : nullptr;
+        a.out = ptr_of(L.out);
+        a.B = B; a.H = Hin; a.W = Win; a.cin = li.cin; a.in_pix_stride = m->pix_stride(L.in.buf);
+        a.Ho = Hin / li.stride; a.Wo = Win / li.stride; a.cout = li.cout; a.cout_pad = li.cout_pad;
+        a.ks = li.ksize; a.stride = li.stride; a.leaky = li.leaky;
+        a.res_pix_stride = L.has_res ? m->pix_stride(L.res.buf) : 0;
+        a.out_pix_stride = m->pix_stride(L.out.buf);
+        a.out_mode = L.out_mode; a.up = L.up;
+        int rc = om::launch_conv_igemm(a, stream);
+        if (rc != OM_OK) {
+            char msg[512];
+            std::snprintf(msg, sizeof(msg), "%s", om::g_err);
+            om::set_error("layer %s: %s", li.name, msg);
+            return rc;
+        }
+    }
+    return OM_OK;
+}
+
+int om_conv2d(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* w, const float* scale,
+              const float* shift, int cout, int ksize, int stride, int leaky, const float* res, int res_pix_stride,
+              float* out, int out_pix_stride, om_stream stream) {
+    OM_REQUIRE(B > 0 && H > 0 && W > 0 && stride >= 1 && H % stride == 0 && W % stride == 0, OM_EINVAL,
+               "om_conv2d: bad shape");
+    om::ConvArgs a;
+    a.in = in; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.cin = cin; a.in_pix_stride = in_pix_stride;
+    a.Ho = H / stride; a.Wo = W / stride; a.cout = cout; a.cout_pad = om::round_up(cout, 32);
+    a.ks = ksize; a.stride = stride; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
+    a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1;
+    return om::launch_conv_igemm(a, static_cast<hipStream_t>(stream));
+}
+
+int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale, const float* shift,
+                   int cout, float* out, om_stream stream) {
+    return om::launch_conv_stem(in, B, H, W, w, scale, shift, cout, out, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

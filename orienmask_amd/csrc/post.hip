@@ -1,0 +1,660 @@
+// Postprocess of OrienMask on gfx950: box decode, confidence threshold, exact top-k, class-aware
+// greedy NMS and orientation-map mask assembly, with no host synchronisation.
+//
+// Restates OrienMaskYOLOPostProcess.apply (/root/reference/eval/orienmask_yolo_postprocess.py:66-166),
+// batched_nms (/root/reference/eval/function.py:77-103) and the CPU NMS backend
+// (/root/reference/eval/src/nms_cpu.cpp:4-63: corners cx +- w/2, area (x2-x1)*(y2-y1), suppress when
+// IoU >= threshold, keep reported in ascending input order).  The reference runs ~30 torch ops per
+// image with four host round trips (nonzero, two numel() branches, the CUDA NMS bit-matrix copy,
+// nms_kernel.cu:105-139) and materialises ~1 GB of temporaries per image; here it is three launches:
+//
+//   post_decode_kernel  grid (tiles, B)   conf = sigmoid(cls) * sigmoid(obj) for every
+//                       (candidate, class) pair; keys (float bits, 0 = below threshold) to the
+//                       workspace, per-tile pass counts, level-1 radix histogram.
+//   post_select_kernel  grid (B), 1024 thr  exact top-nms_pre by 3-level radix select on the key
+//                       bits (ties -> lowest pair index), index-ordered compaction, bitonic sort,
+//                       box decode of the <= nms_pre survivors, 64-bit suppression bit-matrix in LDS
+//                       (one u64 = one row segment of the reference's 64-wide CUDA tiling), serial
+//                       wave-level reduction, top-nms_post, per-detection mask constants.
+//   post_mask_kernel    grid (pixels/4096, B*nms_post)  bilinear x4 of the two orientation planes
+//                       of the detection's anchor evaluated on the fly + the two |P - c| < t tests;
+//                       16 pixels per thread, one 16-byte store each (the only HBM-heavy step).
+//
+// All comparisons that decide indices use IEEE fp32 operations in the reference's order; this file
+// is compiled with -ffp-contract=off and the only fused multiply-adds are the explicit fmaf calls of
+// the bilinear taps (the placement torch's CPU kernel compiles to; see oracle/orienmask_ref.py).
+#include "om_common.h"
+
+namespace om {
+
+constexpr int DEC_TILE = 2048;          // pairs per decode workgroup
+constexpr int SEL_THREADS = 1024;
+constexpr int SEL_MAXN = 512;           // nms_pre limit of the fused path (LDS bit-matrix 32 KiB)
+constexpr int L1_BINS = 2048;           // key >> 19
+constexpr int MASK_PX = 16;             // pixels per thread in the mask kernel
+
+struct PostParams {
+    om_post_cfg cfg;
+    const float* bbox[OM_MAX_SCALES];
+    const float* oriens;
+    int B;
+    int ncand, npairs, ntiles;
+    int cand_off[OM_MAX_SCALES + 1];
+    unsigned* keys;        // [B][ntiles*DEC_TILE]
+    int* tile_count;       // [B][ntiles]
+    unsigned* hist1;       // [B][L1_BINS]
+    float* det_par;        // [B][nms_post][8]
+    float* out_bbox;
+    int64_t* out_cls;
+    uint8_t* out_mask;
+    int32_t* out_count;
+    int32_t* out_keep;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// candidate index -> (scale, anchor slot, pixel)
+__device__ __forceinline__ void locate(const PostParams& p, int cand, int& s, int& a, int& pix) {
+    s = (cand >= p.cand_off[1]) + (cand >= p.cand_off[2]);
+    const int local = cand - p.cand_off[s];
+    const int hw = p.cfg.grid_h[s] * p.cfg.grid_w[s];
+    a = local / hw;
+    pix = local - a * hw;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode: postprocess.py:126-139 (confidence part) and :102 (threshold)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void post_decode_kernel(const PostParams p) {
+    __shared__ unsigned hist[L1_BINS];
+    __shared__ int wcnt[4];
+    const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x;
+    for (int i = tid; i < L1_BINS; i += 256) hist[i] = 0;
+    __syncthreads();
+    const int C = p.cfg.num_classes, per = 5 + C;
+    unsigned* keys = p.keys + (size_t)b * p.ntiles * DEC_TILE + (size_t)tile * DEC_TILE;
+    int cnt = 0;
+#pragma unroll 2
+    for (int j = 0; j < DEC_TILE / 256; ++j) {
+        const int pair = tile * DEC_TILE + j * 256 + tid;
+        unsigned key = 0;
+        if (pair < p.npairs) {
+            const int cand = pair / C, cls = pair - cand * C;
+            int s, a, pix;
+            locate(p, cand, s, a, pix);
+            const int hw = p.cfg.grid_h[s] * p.cfg.grid_w[s];
+            const float* q = p.bbox[s] + ((size_t)b * hw + pix) * p.cfg.bbox_pix_stride + a * per;
+            const float conf = sigmoidf_(q[5 + cls]) * sigmoidf_(q[4]);
+            if (conf > p.cfg.conf_thresh) {
+                key = __float_as_uint(conf);
+                atomicAdd(&hist[key >> 19], 1u);
+                ++cnt;
+            }
+        }
+        keys[j * 256 + tid] = key;
+    }
+    // workgroup total
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d);
+    if ((tid & 63) == 0) wcnt[tid >> 6] = cnt;
+    __syncthreads();
+    const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (tid == 0) p.tile_count[b * p.ntiles + tile] = total;
+    if (total) {
+        unsigned* g = p.hist1 + (size_t)b * L1_BINS;
+        for (int i = tid; i < L1_BINS; i += 256)
+            if (hist[i]) atomicAdd(&g[i], hist[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// workgroup helpers (1024 threads = 16 waves)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_scan_excl(int v, int* s_wave, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SEL_THREADS / 64; ++w) {
+        const int t = s_wave[w];
+        if (w < wave) off += t;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return off + x - v;
+}
+
+// Largest bin t with sum_{i >= t} hist[i] >= need; also the count strictly above it.
+// hist has 2 * SEL_THREADS bins at most (nbins <= 2048).  Results through s_res[0..1].
+__device__ __forceinline__ void find_bin_from_top(const unsigned* hist, int nbins, int need, int* s_wave,
+                                                  int* s_res) {
+    const int tid = threadIdx.x;
+    const int ba = nbins - 1 - 2 * tid, bb = ba - 1;
+    const int ha = ba >= 0 ? (int)hist[ba] : 0, hb = bb >= 0 ? (int)hist[bb] : 0;
+    int total;
+    const int excl = block_scan_excl(ha + hb, s_wave, total);
+    if (ba >= 0 && excl < need && excl + ha >= need) { s_res[0] = ba; s_res[1] = excl; }
+    if (bb >= 0 && excl + ha < need && excl + ha + hb >= need) { s_res[0] = bb; s_res[1] = excl + ha; }
+    __syncthreads();
+}
+
+// Descending bitonic sort of n_pad (power of two, <= 1024) u64 values in LDS.
+__device__ __forceinline__ void bitonic_sort_desc(unsigned long long* v, int n_pad) {
+    const int i = threadIdx.x;
+    for (int k = 2; k <= n_pad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int partner = i ^ j;
+            if (i < n_pad && partner > i) {
+                const unsigned long long a = v[i], c = v[partner];
+                const bool desc = (i & k) == 0;
+                if (desc ? (a < c) : (a > c)) { v[i] = c; v[partner] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+struct Box5 { float x1, y1, x2, y2, area; };
+
+// Suppression bit-matrix + serial reduction.  Boxes are already in visiting (score-descending) order.
+// mask: [n][words] u64 (LDS or global).  keep_flag[pi] = 1 when box pi survives.
+__device__ __forceinline__ void nms_bitmask(const float* sx1, const float* sy1, const float* sx2, const float* sy2,
+                                            const float* sarea, int n, float thr, unsigned long long* mask,
+                                            int words, unsigned char* keep_flag) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (int item = tid; item < n * words; item += nthr) {
+        const int pi = item / words, wd = item - pi * words;
+        unsigned long long bits = 0;
+        const int j0 = wd * 64;
+        if (j0 + 63 > pi) {
+            const float ix1 = sx1[pi], iy1 = sy1[pi], ix2 = sx2[pi], iy2 = sy2[pi], ia = sarea[pi];
+            const int jend = min(64, n - j0);
+            for (int jj = max(0, pi + 1 - j0); jj < jend; ++jj) {
+                const int pj = j0 + jj;
+                const float xx1 = fmaxf(ix1, sx1[pj]), yy1 = fmaxf(iy1, sy1[pj]);
+                const float xx2 = fminf(ix2, sx2[pj]), yy2 = fminf(iy2, sy2[pj]);
+                const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+                const float inter = w * h;
+                const float ovr = inter / (ia + sarea[pj] - inter);
+                if (ovr >= thr) bits |= 1ull << jj;
+            }
+        }
+        mask[item] = bits;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        unsigned long long removed = 0;     // lane w holds word w
+        for (int pi = 0; pi < n; ++pi) {
+            const unsigned long long row = tid < words ? mask[pi * words + tid] : 0ull;
+            const unsigned long long rw = __shfl(removed, pi >> 6);
+            const bool kept = !((rw >> (pi & 63)) & 1ull);
+            if (kept) removed |= row;
+            if (tid == 0) keep_flag[pi] = kept ? 1 : 0;
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// select + NMS: postprocess.py:102-122, :146-154; function.py:77-103; nms_cpu.cpp:4-63
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostParams p) {
+    __shared__ unsigned hist[L1_BINS];
+    __shared__ int s_wave[SEL_THREADS / 64];
+    __shared__ int s_res[4];
+    __shared__ unsigned long long s_comp[SEL_MAXN];         // (key << 32) | ~position
+    __shared__ unsigned s_key[SEL_MAXN];
+    __shared__ int s_pair[SEL_MAXN];
+    // decoded boxes alias the histogram (free once the radix select is done)
+    float* const s_bx = reinterpret_cast<float*>(hist);
+    float* const s_by = s_bx + SEL_MAXN;
+    float* const s_bw = s_by + SEL_MAXN;
+    float* const s_bh = s_bw + SEL_MAXN;
+    static_assert(4 * SEL_MAXN <= L1_BINS, "box arrays must fit in the histogram");
+    __shared__ float s_x1[SEL_MAXN], s_y1[SEL_MAXN], s_x2[SEL_MAXN], s_y2[SEL_MAXN], s_area[SEL_MAXN];
+    __shared__ unsigned long long s_mask[SEL_MAXN * (SEL_MAXN / 64)];
+    __shared__ unsigned char s_keep[SEL_MAXN];
+    __shared__ unsigned char s_keep_pos[SEL_MAXN];
+    __shared__ short s_ord[SEL_MAXN];
+
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int nms_pre = p.cfg.nms_pre, nms_post = p.cfg.nms_post;
+    const unsigned* keys = p.keys + (size_t)b * p.ntiles * DEC_TILE;
+    const int* tcount = p.tile_count + (size_t)b * p.ntiles;
+    const int nchunks = (p.ntiles + 1) / 2;       // chunk = 2 tiles = 4096 keys, 4 per thread
+
+    // ---- how many pairs passed the threshold
+    int total;
+    {
+        int c = 0;
+        for (int t = tid; t < p.ntiles; t += SEL_THREADS) c += tcount[t];
+        block_scan_excl(c, s_wave, total);
+    }
+    if (total == 0) {
+        if (tid == 0) p.out_count[b] = 0;
+        return;
+    }
+
+    // ---- exact threshold key T and number r of ties to take (3-level radix select on the bits)
+    unsigned T = 0;      // take every key > T, plus the first r keys == T in index order
+    int r = 0, above = total;
+    if (total > nms_pre) {
+        for (int i = tid; i < L1_BINS; i += SEL_THREADS) hist[i] = p.hist1[(size_t)b * L1_BINS + i];
+        __syncthreads();
+        find_bin_from_top(hist, L1_BINS, nms_pre, s_wave, s_res);
+        const unsigned t1 = s_res[0];
+        int need = nms_pre - s_res[1];
+        above = s_res[1];
+        __syncthreads();
+        // level 2: bits 18..8 of keys whose top bits equal t1
+        for (int i = tid; i < 2048; i += SEL_THREADS) hist[i] = 0;
+        __syncthreads();
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int t0 = ch * 2, t1i = min(ch * 2 + 1, p.ntiles - 1);
+            if (tcount[t0] + tcount[t1i] == 0) continue;
+            if (ch * 4096 + tid * 4 < p.ntiles * DEC_TILE) {
+                const uint4 k4 = *reinterpret_cast<const uint4*>(keys + (size_t)ch * 4096 + tid * 4);
+                const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (kk[e] != 0 && (kk[e] >> 19) == t1) atomicAdd(&hist[(kk[e] >> 8) & 0x7FFu], 1u);
+            }
+        }
+        __syncthreads();
+        find_bin_from_top(hist, 2048, need, s_wave, s_res);
+        const unsigned t2 = s_res[0];
+        above += s_res[1];
+        need -= s_res[1];
+        __syncthreads();
+        // level 3: low 8 bits
+        for (int i = tid; i < 256; i += SEL_THREADS) hist[i] = 0;
+        __syncthreads();
+        const unsigned hi = (t1 << 11) | t2;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int t0 = ch * 2, t1i = min(ch * 2 + 1, p.ntiles - 1);
+            if (tcount[t0] + tcount[t1i] == 0) continue;
+            if (ch * 4096 + tid * 4 < p.ntiles * DEC_TILE) {
+                const uint4 k4 = *reinterpret_cast<const uint4*>(keys + (size_t)ch * 4096 + tid * 4);
+                const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (kk[e] != 0 && (kk[e] >> 8) == hi) atomicAdd(&hist[kk[e] & 0xFFu], 1u);
+            }
+        }
+        __syncthreads();
+        find_bin_from_top(hist, 256, need, s_wave, s_res);
+        T = (hi << 8) | (unsigned)s_res[0];
+        above += s_res[1];
+        r = nms_pre - above;
+        __syncthreads();
+    }
+    const int n = total > nms_pre ? nms_pre : total;
+
+    // ---- index-ordered compaction (row-major (candidate, class) order, postprocess.py:102)
+    {
+        int run_gt = 0, run_eq = 0;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int t0 = ch * 2, t1i = min(ch * 2 + 1, p.ntiles - 1);
+            if (tcount[t0] + tcount[t1i] == 0) continue;
+            unsigned kk[4] = {0, 0, 0, 0};
+            if (ch * 4096 + tid * 4 < p.ntiles * DEC_TILE) {
+                const uint4 k4 = *reinterpret_cast<const uint4*>(keys + (size_t)ch * 4096 + tid * 4);
+                kk[0] = k4.x; kk[1] = k4.y; kk[2] = k4.z; kk[3] = k4.w;
+            }
+            int ngt = 0, neq = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ngt += kk[e] > T;
+                neq += (T != 0 && kk[e] == T);
+            }
+            int tot;
+            const int ex = block_scan_excl(ngt | (neq << 16), s_wave, tot);
+            int pg = run_gt + (ex & 0xFFFF), pe = run_eq + (ex >> 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pair = ch * 4096 + tid * 4 + e;
+                if (kk[e] > T) {
+                    if (pg < SEL_MAXN) { s_key[pg] = kk[e]; s_pair[pg] = pair; }
+                    ++pg;
+                } else if (T != 0 && kk[e] == T) {
+                    if (pe < r) { s_key[above + pe] = kk[e]; s_pair[above + pe] = pair; }
+                    ++pe;
+                }
+            }
+            run_gt += tot & 0xFFFF;
+            run_eq += tot >> 16;
+        }
+    }
+    __syncthreads();
+
+    // ---- visiting order: score descending, ties by list position ascending
+    int n_pad = 64;
+    while (n_pad < n) n_pad <<= 1;
+    if (tid < n_pad)
+        s_comp[tid] = tid < n ? (((unsigned long long)s_key[tid] << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)tid)) : 0ull;
+    __syncthreads();
+    bitonic_sort_desc(s_comp, n_pad);
+    // case A (more than nms_pre passed): the reference's list IS the sorted top-k, so list position = pi.
+    // case B: the reference's list is the index-ordered one, NMS visits it through the argsort.
+    const bool caseA = total > nms_pre;
+
+    // ---- decode the survivors' boxes (postprocess.py:126-139) in visiting order
+    if (tid < n) {
+        const int pos = (int)(0xFFFFFFFFu - (unsigned)(s_comp[tid] & 0xFFFFFFFFull));
+        s_ord[tid] = (short)pos;
+        const int pair = s_pair[pos];
+        const int C = p.cfg.num_classes;
+        const int cand = pair / C, cls = pair - cand * C;
+        int s, a, pix;
+        locate(p, cand, s, a, pix);
+        const int gh = p.cfg.grid_h[s], gw = p.cfg.grid_w[s];
+        const int gy = pix / gw, gx = pix - gy * gw;
+        const float* q = p.bbox[s] + ((size_t)b * gh * gw + pix) * p.cfg.bbox_pix_stride + a * (5 + C);
+        const int aid = p.cfg.anchor_mask[s][a];
+        const float bx = (sigmoidf_(q[0]) + (float)gx) / (float)gw;
+        const float by = (sigmoidf_(q[1]) + (float)gy) / (float)gh;
+        const float bw = expf(q[2]) * (p.cfg.anchor_w[aid] / (float)p.cfg.image_w);
+        const float bh = expf(q[3]) * (p.cfg.anchor_h[aid] / (float)p.cfg.image_h);
+        s_bx[tid] = bx; s_by[tid] = by; s_bw[tid] = bw; s_bh[tid] = bh;
+        // class offset (function.py:93-96) then corners and area (nms_cpu.cpp:17-22)
+        const float off = (float)cls * 2.0f;
+        const float ox = bx + off, oy = by + off;
+        const float x1 = ox - bw / 2.0f, y1 = oy - bh / 2.0f, x2 = ox + bw / 2.0f, y2 = oy + bh / 2.0f;
+        s_x1[tid] = x1; s_y1[tid] = y1; s_x2[tid] = x2; s_y2[tid] = y2;
+        s_area[tid] = (x2 - x1) * (y2 - y1);
+    }
+    __syncthreads();
+
+    const int words = (n + 63) >> 6;
+    nms_bitmask(s_x1, s_y1, s_x2, s_y2, s_area, n, p.cfg.nms_thresh, s_mask, words, s_keep);
+
+    // ---- output order (nms_cpu.cpp:62 ascending list position; postprocess.py:150-154 top-nms_post)
+    int kept_total;
+    const int my_keep = (tid < n) ? s_keep[tid] : 0;
+    const int rank_sorted = block_scan_excl(my_keep, s_wave, kept_total);
+    int K, slot = -1;
+    if (caseA || kept_total > nms_post) {
+        K = kept_total < nms_post ? kept_total : nms_post;
+        if (my_keep && rank_sorted < K) slot = rank_sorted;
+    } else {
+        K = kept_total;
+        int* const s_slot = reinterpret_cast<int*>(s_key);      // s_key is dead once s_comp exists
+        if (tid < n) s_keep_pos[tid] = 0;
+        __syncthreads();
+        if (my_keep) s_keep_pos[s_ord[tid]] = 1;
+        __syncthreads();
+        int dummy;
+        const int flag = (tid < n) ? s_keep_pos[tid] : 0;        // thread tid speaks for list position tid
+        const int rank_pos = block_scan_excl(flag, s_wave, dummy);
+        if (flag) s_slot[tid] = rank_pos;
+        __syncthreads();
+        if (my_keep) slot = s_slot[s_ord[tid]];
+    }
+    if (tid == 0) p.out_count[b] = K;
+    if (slot >= 0) {
+        const int pos = s_ord[tid];
+        const int pair = s_pair[pos];
+        const int C = p.cfg.num_classes;
+        const int cand = pair / C, cls = pair - cand * C;
+        int s, a, pix;
+        locate(p, cand, s, a, pix);
+        const int aid = p.cfg.anchor_mask[s][a];
+        const size_t o = (size_t)b * nms_post + slot;
+        const float bx = s_bx[tid], by = s_by[tid], bw = s_bw[tid], bh = s_bh[tid];
+        float* ob = p.out_bbox + o * 5;
+        ob[0] = bx; ob[1] = by; ob[2] = bw; ob[3] = bh;
+        ob[4] = __uint_as_float((unsigned)(s_comp[tid] >> 32));
+        p.out_cls[o] = cls;
+        if (p.out_keep) p.out_keep[o] = caseA ? tid : pos;
+        // mask constants (postprocess.py:156-164)
+        const float nW = (float)p.cfg.grid_w[s], nH = (float)p.cfg.grid_h[s];
+        float* dp = p.det_par + o * 8;
+        dp[0] = nW * bx;
+        dp[1] = nH * by;
+        dp[2] = (p.cfg.orien_thresh * bw) * nW;
+        dp[3] = (p.cfg.orien_thresh * bh) * nH;
+        dp[4] = (p.cfg.anchor_w[aid] / (float)p.cfg.image_w) * nW;      // grid_anchors, postprocess.py:21-25
+        dp[5] = (p.cfg.anchor_h[aid] / (float)p.cfg.image_h) * nH;
+        dp[6] = __int_as_float((s * p.cfg.anchors_per_scale + a) * 2);  // first orientation channel
+        dp[7] = __int_as_float(s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mask assembly: postprocess.py:69-72 (bilinear x4), :141-144 (get_orien_grid), :156-164 (predicate)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bil_row(float v0, float v1, float w0, float w1) { return fmaf(v0, w0, v1 * w1); }
+
+__global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
+    const int det = blockIdx.y;
+    const int b = det / p.cfg.nms_post, k = det - b * p.cfg.nms_post;
+    if (k >= p.out_count[b]) return;
+    const int H = p.cfg.image_h, W = p.cfg.image_w;
+    const int groups = W / MASK_PX;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= H * groups) return;
+    const int y = item / groups, g = item - y * groups;
+    const float* dp = p.det_par + (size_t)det * 8;
+    const float cx = dp[0], cy = dp[1], tx = dp[2], ty = dp[3], gax = dp[4], gay = dp[5];
+    const int chan = __float_as_int(dp[6]), s = __float_as_int(dp[7]);
+    const float nW = (float)p.cfg.grid_w[s], nH = (float)p.cfg.grid_h[s];
+    const int oh = H / 4, ow = W / 4;
+    const int nch = p.cfg.num_scales * p.cfg.anchors_per_scale * 2;
+    const float* px = p.oriens + ((size_t)b * nch + chan) * oh * ow;
+    const float* py = px + (size_t)oh * ow;
+
+    // vertical taps (generic, clamped like torch: src >= 0, i1 = min(i0 + 1, n - 1))
+    const float sy = fmaxf(((float)y + 0.5f) * 0.25f - 0.5f, 0.0f);
+    const int y0 = (int)sy;
+    const int y1 = y0 + (y0 < oh - 1 ? 1 : 0);
+    const float wy1 = sy - (float)y0, wy0 = 1.0f - wy1;
+    const float base_y = ((float)y / (float)H) * nH;                      // postprocess.py:40-41
+
+    // six source columns 4g-1 .. 4g+4 cover the 16 outputs; clamp the loads at the borders
+    float ax[2][6], ay[2][6];
+    const int c_first = 4 * g - 1;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const int col = min(max(c_first + c, 0), ow - 1);
+        ax[0][c] = px[(size_t)y0 * ow + col]; ax[1][c] = px[(size_t)y1 * ow + col];
+        ay[0][c] = py[(size_t)y0 * ow + col]; ay[1][c] = py[(size_t)y1 * ow + col];
+    }
+    const bool left_edge = (g == 0);
+    unsigned packed[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < MASK_PX; ++e) {
+        const int ph = e & 3, j = e >> 2;
+        // phase -> (local column of x0, weight of x1): src = j + ph/4 - 0.375 (relative to column 4g)
+        const int c0 = j + (ph < 2 ? 0 : 1);
+        float wx1 = ph == 0 ? 0.625f : ph == 1 ? 0.875f : ph == 2 ? 0.125f : 0.375f;
+        float v00x, v01x, v10x, v11x, v00y, v01y, v10y, v11y;
+        if (e < 2) {
+            // outputs 0 and 1 of the first group clamp to src = 0: x0 = 0, weight of x1 = 0
+            wx1 = left_edge ? 0.0f : wx1;
+            v00x = left_edge ? ax[0][1] : ax[0][0]; v01x = left_edge ? ax[0][2] : ax[0][1];
+            v10x = left_edge ? ax[1][1] : ax[1][0]; v11x = left_edge ? ax[1][2] : ax[1][1];
+            v00y = left_edge ? ay[0][1] : ay[0][0]; v01y = left_edge ? ay[0][2] : ay[0][1];
+            v10y = left_edge ? ay[1][1] : ay[1][0]; v11y = left_edge ? ay[1][2] : ay[1][1];
+        } else {
+            v00x = ax[0][c0]; v01x = ax[0][c0 + 1]; v10x = ax[1][c0]; v11x = ax[1][c0 + 1];
+            v00y = ay[0][c0]; v01y = ay[0][c0 + 1]; v10y = ay[1][c0]; v11y = ay[1][c0 + 1];
+        }
+        const float wx0 = 1.0f - wx1;
+        const float vx = fmaf(bil_row(v00x, v01x, wx0, wx1), wy0, bil_row(v10x, v11x, wx0, wx1) * wy1);
+        const float vy = fmaf(bil_row(v00y, v01y, wx0, wx1), wy0, bil_row(v10y, v11y, wx0, wx1) * wy1);
+        const int x = g * MASK_PX + e;
+        const float base_x = ((float)x / (float)W) * nW;
+        const float Px = (vx * gax) / 2.0f + base_x;                      // postprocess.py:142-143
+        const float Py = (vy * gay) / 2.0f + base_y;
+        const bool inside = (fabsf(Px - cx) < tx) && (fabsf(Py - cy) < ty);
+        packed[e >> 2] |= (inside ? 1u : 0u) << ((e & 3) * 8);
+    }
+    uint4 o;
+    o.x = packed[0]; o.y = packed[1]; o.z = packed[2]; o.w = packed[3];
+    *reinterpret_cast<uint4*>(p.out_mask + ((size_t)det * H + y) * W + (size_t)g * MASK_PX) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// standalone NMS (the reference's native export): sort, bit-matrix in the caller's workspace, reduce
+// ------------------------------------------------------------------------------------------------
+constexpr int NMS_MAXN = 1024;
+
+__global__ __launch_bounds__(1024) void nms_kernel(const float* dets, int n, float thr, int64_t* keep, int32_t* n_keep,
+                                                   unsigned long long* mask) {
+    __shared__ unsigned long long s_comp[NMS_MAXN];
+    __shared__ float s_x1[NMS_MAXN], s_y1[NMS_MAXN], s_x2[NMS_MAXN], s_y2[NMS_MAXN], s_area[NMS_MAXN];
+    __shared__ unsigned char s_keep[NMS_MAXN], s_keep_pos[NMS_MAXN];
+    __shared__ int s_wave[16];
+    const int tid = threadIdx.x;
+    int n_pad = 64;
+    while (n_pad < n) n_pad <<= 1;
+    if (tid < n_pad) {
+        unsigned long long c = 0;
+        if (tid < n) {
+            // order-preserving map of the float score to u32 (handles negative scores too)
+            unsigned u = __float_as_uint(dets[tid * 5 + 4]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            c = ((unsigned long long)u << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)tid);
+        }
+        s_comp[tid] = c;
+    }
+    __syncthreads();
+    bitonic_sort_desc(s_comp, n_pad);
+    int pos = 0;
+    if (tid < n) {
+        pos = (int)(0xFFFFFFFFu - (unsigned)(s_comp[tid] & 0xFFFFFFFFull));
+        const float* d = dets + pos * 5;
+        const float cx = d[0], cy = d[1], w = d[2], h = d[3];
+        const float x1 = cx - w / 2.0f, y1 = cy - h / 2.0f, x2 = cx + w / 2.0f, y2 = cy + h / 2.0f;
+        s_x1[tid] = x1; s_y1[tid] = y1; s_x2[tid] = x2; s_y2[tid] = y2;
+        s_area[tid] = (x2 - x1) * (y2 - y1);
+        s_keep_pos[tid] = 0;
+    }
+    __syncthreads();
+    const int words = (n + 63) >> 6;
+    nms_bitmask(s_x1, s_y1, s_x2, s_y2, s_area, n, thr, mask, words, s_keep);
+    if (tid < n && s_keep[tid]) s_keep_pos[pos] = 1;
+    __syncthreads();
+    int total;
+    const int flag = tid < n ? s_keep_pos[tid] : 0;
+    const int rank = block_scan_excl(flag, s_wave, total);
+    if (flag) keep[rank] = tid;
+    if (tid == 0) *n_keep = total;
+}
+
+static int fill_params(const om_post_cfg* cfg, PostParams& p) {
+    OM_REQUIRE(cfg->num_scales == 3 && cfg->anchors_per_scale >= 1 && cfg->anchors_per_scale <= 3, OM_EINVAL,
+               "postprocess: %d scales x %d anchors not supported", cfg->num_scales, cfg->anchors_per_scale);
+    OM_REQUIRE(cfg->image_h % 32 == 0 && cfg->image_w % 32 == 0 && cfg->image_h > 0 && cfg->image_w > 0, OM_EINVAL,
+               "postprocess: image %dx%d must be a multiple of 32", cfg->image_h, cfg->image_w);
+    OM_REQUIRE(cfg->nms_pre >= 1 && cfg->nms_pre <= SEL_MAXN && cfg->nms_post >= 1 && cfg->nms_post <= cfg->nms_pre,
+               OM_EINVAL, "postprocess: nms_pre=%d (max %d), nms_post=%d", cfg->nms_pre, SEL_MAXN, cfg->nms_post);
+    OM_REQUIRE(cfg->num_classes >= 1 && cfg->anchors_per_scale * (5 + cfg->num_classes) <= cfg->bbox_pix_stride,
+               OM_EINVAL, "postprocess: bbox_pix_stride=%d too small", cfg->bbox_pix_stride);
+    OM_REQUIRE(cfg->conf_thresh >= 0.0f, OM_EINVAL, "postprocess: conf_thresh must be >= 0");
+    p.cfg = *cfg;
+    p.cand_off[0] = 0;
+    for (int s = 0; s < 3; ++s) {
+        OM_REQUIRE(cfg->grid_h[s] > 0 && cfg->grid_w[s] > 0, OM_EINVAL, "postprocess: bad grid");
+        for (int a = 0; a < cfg->anchors_per_scale; ++a)
+            OM_REQUIRE(cfg->anchor_mask[s][a] >= 0 && cfg->anchor_mask[s][a] < OM_MAX_ANCHORS, OM_EINVAL,
+                       "postprocess: bad anchor_mask");
+        p.cand_off[s + 1] = p.cand_off[s] + cfg->anchors_per_scale * cfg->grid_h[s] * cfg->grid_w[s];
+    }
+    p.ncand = p.cand_off[3];
+    const long long npairs = (long long)p.ncand * cfg->num_classes;
+    OM_REQUIRE(npairs < (1ll << 30), OM_EINVAL, "postprocess: too many (candidate, class) pairs");
+    p.npairs = (int)npairs;
+    p.ntiles = (p.npairs + DEC_TILE - 1) / DEC_TILE;
+    return OM_OK;
+}
+
+struct PostWs { size_t keys, tile_count, hist1, det_par, total; };
+
+static PostWs post_ws_layout(const PostParams& p, int B) {
+    PostWs w;
+    size_t off = 0;
+    w.keys = off; off += align_up((size_t)B * p.ntiles * DEC_TILE * sizeof(unsigned), 256);
+    w.tile_count = off; off += align_up((size_t)B * p.ntiles * sizeof(int), 256);
+    w.hist1 = off; off += align_up((size_t)B * L1_BINS * sizeof(unsigned), 256);
+    w.det_par = off; off += align_up((size_t)B * p.cfg.nms_post * 8 * sizeof(float), 256);
+    w.total = off;
+    return w;
+}
+
+}  // namespace om
+
+extern "C" {
+
+size_t om_postprocess_workspace_bytes(const om_post_cfg* cfg, int B) {
+    if (!cfg || B <= 0) return 0;
+    om::PostParams p;
+    if (om::fill_params(cfg, p) != OM_OK) return 0;
+    return om::post_ws_layout(p, B).total;
+}
+
+int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbox16, const float* bbox8,
+                   const float* oriens, int B, float* out_bbox, int64_t* out_cls, uint8_t* out_mask,
+                   int32_t* out_count, int32_t* out_keep, void* workspace, size_t ws_bytes, om_stream stream_) {
+    OM_REQUIRE(cfg && bbox32 && bbox16 && bbox8 && oriens && out_bbox && out_cls && out_mask && out_count && workspace,
+               OM_EINVAL, "om_postprocess: null argument");
+    OM_REQUIRE(B > 0 && B < 65536, OM_EINVAL, "om_postprocess: B=%d", B);
+    om::PostParams p;
+    int rc = om::fill_params(cfg, p);
+    if (rc != OM_OK) return rc;
+    const om::PostWs w = om::post_ws_layout(p, B);
+    OM_REQUIRE(ws_bytes >= w.total, OM_ENOMEM, "om_postprocess: workspace %zu bytes < %zu needed", ws_bytes, w.total);
+    OM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0 && (reinterpret_cast<uintptr_t>(out_mask) & 15) == 0,
+               OM_EINVAL, "om_postprocess: workspace must be 256-byte and out_mask 16-byte aligned");
+    OM_REQUIRE((long long)B * cfg->nms_post < 65536, OM_EINVAL, "om_postprocess: B * nms_post must be < 65536");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char* base = static_cast<char*>(workspace);
+    p.bbox[0] = bbox32; p.bbox[1] = bbox16; p.bbox[2] = bbox8; p.oriens = oriens; p.B = B;
+    p.keys = reinterpret_cast<unsigned*>(base + w.keys);
+    p.tile_count = reinterpret_cast<int*>(base + w.tile_count);
+    p.hist1 = reinterpret_cast<unsigned*>(base + w.hist1);
+    p.det_par = reinterpret_cast<float*>(base + w.det_par);
+    p.out_bbox = out_bbox; p.out_cls = out_cls; p.out_mask = out_mask; p.out_count = out_count; p.out_keep = out_keep;
+
+    OM_CHECK_HIP(hipMemsetAsync(p.hist1, 0, (size_t)B * om::L1_BINS * sizeof(unsigned), stream));
+    hipLaunchKernelGGL(om::post_decode_kernel, dim3(p.ntiles, B), dim3(256), 0, stream, p);
+    OM_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(om::post_select_kernel, dim3(B), dim3(om::SEL_THREADS), 0, stream, p);
+    OM_CHECK_HIP(hipGetLastError());
+    const int items = cfg->image_h * (cfg->image_w / om::MASK_PX);
+    hipLaunchKernelGGL(om::post_mask_kernel, dim3((items + 255) / 256, B * cfg->nms_post), dim3(256), 0, stream, p);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
+size_t om_nms_workspace_bytes(int n) {
+    if (n <= 0) return 256;
+    const size_t words = ((size_t)n + 63) / 64;
+    return om::align_up((size_t)n * words * sizeof(unsigned long long), 256);
+}
+
+int om_nms(const float* dets, int n, float thresh, int64_t* keep, int32_t* n_keep, void* workspace, size_t ws_bytes,
+           om_stream stream_) {
+    OM_REQUIRE(n_keep && (n == 0 || (dets && keep && workspace)), OM_EINVAL, "om_nms: null argument");
+    OM_REQUIRE(n >= 0 && n <= om::NMS_MAXN, OM_EINVAL, "om_nms: n=%d, at most %d boxes supported", n, om::NMS_MAXN);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n == 0) {
+        OM_CHECK_HIP(hipMemsetAsync(n_keep, 0, sizeof(int32_t), stream));
+        return OM_OK;
+    }
+    OM_REQUIRE(ws_bytes >= om_nms_workspace_bytes(n), OM_ENOMEM, "om_nms: workspace %zu bytes < %zu needed", ws_bytes,
+               om_nms_workspace_bytes(n));
+    hipLaunchKernelGGL(om::nms_kernel, dim3(1), dim3(1024), 0, stream, dets, n, thresh, keep, n_keep,
+                       static_cast<unsigned long long*>(workspace));
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,196 @@
+"""Drop-in for the reference's ``eval`` module on the inference path.
+
+  OrienMaskYOLOPostProcess  same constructor and call contract as
+                            /root/reference/eval/orienmask_yolo_postprocess.py:8-64
+  batched_nms, nms          same signatures and return triples as
+                            /root/reference/eval/function.py:55-103
+
+Everything runs in liborienmask_hip.so (``om_postprocess`` / ``om_nms``); the whole batch is three
+kernel launches and ONE device->host copy (the per-image detection counts), against the reference's
+per-image Python loop with four host round trips.  Suppression follows the reference's CPU backend
+(nms_cpu.cpp: IoU >= threshold, ascending-index keep order), the only backend that builds today.
+"""
+import ctypes
+import functools
+
+import torch
+
+from . import lib as _lib
+from .model import HEAD_PIX_STRIDE
+
+
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def nms(dets, cats, threshold=0.5):
+    """Plain NMS; returns (dets[keep], cats[keep], keep).  /root/reference/eval/function.py:55-74."""
+    keep = _nms_keep(dets, threshold)
+    return dets[keep], cats[keep], keep
+
+
+def batched_nms(dets, cats, threshold=0.5, normalized=True):
+    """Class-aware NMS: boxes are shifted by class * (max_coordinate + 0.5) so that classes never
+    interact.  /root/reference/eval/function.py:77-103."""
+    if dets.size(0) == 0:
+        keep = dets.new_zeros(0, dtype=torch.long)
+    else:
+        max_coordinate = 1.5 if normalized else dets[:, :2].max() + dets[:, 2:4].max() / 2
+        shifted = dets.clone()
+        shifted[:, :2] += cats.float().view(-1, 1) * (max_coordinate + 0.5)
+        keep = _nms_keep(shifted, threshold)
+    return dets[keep], cats[keep], keep
+
+
+def _nms_keep(dets, threshold):
+    """om_nms: the native export nms(dets[n,5], threshold) -> keep of
+    /root/reference/eval/src/nms_cpu.cpp:65-75 / nms_cuda.cpp:8-17."""
+    if dets.size(0) == 0:
+        return dets.new_zeros(0, dtype=torch.long)
+    _lib.require_cuda_tensor(dets, "dets")
+    L = _lib.load()
+    d = dets.detach().to(torch.float32).contiguous()
+    n = d.shape[0]
+    dev = d.device
+    keep = torch.empty(n, dtype=torch.long, device=dev)
+    n_keep = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(L.om_nms_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.om_nms(ctypes.c_void_p(d.data_ptr()), n, float(threshold), ctypes.c_void_p(keep.data_ptr()),
+                      ctypes.c_void_p(n_keep.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                      _lib.current_stream_ptr(dev))
+    _lib.check(rc, "om_nms")
+    return keep[:int(n_keep.item())]
+
+
+class OrienMaskYOLOPostProcess:
+    def __init__(self, grid_size, image_size, anchors, anchor_mask, num_classes, conf_thresh=0.05, nms_func=None,
+                 nms_pre=400, nms_post=100, orien_thresh=0.3, device=None):
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device()) \
+            if torch.cuda.is_available() else torch.device("cpu")
+        self.nHs = [int(g[0]) for g in grid_size]
+        self.nWs = [int(g[1]) for g in grid_size]
+        self.scales = len(grid_size)
+        self.image_h, self.image_w = _pair(image_size)
+        self.anchors = [[float(a[0]), float(a[1])] for a in anchors]
+        self.anchor_mask = [list(m) for m in anchor_mask]
+        self.num_anchors = [len(m) for m in anchor_mask]
+        self.num_classes = int(num_classes)
+        self.conf_thresh = float(conf_thresh)
+        self.nms_pre = int(nms_pre)
+        self.nms_post = int(nms_post)
+        self.orien_thresh = float(orien_thresh)
+        self.nms = nms_func if nms_func else batched_nms
+        self.nms_thresh = self._threshold_of(self.nms)
+        if self.scales != 3 or len(set(self.num_anchors)) != 1:
+            raise ValueError("the HIP postprocess supports 3 scales with the same number of anchors each")
+        if len(self.anchors) > _lib.OM_MAX_ANCHORS:
+            raise ValueError("at most %d anchors" % _lib.OM_MAX_ANCHORS)
+        self._ws = {}
+
+    @staticmethod
+    def _threshold_of(func):
+        """The fused kernel implements batched_nms itself; it only needs the IoU threshold that
+        build_postprocess bound into the partial (/root/reference/trainer/builder.py:73-77)."""
+        if func is batched_nms:
+            return 0.5
+        if isinstance(func, functools.partial) and func.func is batched_nms:
+            if func.keywords.get("normalized", True) is not True:
+                raise NotImplementedError("the fused postprocess implements batched_nms(normalized=True) only")
+            return float(func.keywords.get("threshold", 0.5))
+        raise NotImplementedError(
+            "nms_func must be orienmask_amd.eval.batched_nms or a functools.partial of it; a foreign NMS callable "
+            "cannot run inside the fused HIP postprocess (there is no Python fallback)")
+
+    def cfg_struct(self, bbox_pix_stride):
+        c = _lib.PostCfg()
+        c.num_scales = 3
+        for i in range(3):
+            c.grid_h[i] = self.nHs[i]
+            c.grid_w[i] = self.nWs[i]
+            for a in range(self.num_anchors[i]):
+                c.anchor_mask[i][a] = self.anchor_mask[i][a]
+        c.image_h, c.image_w = self.image_h, self.image_w
+        c.anchors_per_scale = self.num_anchors[0]
+        for i, (w, h) in enumerate(self.anchors):
+            c.anchor_w[i] = w
+            c.anchor_h[i] = h
+        c.num_classes = self.num_classes
+        c.conf_thresh = self.conf_thresh
+        c.nms_thresh = self.nms_thresh
+        c.nms_pre, c.nms_post = self.nms_pre, self.nms_post
+        c.orien_thresh = self.orien_thresh
+        c.bbox_pix_stride = bbox_pix_stride
+        return c
+
+    def __call__(self, predict):
+        return self.apply(predict)
+
+    # -- input plumbing: accept the HIP model's layouts zero-copy, anything else after one repack
+    def _bbox_nhwc(self, predict):
+        per = self.num_anchors[0] * (5 + self.num_classes)
+        strides = set()
+        for i, (bbox, _) in enumerate(predict):
+            B, C, nH, nW = bbox.shape
+            if C != per or nH != self.nHs[i] or nW != self.nWs[i]:
+                raise ValueError("bbox head %d has shape %s, expected [B,%d,%d,%d]" % (i, tuple(bbox.shape), per,
+                                                                                     self.nHs[i], self.nWs[i]))
+            s = bbox.stride()
+            if s[1] == 1 and s[3] >= C and s[2] == nW * s[3] and s[0] == nH * nW * s[3]:
+                strides.add(s[3])
+            else:
+                strides.add(-1)
+        if len(strides) == 1 and -1 not in strides:
+            return [p[0] for p in predict], strides.pop()
+        return [p[0].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2) for p in predict], per
+
+    def _oriens_nchw(self, predict):
+        o = [p[1] for p in predict]
+        oh, ow = self.image_h // 4, self.image_w // 4
+        A2 = self.num_anchors[0] * 2
+        base = o[0]
+        same = all(t.shape == (base.shape[0], A2, oh, ow) and t.stride() == (3 * A2 * oh * ow, oh * ow, ow, 1)
+                   for t in o)
+        if same and all(o[i].data_ptr() == base.data_ptr() + i * A2 * oh * ow * 4 for i in range(3)):
+            return base          # three views of one [B, 3*A2, oh, ow] buffer: use it in place
+        return torch.cat(o, dim=1).contiguous()
+
+    def apply(self, predict):
+        """Returns list[dict(bbox [K,5] f32, mask [K,H,W] bool, cls [K] i64)], K <= nms_post, per image
+        (/root/reference/eval/orienmask_yolo_postprocess.py:66-124,146-166)."""
+        for p in predict:
+            _lib.require_cuda_tensor(p[0], "bbox head", torch.float32)
+            _lib.require_cuda_tensor(p[1], "orientation head", torch.float32)
+        L = _lib.load()
+        bboxes, pix_stride = self._bbox_nhwc(predict)
+        oriens = self._oriens_nchw(predict)
+        B = bboxes[0].shape[0]
+        dev = bboxes[0].device
+        cfg = self.cfg_struct(pix_stride)
+        key = (dev, B, pix_stride)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = L.om_postprocess_workspace_bytes(ctypes.byref(cfg), B)
+            if nbytes == 0:
+                _lib.check(-1, "om_postprocess_workspace_bytes")
+            self._ws.clear()
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._ws[key] = ws
+        out_bbox = torch.empty((B, self.nms_post, 5), dtype=torch.float32, device=dev)
+        out_cls = torch.empty((B, self.nms_post), dtype=torch.long, device=dev)
+        out_mask = torch.empty((B, self.nms_post, self.image_h, self.image_w), dtype=torch.uint8, device=dev)
+        out_count = torch.empty((B,), dtype=torch.int32, device=dev)
+        out_keep = torch.empty((B, self.nms_post), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.om_postprocess(ctypes.byref(cfg), ctypes.c_void_p(bboxes[0].data_ptr()),
+                                  ctypes.c_void_p(bboxes[1].data_ptr()), ctypes.c_void_p(bboxes[2].data_ptr()),
+                                  ctypes.c_void_p(oriens.data_ptr()), B, ctypes.c_void_p(out_bbox.data_ptr()),
+                                  ctypes.c_void_p(out_cls.data_ptr()), ctypes.c_void_p(out_mask.data_ptr()),
+                                  ctypes.c_void_p(out_count.data_ptr()), ctypes.c_void_p(out_keep.data_ptr()),
+                                  ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream_ptr(dev))
+        _lib.check(rc, "om_postprocess")
+        counts = out_count.cpu().tolist()          # the one host sync of the batch
+        mask_bool = out_mask.view(torch.bool)
+        self.last_keep = [out_keep[b, :k] for b, k in enumerate(counts)]
+        return [{"bbox": out_bbox[b, :k], "mask": mask_bool[b, :k], "cls": out_cls[b, :k]}
+                for b, k in enumerate(counts)]

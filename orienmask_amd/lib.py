@@ -1,0 +1,105 @@
+"""ctypes binding of liborienmask_hip.so (C ABI declared in include/orienmask_hip.h).
+
+The HIP library IS the product: there is no CPU or eager-PyTorch fallback.  If the shared
+object is missing or does not export a declared symbol, loading raises immediately.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liborienmask_hip.so")
+
+OM_MAX_SCALES = 3
+OM_MAX_ANCHORS = 9
+
+
+class LayerInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 64),
+                ("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("cout_pad", ctypes.c_int32),
+                ("ksize", ctypes.c_int32), ("stride", ctypes.c_int32),
+                ("has_bn", ctypes.c_int32), ("leaky", ctypes.c_int32),
+                ("w_off", ctypes.c_int64), ("scale_off", ctypes.c_int64), ("shift_off", ctypes.c_int64)]
+
+
+class PostCfg(ctypes.Structure):
+    _fields_ = [("num_scales", ctypes.c_int32),
+                ("grid_h", ctypes.c_int32 * OM_MAX_SCALES), ("grid_w", ctypes.c_int32 * OM_MAX_SCALES),
+                ("image_h", ctypes.c_int32), ("image_w", ctypes.c_int32),
+                ("anchors_per_scale", ctypes.c_int32),
+                ("anchor_w", ctypes.c_float * OM_MAX_ANCHORS), ("anchor_h", ctypes.c_float * OM_MAX_ANCHORS),
+                ("anchor_mask", (ctypes.c_int32 * 3) * OM_MAX_SCALES),
+                ("num_classes", ctypes.c_int32),
+                ("conf_thresh", ctypes.c_float), ("nms_thresh", ctypes.c_float),
+                ("nms_pre", ctypes.c_int32), ("nms_post", ctypes.c_int32),
+                ("orien_thresh", ctypes.c_float),
+                ("bbox_pix_stride", ctypes.c_int32)]
+
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# symbol -> (restype, argtypes); must list every function include/orienmask_hip.h declares
+SIGNATURES = {
+    "om_version": (_i, []),
+    "om_last_error": (ctypes.c_char_p, []),
+    "om_model_create": (_i, [ctypes.POINTER(_vp), _i, _i]),
+    "om_model_destroy": (None, [_vp]),
+    "om_model_num_layers": (_i, [_vp]),
+    "om_model_layer_info": (_i, [_vp, _i, ctypes.POINTER(LayerInfo)]),
+    "om_model_weight_floats": (_sz, [_vp]),
+    "om_model_load_weights": (_i, [_vp, _vp, _sz, _i]),
+    "om_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "om_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "om_conv2d": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "om_conv2d_stem": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "om_postprocess_workspace_bytes": (_sz, [ctypes.POINTER(PostCfg), _i]),
+    "om_postprocess": (_i, [ctypes.POINTER(PostCfg), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "om_nms_workspace_bytes": (_sz, [_i]),
+    "om_nms": (_i, [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+class OrienMaskHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library once; raise loudly if it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OrienMaskHipError(
+            "%s not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C orienmask_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise OrienMaskHipError("%s does not export %s" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().om_last_error()
+        raise OrienMaskHipError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def require_cuda_tensor(t, name, dtype=None):
+    import torch
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise OrienMaskHipError("%s must be a tensor on an MI355X device (got %s); this path has no CPU fallback"
+                                % (name, getattr(t, "device", type(t))))
+    if dtype is not None and t.dtype != dtype:
+        raise OrienMaskHipError("%s must be %s, got %s" % (name, dtype, t.dtype))
+
+
+def current_stream_ptr(device):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,174 @@
+"""Drop-in for the reference's ``model`` module on the inference path.
+
+``OrienMaskYOLOFPNPlus`` keeps the reference constructor and forward() signature
+(/root/reference/model/orienmask_yolo_fpnplus.py:9-10,74-90) and the reference's 524-key
+state_dict, so ``build(config['model'], orienmask_amd.model)`` followed by
+``load_state_dict(weights, strict=True)`` works exactly as in /root/reference/infer.py:79-83 and
+/root/reference/trainer/builder.py:50-52 -- but forward() is ONE call into the HIP library
+(``om_forward``): ~90 fused conv launches on torch's current stream, no torch.nn ops.
+
+Differences a caller can observe (documented in INTEGRATION.md):
+  * inference only: forward() raises in training mode and on CPU tensors (no fallback);
+  * the three box tensors come back with the reference's SHAPE [B, A*(5+C), nH, nW] but in
+    channels-last memory (NHWC, 256-float pixel stride); the orientation tensors are views of one
+    contiguous [B, 6A, H/4, W/4] buffer exactly as torch.split returns them in the reference.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from . import lib as _lib
+from . import pack as _pack
+from .arch import fpnplus_convs, state_dict_entries
+
+HEAD_PIX_STRIDE = 256
+
+
+class _Node(nn.Module):
+    """Pure container: holds parameters/buffers under the reference's names, never runs."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("container module; OrienMaskYOLOFPNPlus.forward runs the whole graph in HIP")
+
+
+def _descend(root, parts):
+    node = root
+    for p in parts:
+        if p not in node._modules:
+            node.add_module(p, _Node())
+        node = node._modules[p]
+    return node
+
+
+class OrienMaskYOLOFPNPlus(nn.Module):
+    def __init__(self, num_anchors, num_classes, pretrained=None, freeze_backbone=False,
+                 backbone_batchnorm_eval=False):
+        super().__init__()
+        self.num_anchors = num_anchors
+        self.num_classes = num_classes
+        self.pretrained = pretrained
+        self.freeze_backbone = freeze_backbone
+        self.backbone_batchnorm_eval = backbone_batchnorm_eval
+        for spec in fpnplus_convs(num_anchors, num_classes):
+            for key, shape, role in state_dict_entries(spec):
+                *path, leaf = key.split(".")
+                node = _descend(self, path)
+                if role == "conv_w":
+                    w = torch.empty(shape)
+                    nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+                    node.register_parameter(leaf, nn.Parameter(w, requires_grad=False))
+                elif role == "conv_b":
+                    bound = 1.0 / math.sqrt(spec.cin * spec.ksize * spec.ksize)
+                    node.register_parameter(leaf, nn.Parameter(torch.empty(shape).uniform_(-bound, bound),
+                                                               requires_grad=False))
+                elif role == "bn_gamma":
+                    node.register_parameter(leaf, nn.Parameter(torch.ones(shape), requires_grad=False))
+                elif role == "bn_beta":
+                    node.register_parameter(leaf, nn.Parameter(torch.zeros(shape), requires_grad=False))
+                elif role == "bn_mean":
+                    node.register_buffer(leaf, torch.zeros(shape))
+                elif role == "bn_var":
+                    node.register_buffer(leaf, torch.ones(shape))
+                else:
+                    node.register_buffer(leaf, torch.tensor(0, dtype=torch.long))
+        self._handle = None
+        self._layers = None
+        self._packed = None          # device blob currently bound to the handle
+        self._packed_device = None
+        self._workspace = {}         # (device, B, H, W) -> uint8 tensor
+        if pretrained is not None:
+            # reference: BaseBackbone._load_pretrained_weights, /root/reference/model/base.py:48-64
+            sd = _pack.unwrap_checkpoint(torch.load(pretrained, map_location="cpu"))
+            own = self.state_dict()
+            own.update({k: v for k, v in sd.items() if k in own and v.shape == own[k].shape})
+            self.load_state_dict(own)
+
+    # ------------------------------------------------------------------ weights
+    def _ensure_handle(self):
+        if self._handle is None:
+            L = _lib.load()
+            h = ctypes.c_void_p()
+            _lib.check(L.om_model_create(ctypes.byref(h), self.num_anchors, self.num_classes), "om_model_create")
+            self._handle = h
+            self._layers = _pack.graph_layers(h)
+            _pack.check_graph_matches_arch(self._layers, self.num_anchors, self.num_classes)
+        return self._handle
+
+    def invalidate_packed(self):
+        """Call after mutating parameters in place; load_state_dict/.to() do it themselves."""
+        self._packed = None
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.invalidate_packed()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.invalidate_packed()
+        return out
+
+    def packed_weights(self, device):
+        """Device blob in the library's layout (built lazily, cached until weights change)."""
+        h = self._ensure_handle()
+        if self._packed is None or self._packed_device != device:
+            L = _lib.load()
+            total = L.om_model_weight_floats(h)
+            blob = _pack.pack_state_dict(self.state_dict(), self._layers, total).to(device)
+            self.bind_packed(blob)
+        return self._packed
+
+    def bind_packed(self, blob):
+        """Bind an already packed device blob (used after an RCCL broadcast of rank 0's blob)."""
+        h = self._ensure_handle()
+        _lib.require_cuda_tensor(blob, "packed weights", torch.float32)
+        L = _lib.load()
+        with torch.cuda.device(blob.device):
+            _lib.check(L.om_model_load_weights(h, ctypes.c_void_p(blob.data_ptr()), blob.numel() * 4, 0),
+                       "om_model_load_weights")
+        self._packed = blob
+        self._packed_device = blob.device
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("orienmask_amd.OrienMaskYOLOFPNPlus is inference-only: call .eval() first")
+        _lib.require_cuda_tensor(x, "x", torch.float32)
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError("x must be [B,3,H,W] with H and W multiples of 32, got %s" % (tuple(x.shape),))
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        dev = x.device
+        L = _lib.load()
+        self.packed_weights(dev)
+        h = self._handle
+        key = (dev, B, H, W)
+        ws = self._workspace.get(key)
+        if ws is None:
+            nbytes = L.om_forward_workspace_bytes(h, B, H, W)
+            self._workspace.clear()
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._workspace[key] = ws
+        A = self.num_anchors
+        bbox_dim = A * (5 + self.num_classes)
+        heads = [torch.empty((B, H // s, W // s, HEAD_PIX_STRIDE), dtype=torch.float32, device=dev) for s in (32, 16, 8)]
+        oriens = torch.empty((B, 6 * A, H // 4, W // 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.om_forward(h, ctypes.c_void_p(x.data_ptr()), B, H, W,
+                              ctypes.c_void_p(heads[0].data_ptr()), ctypes.c_void_p(heads[1].data_ptr()),
+                              ctypes.c_void_p(heads[2].data_ptr()), ctypes.c_void_p(oriens.data_ptr()),
+                              ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream_ptr(dev))
+        _lib.check(rc, "om_forward")
+        bboxes = [t[..., :bbox_dim].permute(0, 3, 1, 2) for t in heads]
+        o32, o16, o8 = torch.split(oriens, A * 2, dim=1)
+        return (bboxes[0], o32), (bboxes[1], o16), (bboxes[2], o8)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                _lib.load().om_model_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass

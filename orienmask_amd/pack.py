@@ -1,0 +1,76 @@
+"""Reference state_dict (524 keys) -> packed weight blob of the HIP graph.
+
+Blob layout comes from the library (``om_model_layer_info``): per convolution
+  weights [cout_pad][kh*kw][cin]  (OHWI, rows >= cout zero)   scale [cout_pad]   shift [cout_pad]
+with eval-mode BatchNorm folded into the epilogue constants,
+  scale = gamma / sqrt(running_var + eps),  shift = beta - running_mean * scale
+(/root/reference/model/base.py:113-128; eps = 1e-5 is nn.BatchNorm2d's default) and, for the four
+bias-only head convolutions (/root/reference/model/orienmask_yolo_fpnplus.py:60,71), scale = 1 and
+shift = bias.  The fold is computed in float64 and rounded once.
+
+Checkpoint formats accepted are the reference's: a raw state_dict or {'state_dict': ...}
+(/root/reference/infer.py:81-83, /root/reference/trainer/builder.py:45-52).
+"""
+import ctypes
+
+import torch
+
+from . import lib as _lib
+from .arch import BN_EPS, fpnplus_convs
+
+
+def graph_layers(handle):
+    """Layer table of a created om_model as a list of dicts (execution order)."""
+    L = _lib.load()
+    out = []
+    for i in range(L.om_model_num_layers(handle)):
+        info = _lib.LayerInfo()
+        _lib.check(L.om_model_layer_info(handle, i, ctypes.byref(info)), "om_model_layer_info")
+        out.append(dict(name=info.name.decode(), cin=info.cin, cout=info.cout, cout_pad=info.cout_pad,
+                        ksize=info.ksize, stride=info.stride, has_bn=bool(info.has_bn), leaky=bool(info.leaky),
+                        w_off=info.w_off, scale_off=info.scale_off, shift_off=info.shift_off))
+    return out
+
+
+def check_graph_matches_arch(layers, num_anchors, num_classes):
+    """The C++ graph and the Python layer table are written independently; they must agree."""
+    want = {s.name: s for s in fpnplus_convs(num_anchors, num_classes)}
+    got = {l["name"]: l for l in layers}
+    if set(want) != set(got):
+        raise _lib.OrienMaskHipError("graph/arch layer names differ: %s" % sorted(set(want) ^ set(got)))
+    for name, s in want.items():
+        l = got[name]
+        if (s.cin, s.cout, s.ksize, s.stride, s.bn) != (l["cin"], l["cout"], l["ksize"], l["stride"], l["has_bn"]):
+            raise _lib.OrienMaskHipError("graph/arch disagree on %s: %s vs %s" % (name, s, l))
+
+
+def unwrap_checkpoint(obj):
+    if isinstance(obj, dict) and "state_dict" in obj and isinstance(obj["state_dict"], dict):
+        return obj["state_dict"]
+    return obj
+
+
+def pack_state_dict(state_dict, layers, total_floats):
+    """Returns a CPU float32 tensor of total_floats elements laid out as the graph expects."""
+    sd = unwrap_checkpoint(state_dict)
+    blob = torch.zeros(total_floats, dtype=torch.float32)
+    for l in layers:
+        name, cin, cout, cpad, k = l["name"], l["cin"], l["cout"], l["cout_pad"], l["ksize"]
+        if l["has_bn"]:
+            w = sd[name + ".conv_block.0.weight"]
+            p = name + ".conv_block.1."
+            gamma, beta = sd[p + "weight"].double().cpu(), sd[p + "bias"].double().cpu()
+            mean, var = sd[p + "running_mean"].double().cpu(), sd[p + "running_var"].double().cpu()
+            scale = gamma / torch.sqrt(var + BN_EPS)
+            shift = beta - mean * scale
+        else:
+            w = sd[name + ".weight"]
+            scale = torch.ones(cout, dtype=torch.float64)
+            shift = sd[name + ".bias"].double().cpu()
+        if tuple(w.shape) != (cout, cin, k, k):
+            raise _lib.OrienMaskHipError("%s: weight shape %s, expected %s" % (name, tuple(w.shape), (cout, cin, k, k)))
+        ohwi = w.detach().float().cpu().permute(0, 2, 3, 1).reshape(cout, k * k * cin)
+        blob[l["w_off"]:l["w_off"] + cout * k * k * cin] = ohwi.reshape(-1)
+        blob[l["scale_off"]:l["scale_off"] + cout] = scale.float()
+        blob[l["shift_off"]:l["shift_off"] + cout] = shift.float()
+    return blob

@@ -1,0 +1,309 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Tolerances (BASELINE.json north_star): class / index results bit-exact, box coordinates and head
+tensors within 1e-4 (relative to the tensor's scale), mask IoU >= 1 - 1e-4.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_files, post_cfg
+from oracle import orienmask_ref as R
+from orienmask_amd import lib as omlib
+from orienmask_amd import synth
+from test_oracle_golden import unpack_masks
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev(built):
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    omlib.load()
+    return torch.device("cuda:0")
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _rel_err(got, want):
+    return (got - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
+
+
+# ------------------------------------------------------------------------------------------------
+# single convolutions
+# ------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # B, H, W, cin, cout, k, stride, leaky, residual
+    (2, 16, 16, 32, 64, 3, 2, 1, False),
+    (2, 12, 20, 64, 32, 1, 1, 1, False),
+    (1, 17, 17, 32, 64, 3, 1, 1, True),
+    (3, 8, 8, 128, 128, 3, 1, 1, True),
+    (2, 9, 7, 256, 255, 1, 1, 0, False),
+    (1, 10, 10, 64, 18, 1, 1, 0, False),
+    (2, 6, 6, 384, 128, 1, 1, 1, False),
+    (1, 34, 34, 128, 256, 3, 1, 1, False),
+    (5, 4, 4, 1024, 512, 1, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_layer_matches_torch(dev, case):
+    B, H, W, cin, cout, k, stride, leaky, use_res = case
+    L = omlib.load()
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.2
+    Ho, Wo = H // stride, W // stride
+    res = torch.randn(B, cout, Ho, Wo, generator=g) if use_res else None
+    want = torch.nn.functional.conv2d(x.double(), w.double(), None, stride, k // 2)
+    want = want * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if leaky:
+        want = torch.where(want > 0, want, want * 0.1)
+    if use_res:
+        want = want + res.double()
+    cpad = (cout + 31) // 32 * 32
+    wp = torch.zeros(cpad, k * k * cin)
+    wp[:cout] = w.permute(0, 2, 3, 1).reshape(cout, -1)
+    sp = torch.zeros(cpad); sp[:cout] = scale
+    hp = torch.zeros(cpad); hp[:cout] = shift
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd, sd_, hd = wp.to(dev), sp.to(dev), hp.to(dev)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None
+    out = torch.full((B, Ho, Wo, cout), float("nan"), device=dev)
+    rc = L.om_conv2d(_p(xd), B, H, W, cin, cin, _p(wd), _p(sd_), _p(hd), cout, k, stride, leaky,
+                     _p(rd) if use_res else None, cout if use_res else 0, _p(out), cout,
+                     omlib.current_stream_ptr(dev))
+    omlib.check(rc, "om_conv2d")
+    got = out.cpu().permute(0, 3, 1, 2).double()
+    assert torch.isfinite(got).all()
+    assert _rel_err(got, want) < 2e-6, case
+
+
+def test_stem_matches_torch(dev):
+    L = omlib.load()
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 2, 40, 72
+    x = torch.rand(B, 3, H, W, generator=g)
+    w = torch.randn(32, 3, 3, 3, generator=g) * 0.3
+    scale = torch.rand(32, generator=g) + 0.5
+    shift = torch.randn(32, generator=g) * 0.2
+    want = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+    want = want * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    want = torch.where(want > 0, want, want * 0.1)
+    wp = w.permute(0, 2, 3, 1).reshape(32, 27).contiguous().to(dev)
+    out = torch.full((B, H, W, 32), float("nan"), device=dev)
+    xd, scd, shd = x.to(dev), scale.to(dev), shift.to(dev)      # keep the device tensors alive over the call
+    rc = L.om_conv2d_stem(_p(xd), B, H, W, _p(wp), _p(scd), _p(shd), 32, _p(out), omlib.current_stream_ptr(dev))
+    omlib.check(rc, "om_conv2d_stem")
+    got = out.cpu().permute(0, 3, 1, 2).double()
+    assert _rel_err(got, want) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# forward
+# ------------------------------------------------------------------------------------------------
+def _hip_model(sd, dev):
+    from orienmask_amd.model import OrienMaskYOLOFPNPlus
+    net = OrienMaskYOLOFPNPlus(3, 80).eval()
+    net.load_state_dict(sd, strict=True)
+    return net.to(dev)
+
+
+@pytest.mark.parametrize("fname", golden_files("fwd_"))
+def test_forward_matches_reference_golden(dev, fname):
+    """HIP forward vs tensors the real reference produced (tests/golden/fwd_*.npz)."""
+    g = np.load(os.path.join(GOLDEN, fname))
+    size = tuple(int(v) for v in g["size"]); batch = int(g["batch"])
+    sd = synth.synth_state_dict(int(g["wseed"]), obj_bias=float(g["obj_bias"]), head_gain=float(g["head_gain"]))
+    x = synth.synth_image_batch(int(g["xseed"]), batch, size[0], size[1])
+    net = _hip_model(sd, dev)
+    with torch.no_grad():
+        out = net(x.to(dev))
+    torch.cuda.synchronize()
+    got = dict(bbox32=out[0][0], bbox16=out[1][0], bbox8=out[2][0],
+               oriens=torch.cat([out[0][1], out[1][1], out[2][1]], 1))
+    for k, t in got.items():
+        assert list(t.shape) == g[k + "_shape"].tolist(), k
+        flat = t.contiguous().cpu().reshape(-1)
+        scale = float(g[k + "_absmax"])
+        samp = flat[torch.from_numpy(g[k + "_idx"])].numpy()
+        assert np.max(np.abs(samp - g[k + "_samples"])) <= REL_TOL * scale, k
+        assert abs(flat.double().sum().item() - g[k + "_sum"][0]) <= REL_TOL * g[k + "_sum"][1], k
+        if k in g.files:
+            assert np.max(np.abs(flat.numpy() - g[k].reshape(-1))) <= REL_TOL * scale, k
+
+
+def test_forward_matches_oracle_and_layouts(dev):
+    """Full head tensors vs the oracle on a non-square input; also pins the returned layouts."""
+    sd = synth.synth_state_dict(5, obj_bias=-16.0, head_gain=4.0)
+    x = synth.synth_image_batch(6, 3, 128, 192)
+    net = _hip_model(sd, dev)
+    with torch.no_grad():
+        out = net(x.to(dev))
+    ref = R.forward(sd, x)
+    for (gb, go), (rb, ro) in zip(out, ref):
+        assert gb.shape == rb.shape and go.shape == ro.shape
+        assert gb.stride(1) == 1                      # channels-last box heads
+        assert go.stride() == (18 * go.shape[2] * go.shape[3], go.shape[2] * go.shape[3], go.shape[3], 1)
+        assert _rel_err(gb.cpu(), rb) < REL_TOL
+        assert _rel_err(go.cpu(), ro) < REL_TOL
+
+
+def test_forward_is_batch_invariant(dev):
+    """Size-independent property at the full 544x544 size: an image's outputs do not depend on what
+    else is in the batch (bit-exact), and repeated runs are bit-identical."""
+    sd = synth.synth_state_dict(7, obj_bias=-16.0, head_gain=4.0)
+    x = synth.synth_image_batch(8, 4, 544, 544).to(dev)
+    net = _hip_model(sd, dev)
+    with torch.no_grad():
+        full = net(x)
+        again = net(x)
+        single = net(x[2:3])
+    for (fb, fo), (ab, ao), (sb, so) in zip(full, again, single):
+        assert torch.equal(fb, ab) and torch.equal(fo, ao)
+        assert torch.equal(fb[2:3], sb) and torch.equal(fo[2:3], so)
+        assert torch.isfinite(fb).all() and torch.isfinite(fo).all()
+
+
+def test_forward_rejects_cpu_and_training(dev):
+    from orienmask_amd.model import OrienMaskYOLOFPNPlus
+    net = OrienMaskYOLOFPNPlus(3, 80)
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 64, 64, device=dev))          # training mode
+    net.eval()
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 64, 64))                      # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------------------------------------
+# postprocess
+# ------------------------------------------------------------------------------------------------
+def _hip_post(size, dev):
+    from orienmask_amd.eval import OrienMaskYOLOPostProcess
+    return OrienMaskYOLOPostProcess(device=dev, **post_cfg(size))
+
+
+def _mask_iou(a, b):
+    inter = np.logical_and(a, b).sum(); union = np.logical_or(a, b).sum()
+    return 1.0 if union == 0 else inter / union
+
+
+def _to_model_layout(heads, dev):
+    """CPU NCHW heads -> the HIP model's own layouts (NHWC stride-256 boxes, one oriens buffer)."""
+    out = []
+    B = heads[0][0].shape[0]
+    oriens = torch.cat([h[1] for h in heads], 1).contiguous().to(dev)
+    os_ = torch.split(oriens, heads[0][1].shape[1], dim=1)
+    for i, (b, _) in enumerate(heads):
+        nh, nw = b.shape[2], b.shape[3]
+        buf = torch.zeros(B, nh, nw, 256, device=dev)
+        buf[..., :b.shape[1]] = b.permute(0, 2, 3, 1).to(dev)
+        out.append((buf[..., :b.shape[1]].permute(0, 3, 1, 2), os_[i]))
+    return tuple(out)
+
+
+@pytest.mark.parametrize("layout", ["model", "plain"])
+@pytest.mark.parametrize("fname", golden_files("post_"))
+def test_postprocess_matches_reference_golden(dev, fname, layout):
+    g = np.load(os.path.join(GOLDEN, fname))
+    size = tuple(int(v) for v in g["size"]); batch = int(g["batch"])
+    pc = post_cfg(size)
+    heads = synth.synth_heads(int(g["seed"]), batch, pc["grid_size"], regime=str(g["regime"]))
+    dheads = _to_model_layout(heads, dev) if layout == "model" else tuple((b.to(dev), o.to(dev)) for b, o in heads)
+    post = _hip_post(size, dev)
+    res = post(dheads)
+    torch.cuda.synchronize()
+    assert len(res) == batch
+    for b, r in enumerate(res):
+        want_bbox, want_cls = g["bbox%d" % b], g["cls%d" % b]
+        assert r["bbox"].shape[0] == want_bbox.shape[0], (fname, b, r["bbox"].shape, want_bbox.shape)
+        assert r["mask"].dtype == torch.bool and r["cls"].dtype == torch.long
+        assert np.array_equal(r["cls"].cpu().numpy(), want_cls), (fname, b)          # indices: bit-exact
+        if want_bbox.shape[0]:
+            assert np.max(np.abs(r["bbox"].cpu().numpy() - want_bbox)) <= 1e-4 * max(1.0, np.abs(want_bbox).max())
+        want_mask = unpack_masks(g["mask%d" % b], g["maskshape%d" % b])
+        got_mask = r["mask"].cpu().numpy()
+        assert got_mask.shape == want_mask.shape
+        for k in range(want_mask.shape[0]):
+            assert _mask_iou(got_mask[k], want_mask[k]) >= 1 - 1e-4, (fname, b, k)
+
+
+@pytest.mark.parametrize("regime,seed", [("mixed", 101), ("clustered", 102), ("sparse", 103), ("sparse_many", 104),
+                                         ("dense", 105), ("empty", 106)])
+def test_postprocess_matches_oracle_indices(dev, regime, seed):
+    """Fresh seeds (not in the fixtures): same heads in, same candidate indices / classes out."""
+    size = (160, 192)
+    pc = post_cfg(size)
+    heads = synth.synth_heads(seed, 3, pc["grid_size"], regime=regime)
+    oracle = R.PostProcessOracle(pc["grid_size"], pc["image_size"], pc["anchors"], pc["anchor_mask"], 80,
+                                 conf_thresh=pc["conf_thresh"])
+    want = oracle(heads)
+    post = _hip_post(size, dev)
+    got = post(tuple((b.to(dev), o.to(dev)) for b, o in heads))
+    for b, (r, w) in enumerate(zip(got, want)):
+        assert r["bbox"].shape[0] == w["bbox"].shape[0], (regime, b)
+        assert torch.equal(r["cls"].cpu(), w["cls"])
+        assert torch.equal(post.last_keep[b].cpu().long(), w["keep"])
+        if w["bbox"].numel():
+            assert (r["bbox"].cpu() - w["bbox"]).abs().max().item() <= 1e-4
+            for k in range(w["mask"].shape[0]):
+                assert _mask_iou(r["mask"][k].cpu().numpy(), w["mask"][k].numpy()) >= 1 - 1e-4
+
+
+def test_postprocess_full_size_batch_properties(dev):
+    """bs=32 at 544x544 (BASELINE.json configs[2]): per-image results equal the single-image run
+    bit for bit; counts bounded; masks only inside [0,1]."""
+    size = (544, 544)
+    pc = post_cfg(size)
+    heads = synth.synth_heads(55, 32, pc["grid_size"], regime="mixed")
+    dheads = _to_model_layout(heads, dev)
+    post = _hip_post(size, dev)
+    res = post(dheads)
+    assert len(res) == 32
+    for b in (0, 13, 31):
+        one = post(tuple((h[0][b:b + 1], h[1][b:b + 1]) for h in dheads))[0]
+        assert torch.equal(one["bbox"], res[b]["bbox"]) and torch.equal(one["cls"], res[b]["cls"])
+        assert torch.equal(one["mask"], res[b]["mask"])
+    for r in res:
+        assert 0 < r["bbox"].shape[0] <= 100
+        s = r["bbox"][:, 4]
+        assert ((s > 0.005) & (s <= 1.0)).all()
+        assert r["mask"].view(torch.uint8).max().item() <= 1
+
+
+# ------------------------------------------------------------------------------------------------
+# NMS
+# ------------------------------------------------------------------------------------------------
+def test_nms_known_answers(dev):
+    from orienmask_amd.eval import batched_nms, nms
+    kat = np.load(os.path.join(GOLDEN, "nms_kat.npz"))
+    names = sorted(k[:-5] for k in kat.files if k.endswith("_keep"))
+    for name in names:
+        dets = torch.from_numpy(kat[name + "_dets"]).to(dev); cats = torch.from_numpy(kat[name + "_cats"]).to(dev)
+        thr = float(kat[name + "_thr"])
+        kd, kc, keep = batched_nms(dets, cats, threshold=thr)
+        assert keep.cpu().numpy().tolist() == kat[name + "_keep"].tolist(), name
+        assert kd.shape[0] == keep.shape[0] == kc.shape[0]
+        _, _, keep2 = nms(dets, cats, threshold=thr)
+        assert keep2.cpu().numpy().tolist() == kat[name + "_keep_plain"].tolist(), name
+
+
+def test_nms_random_vs_oracle(dev):
+    from orienmask_amd.eval import batched_nms
+    rng = np.random.Generator(np.random.PCG64(9))
+    for n in (2, 17, 128, 513, 1024):
+        d = np.concatenate([rng.random((n, 2)), rng.random((n, 2)) * 0.3 + 0.02, rng.random((n, 1))], 1).astype(np.float32)
+        c = rng.integers(0, 3, n)
+        dt, ct = torch.from_numpy(d), torch.from_numpy(c)
+        _, _, want = R.batched_nms(dt, ct, 0.45)
+        _, _, got = batched_nms(dt.to(dev), ct.to(dev), threshold=0.45)
+        assert got.cpu().tolist() == want.tolist(), n

@@ -1,0 +1,134 @@
+"""CPU: host logic and the C-ABI surface (no GPU compute calls)."""
+import ctypes
+import functools
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import REPO, post_cfg
+from orienmask_amd import arch, lib as omlib, pack, synth
+
+
+def test_library_exports_every_declared_symbol(built):
+    """Every function include/orienmask_hip.h declares is exported and bound."""
+    header = open(os.path.join(REPO, "include", "orienmask_hip.h")).read()
+    declared = set(re.findall(r"\b(om_[a-z0-9_]+)\s*\(", header))
+    declared -= {"om_model", "om_stream"}
+    assert declared == set(omlib.SIGNATURES), declared ^ set(omlib.SIGNATURES)
+    L = omlib.load()
+    for name in declared:
+        assert hasattr(L, name)
+    assert L.om_version() == 100
+
+
+def test_struct_layouts_match_header(built):
+    assert ctypes.sizeof(omlib.LayerInfo) == 64 + 7 * 4 + 4 + 3 * 8      # 4 bytes of padding before the int64s
+    assert ctypes.sizeof(omlib.PostCfg) == 4 * (1 + 3 + 3 + 2 + 1 + 9 + 9 + 9 + 1 + 2 + 2 + 1 + 1)
+
+
+def test_graph_matches_reference_state_dict(built):
+    """90 convolutions, 524 keys, 63,662,063 parameters."""
+    from orienmask_amd.model import OrienMaskYOLOFPNPlus
+    net = OrienMaskYOLOFPNPlus(num_anchors=3, num_classes=80, pretrained=None, freeze_backbone=False,
+                               backbone_batchnorm_eval=False)
+    sd = net.state_dict()
+    assert len(sd) == 524
+    assert sum(p.numel() for p in net.parameters()) == 63662063
+    for k in ("backbone.conv1.conv_block.0.weight", "backbone.conv2.1.conv.0.conv_block.1.running_var",
+              "bbox_head32.1.bias", "orien_head.5.weight", "skip4.conv_block.1.num_batches_tracked"):
+        assert k in sd
+    h = net._ensure_handle()
+    assert len(net._layers) == 90 == len(arch.fpnplus_convs())
+    L = omlib.load()
+    assert L.om_forward_workspace_bytes(h, 1, 544, 544) > 0
+    assert L.om_forward_workspace_bytes(h, 1, 540, 544) == 0          # not a multiple of 32
+    # strict loading of a reference-format checkpoint, both accepted wrappers
+    ref_sd = synth.synth_state_dict(3)
+    net.load_state_dict(ref_sd, strict=True)
+    with pytest.raises(RuntimeError):
+        bad = dict(ref_sd); bad.pop("neck8.2.conv_block.0.weight")
+        net.load_state_dict(bad, strict=True)
+    assert pack.unwrap_checkpoint({"state_dict": ref_sd, "config": {}}) is ref_sd
+
+
+def test_pack_folds_batchnorm(built):
+    from orienmask_amd.model import OrienMaskYOLOFPNPlus
+    net = OrienMaskYOLOFPNPlus(3, 80)
+    sd = synth.synth_state_dict(4)
+    net.load_state_dict(sd)
+    h = net._ensure_handle()
+    L = omlib.load()
+    blob = pack.pack_state_dict(net.state_dict(), net._layers, L.om_model_weight_floats(h))
+    by_name = {l["name"]: l for l in net._layers}
+    l = by_name["backbone.conv3.1.conv.1"]
+    g, b = sd["backbone.conv3.1.conv.1.conv_block.1.weight"].double(), sd["backbone.conv3.1.conv.1.conv_block.1.bias"].double()
+    m, v = sd["backbone.conv3.1.conv.1.conv_block.1.running_mean"].double(), sd["backbone.conv3.1.conv.1.conv_block.1.running_var"].double()
+    scale = g / torch.sqrt(v + 1e-5)
+    assert torch.allclose(blob[l["scale_off"]:l["scale_off"] + l["cout"]].double(), scale, rtol=1e-6)
+    assert torch.allclose(blob[l["shift_off"]:l["shift_off"] + l["cout"]].double(), b - m * scale, rtol=1e-5, atol=1e-7)
+    w = sd["backbone.conv3.1.conv.1.conv_block.0.weight"]
+    got = blob[l["w_off"]:l["w_off"] + w.numel()].view(128, 3, 3, 64)
+    assert torch.equal(got, w.permute(0, 2, 3, 1))
+    # bias-only head: scale 1, shift = bias, rows >= cout zero
+    l = by_name["bbox_head16.1"]
+    assert l["cout"] == 255 and l["cout_pad"] == 256 and not l["has_bn"]
+    assert torch.equal(blob[l["scale_off"]:l["scale_off"] + 256], torch.cat([torch.ones(255), torch.zeros(1)]))
+    assert torch.equal(blob[l["shift_off"]:l["shift_off"] + 255], sd["bbox_head16.1.bias"])
+    assert blob[l["w_off"] + 255 * 512:l["w_off"] + 256 * 512].abs().sum() == 0
+
+
+def test_registry_builders_mirror_reference(built):
+    """build()/build_postprocess() consume the reference's config dicts unchanged
+    (/root/reference/trainer/builder.py:61-77, /root/reference/config/base.py:219-236)."""
+    from orienmask_amd import builder, eval as om_eval, model as om_model
+    cfg = dict(type="OrienMaskYOLOPostProcess", nms=dict(type="batched_nms", threshold=0.45), **post_cfg((544, 544)))
+    keep = dict(cfg)
+    post = builder.build_postprocess(cfg, device=torch.device("cpu"))
+    assert cfg == keep                                      # the caller's dict is not mutated
+    assert isinstance(post, om_eval.OrienMaskYOLOPostProcess)
+    assert post.nms_thresh == pytest.approx(0.45) and post.nms_pre == 400 and post.nms_post == 100
+    assert isinstance(post.nms, functools.partial) and post.nms.func is om_eval.batched_nms
+    net = builder.build(dict(type="OrienMaskYOLOFPNPlus", num_anchors=3, num_classes=80, pretrained=None,
+                             freeze_backbone=False, backbone_batchnorm_eval=False), om_model)
+    assert isinstance(net, om_model.OrienMaskYOLOFPNPlus)
+    with pytest.raises(NotImplementedError):
+        om_eval.OrienMaskYOLOPostProcess(nms_func=lambda d, c: None, **post_cfg((544, 544)))
+    c = post.cfg_struct(256)
+    assert (c.grid_h[0], c.grid_w[2], c.image_h, c.anchors_per_scale, c.num_classes) == (17, 68, 544, 3, 80)
+    assert list(c.anchor_mask[0]) == [6, 7, 8] and c.anchor_w[8] == 459.0 and c.anchor_h[8] == 401.0
+    L = omlib.load()
+    assert L.om_postprocess_workspace_bytes(ctypes.byref(c), 32) > 32 * 18207 * 80 * 4
+    c.nms_pre = 4096
+    assert L.om_postprocess_workspace_bytes(ctypes.byref(c), 1) == 0     # beyond the fused path's limit
+
+
+def test_cpu_tensors_are_rejected_loudly(built):
+    from orienmask_amd import eval as om_eval
+    from orienmask_amd.model import OrienMaskYOLOFPNPlus
+    net = OrienMaskYOLOFPNPlus(3, 80).eval()
+    with pytest.raises(omlib.OrienMaskHipError):
+        net(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(omlib.OrienMaskHipError):
+        om_eval.batched_nms(torch.rand(4, 5), torch.zeros(4, dtype=torch.long))
+    post = om_eval.OrienMaskYOLOPostProcess(**post_cfg((96, 96)))
+    heads = synth.synth_heads(1, 1, post_cfg((96, 96))["grid_size"])
+    with pytest.raises(omlib.OrienMaskHipError):
+        post(heads)
+
+
+def test_missing_library_is_fatal(monkeypatch, built):
+    monkeypatch.setattr(omlib, "_lib", None)
+    monkeypatch.setattr(omlib, "LIB_PATH", "/nonexistent/liborienmask_hip.so")
+    with pytest.raises(omlib.OrienMaskHipError):
+        omlib.load()
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "orienmask_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
+                assert "nms_ref" not in text and "libnms_ref" not in text, f
