@@ -1,0 +1,198 @@
+"""Headline benchmark: images/sec end-to-end (forward + postprocess) at 544x544, bs=32 per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is what the reference times around `model(image); postprocess(predict)`
+(/root/reference/trainer/tester.py:39-44, /root/reference/infer.py:154-156) on one batch of 32
+synthetic 544x544 images already resident in HBM (BASELINE.json configs[2]).  Each rank runs its own
+batch (weak scaling, no collective in the timed region); rank 0's packed weights are broadcast once
+over RCCL before timing.  Rank 0 prints ONE JSON line.
+
+roofline:     the dominant kernel is the f32-MFMA implicit-GEMM convolution (128x128 tile).  achieved =
+              algorithmic FLOPs of the layers it runs / their summed duration, measured live with HIP
+              events on the launch stream over the timed steps (om_profile_*); peak = 157.3 TFLOP/s
+              (f32-input MFMA, MI355X_MICROARCH.md).  The forward is FLOP-bound in fp32.
+cpu_baseline: the CPU oracle (torch-CPU restatement of the reference, oracle/) on the host cores, on a
+              bounded sample, N=1 only.  Checker code, timed beside the product, never part of it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+ANCHORS_YOLOV4 = [[12, 16], [19, 36], [40, 28], [36, 75], [76, 55], [72, 146], [142, 110], [192, 243], [459, 401]]
+ANCHOR_MASK = [[6, 7, 8], [3, 4, 5], [0, 1, 2]]
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+WEIGHT_SEED, OBJ_BIAS, HEAD_GAIN = 3, -16.0, 4.0
+
+
+def post_config(h, w):
+    return dict(grid_size=[[h // 32, w // 32], [h // 16, w // 16], [h // 8, w // 8]], image_size=[h, w],
+                anchors=ANCHORS_YOLOV4, anchor_mask=ANCHOR_MASK, num_classes=80, conf_thresh=0.005,
+                nms_pre=400, nms_post=100, orien_thresh=0.3)
+
+
+def cpu_baseline(sd, x_cpu, target_seconds=12.0):
+    """Oracle forward + postprocess on the host cores; bounded sample of the same workload."""
+    from oracle import orienmask_ref as R
+    h, w = x_cpu.shape[2], x_cpu.shape[3]
+    pc = post_config(h, w)
+    post = R.PostProcessOracle(pc["grid_size"], pc["image_size"], pc["anchors"], pc["anchor_mask"], 80,
+                               conf_thresh=pc["conf_thresh"])
+    cores = torch.get_num_threads()
+    sample = x_cpu[:2]
+    post(R.forward(sd, sample[:1]))                                # warm-up
+    t0 = time.perf_counter()
+    n_img = 0
+    reps = 0
+    while True:
+        post(R.forward(sd, sample))
+        n_img += sample.shape[0]
+        reps += 1
+        if time.perf_counter() - t0 >= target_seconds or reps >= 20:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=round(n_img / dt, 4), unit="images/s", cores=cores, kind="port",
+                sample="%d reps of forward+postprocess on 2 images (544x544) of the bench batch, torch-CPU oracle, "
+                       "%d threads" % (reps, cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU (metric is quoted at 32)")
+    ap.add_argument("--size", type=int, default=544)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from orienmask_amd import arch, synth
+    from orienmask_amd.dist import broadcast_packed_weights
+    from orienmask_amd.eval import OrienMaskYOLOPostProcess
+    from orienmask_amd.model import OrienMaskYOLOFPNPlus
+
+    H = W = args.size
+    B = args.batch
+    net = OrienMaskYOLOFPNPlus(3, 80).eval()
+    sd = None
+    if rank == 0:
+        sd = synth.synth_state_dict(WEIGHT_SEED, obj_bias=OBJ_BIAS, head_gain=HEAD_GAIN)
+        net.load_state_dict(sd, strict=True)
+    broadcast_packed_weights(net, dev, src=0)                      # one RCCL broadcast, untimed
+    post = OrienMaskYOLOPostProcess(device=dev, **post_config(H, W))
+    x_cpu = synth.synth_image_batch(1000 + rank, B, H, W)
+    x = x_cpu.to(dev)
+
+    def step():
+        with torch.no_grad():
+            return post(net(x))
+
+    for _ in range(args.warmup):
+        dets = step()
+    torch.cuda.synchronize()
+
+    net.profile_enable(True)
+    post_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        with torch.no_grad():
+            pred = net(x)
+            post_ev[i][0].record()
+            dets = post(pred)
+            post_ev[i][1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    layer_ms, n_fw = net.profile_read()
+    net.profile_enable(False)
+    post_ms = sum(a.elapsed_time(b) for a, b in post_ev) / args.steps
+
+    if rank == 0:
+        specs = {s.name: s for s in arch.fpnplus_convs()}
+        tiles = {}
+        for name, ms in layer_ms:
+            s = specs[name]
+            cpad = (s.cout + 31) // 32 * 32
+            kern = "stem" if name == "backbone.conv1" else ("igemm128" if cpad % 128 == 0 else "igemm64" if cpad % 64 == 0 else "igemm32")
+            wk = arch.layer_work(s, B, H, W)
+            t = tiles.setdefault(kern, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            t["ms"] += ms / n_fw; t["flops"] += wk["flops"]; t["bytes"] += wk["bytes"]; t["launches"] += 1
+        dom = max(tiles, key=lambda k: tiles[k]["ms"])
+        d = tiles[dom]
+        fwd_ms = sum(t["ms"] for t in tiles.values())
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        total_flops = sum(t["flops"] for t in tiles.values())
+        total_bytes = sum(t["bytes"] for t in tiles.values())
+        roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                        kernel="conv_igemm_f32_kernel<128,128,64,64>" if dom == "igemm128" else dom,
+                        launches_per_step=d["launches"], avg_launch_ms=round(d["ms"] / d["launches"], 4),
+                        kernel_ms_per_step=round(d["ms"], 3), forward_kernels_ms_per_step=round(fwd_ms, 3),
+                        postprocess_ms_per_step=round(post_ms, 3),
+                        forward_tflops=round(total_flops / (fwd_ms * 1e-3) / 1e12, 2),
+                        forward_hbm_algorithmic_gbs=round(total_bytes / (fwd_ms * 1e-3) / 1e9, 1),
+                        forward_hbm_frac=round(total_bytes / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                        binding="fp32 FLOPs (f32-input MFMA); HBM bound is ~9x further away (SURVEY.md 8d)")
+        if args.layers:
+            for name, ms in layer_ms:
+                wk = arch.layer_work(specs[name], B, H, W)
+                print("%-28s %8.3f ms  %7.2f TF  %7.1f GB/s" % (name, ms / n_fw, wk["flops"] / (ms / n_fw * 1e-3) / 1e12,
+                                                               wk["bytes"] / (ms / n_fw * 1e-3) / 1e9), file=sys.stderr)
+            for k, t in sorted(tiles.items()):
+                print("%-10s %3d launches %8.3f ms %7.2f TF" % (k, t["launches"], t["ms"], t["flops"] / (t["ms"] * 1e-3) / 1e12),
+                      file=sys.stderr)
+        total_images = world * B * args.steps
+        line = dict(metric="images/sec end-to-end (544^2, bs=32) forward+postprocess", value=round(total_images / elapsed, 2),
+                    unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                    ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
+                    vs_baseline=None, dtype="f32", data="synthetic",
+                    config=dict(workload="OrienMaskYOLOFPNPlus forward + OrienMaskYOLOPostProcess, %d x [3,%d,%d] per GPU "
+                                         "(BASELINE configs[2]); seeded random-init weights (seed %d, obj_bias %g, head_gain %g): "
+                                         ">400 candidates pass conf_thresh per image, NMS, 100 masks per image"
+                                         % (B, H, W, WEIGHT_SEED, OBJ_BIAS, HEAD_GAIN),
+                                per_gpu_batch=B, image_size=[H, W], detections_per_image=round(sum(int(d_["bbox"].shape[0]) for d_ in dets) / B, 1),
+                                parallelism="batch shard x%d, one RCCL weight broadcast, no collective in the step" % world),
+                    roofline=roofline)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, x_cpu)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

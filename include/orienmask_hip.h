@@ -94,6 +94,13 @@ size_t om_forward_workspace_bytes(const om_model* m, int B, int H, int W);
 int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, float* bbox16, float* bbox8,
                float* oriens, void* workspace, size_t ws_bytes, om_stream stream);
 
+/* ---- measurement: per-layer durations with HIP events on the stream om_forward launches on
+ * (the reference measures with torch.cuda.Event pairs, utils/timer.py:70-82).  While enabled, every
+ * om_forward records one event pair per layer; om_profile_read synchronises on them and returns the
+ * summed milliseconds per layer (graph order of om_model_layer_info) and the number of forwards. */
+int om_profile_enable(om_model* m, int enable);
+int om_profile_read(om_model* m, float* layer_ms, int n_layers, int* n_forwards);
+
 /* ---- one convolution (unit-test entry) ----------------------------------------------------- */
 /* in: [B,H,W,cin] NHWC (pixel stride in_pix_stride floats); w/scale/shift as in om_layer_info;
  * res: optional [B,Ho,Wo,cout] NHWC added after the activation; out: [B,Ho,Wo,cout] NHWC. */

@@ -78,3 +78,32 @@ def state_dict_entries(spec):
 def is_residual_tail(spec):
     """True for the 3x3 conv that closes a DarkNet residual block."""
     return spec.name.startswith("backbone.") and spec.name.endswith(".conv.1")
+
+
+def layer_div(spec):
+    """Spatial divisor (image / div) of a convolution's OUTPUT; its input is at div / stride."""
+    n = spec.name
+    if n == "backbone.conv1":
+        return 1
+    if n.startswith("backbone.conv"):
+        return 2 ** (int(n[len("backbone.conv")]) - 1)
+    if n.startswith("skip4") or n.startswith("neck4") or n.startswith("orien_head"):
+        return 4
+    for s in (32, 16, 8):
+        if n.split(".")[0].endswith(str(s)):
+            return s
+    raise ValueError(n)
+
+
+def layer_work(spec, batch, height, width):
+    """Algorithmic work of one fused convolution launch (SURVEY.md section 8d accounting):
+    flops = 2 * MACs; bytes = input read once + output written once + residual re-read once
+    + weights once, all fp32."""
+    div = layer_div(spec)
+    ho, wo = height // div, width // div
+    hi, wi = ho * spec.stride, wo * spec.stride
+    m = batch * ho * wo
+    macs = m * spec.cout * spec.cin * spec.ksize * spec.ksize
+    elems = batch * hi * wi * spec.cin + m * spec.cout + (m * spec.cout if is_residual_tail(spec) else 0)
+    weights = spec.cout * spec.cin * spec.ksize * spec.ksize
+    return dict(flops=2 * macs, bytes=4 * (elems + weights), m=m)

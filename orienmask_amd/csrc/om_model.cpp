@@ -61,6 +61,11 @@ struct om_model {
     std::vector<om::LayerDef> layers;
     size_t weight_floats = 0;
     const float* weights = nullptr;
+    // optional per-layer timing with HIP events on the launch stream (om_profile_*)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;     // 2 events per (recorded forward, layer)
+    size_t ev_used = 0;
+    int prof_forwards = 0;
 
     int new_buf(int div, int C) {
         bufs.push_back({div, C});
@@ -195,7 +200,11 @@ int om_model_create(om_model** out, int num_anchors, int num_classes) {
     return OM_OK;
 }
 
-void om_model_destroy(om_model* m) { delete m; }
+void om_model_destroy(om_model* m) {
+    if (!m) return;
+    for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
+    delete m;
+}
 
 int om_model_num_layers(const om_model* m) { return m ? (int)m->layers.size() : OM_EINVAL; }
 
@@ -256,6 +265,23 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
 
     for (const om::LayerDef& L : m->layers) {
         const om_layer_info& li = L.info;
+        hipEvent_t ev_stop = nullptr;
+        if (m->profiling) {
+            if (m->ev_used + 2 > m->ev_pool.size()) {
+                for (int k = 0; k < 2; ++k) {
+                    hipEvent_t e;
+                    OM_CHECK_HIP(hipEventCreate(&e));
+                    m->ev_pool.push_back(e);
+                }
+            }
+            OM_CHECK_HIP(hipEventRecord(m->ev_pool[m->ev_used], stream));
+            ev_stop = m->ev_pool[m->ev_used + 1];
+            m->ev_used += 2;
+        }
+        struct StopGuard {
+            hipEvent_t e; hipStream_t s;
+            ~StopGuard() { if (e) (void)hipEventRecord(e, s); }
+        } stop_guard{ev_stop, stream};
         const float* w = m->weights + li.w_off;
         const float* scale = m->weights + li.scale_off;
         const float* shift = m->weights + li.shift_off;
@@ -283,6 +309,34 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
             return rc;
         }
     }
+    if (m->profiling) ++m->prof_forwards;
+    return OM_OK;
+}
+
+int om_profile_enable(om_model* m, int enable) {
+    OM_REQUIRE(m, OM_EINVAL, "om_profile_enable: null model");
+    m->profiling = enable != 0;
+    m->ev_used = 0;
+    m->prof_forwards = 0;
+    return OM_OK;
+}
+
+int om_profile_read(om_model* m, float* layer_ms, int n_layers, int* n_forwards) {
+    OM_REQUIRE(m && layer_ms && n_forwards, OM_EINVAL, "om_profile_read: null argument");
+    OM_REQUIRE(n_layers == (int)m->layers.size(), OM_EINVAL, "om_profile_read: n_layers=%d, graph has %zu", n_layers,
+               m->layers.size());
+    OM_REQUIRE(m->ev_used == (size_t)m->prof_forwards * m->layers.size() * 2, OM_ESTATE,
+               "om_profile_read: a profiled forward failed part-way");
+    for (int i = 0; i < n_layers; ++i) layer_ms[i] = 0.f;
+    size_t e = 0;
+    for (int f = 0; f < m->prof_forwards; ++f)
+        for (int i = 0; i < n_layers; ++i, e += 2) {
+            OM_CHECK_HIP(hipEventSynchronize(m->ev_pool[e + 1]));
+            float ms = 0.f;
+            OM_CHECK_HIP(hipEventElapsedTime(&ms, m->ev_pool[e], m->ev_pool[e + 1]));
+            layer_ms[i] += ms;
+        }
+    *n_forwards = m->prof_forwards;
     return OM_OK;
 }
 

@@ -1,0 +1,64 @@
+"""Multi-GPU plumbing: one process per GPU, batches sharded across ranks, weights broadcast once.
+
+The reference has no multi-GPU inference (assert n_gpu <= 1, /root/reference/test.py:23,
+/root/reference/infer.py:69); images are independent through forward and postprocess
+(/root/reference/eval/orienmask_yolo_postprocess.py:75 loops per image), so the path shards with no
+data-path collective.  The only collective is one broadcast of rank 0's packed weight blob
+(63.67 M floats, 255 MB) over RCCL/xGMI at start-up -- not in the timed region.  Results are merged
+on the host per rank, as the reference's validation does with its _temp_coco_eval_%d.json files
+(/root/reference/trainer/trainer.py:175-181,201-205).
+"""
+import torch
+
+
+def world_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous slice [start, stop) of n_items owned by `rank`; sizes differ by at most one."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def broadcast_blob(blob, numel, device, src=0):
+    """Broadcast a flat float32 blob from `src`; ranks other than src pass blob=None."""
+    import torch.distributed as dist
+    rank, world = world_info()
+    if rank == src:
+        if blob is None or blob.numel() != numel or blob.dtype != torch.float32:
+            raise ValueError("source rank must provide the %d-float blob" % numel)
+        blob = blob.to(device).contiguous()
+    else:
+        blob = torch.empty(numel, dtype=torch.float32, device=device)
+    if world > 1:
+        dist.broadcast(blob, src=src)
+    return blob
+
+
+def broadcast_packed_weights(net, device, src=0):
+    """Pack on `src` (which must hold the real state_dict), broadcast, bind on every rank."""
+    from . import lib as _lib
+    from . import pack as _pack
+    rank, _ = world_info()
+    h = net._ensure_handle()
+    numel = _lib.load().om_model_weight_floats(h)
+    blob = _pack.pack_state_dict(net.state_dict(), net._layers, numel) if rank == src else None
+    blob = broadcast_blob(blob, numel, device, src)
+    net.bind_packed(blob)
+    return blob
+
+
+def gather_detections(local, src_indices=None):
+    """Host-side merge of per-rank result lists (any picklable objects) in rank order."""
+    import torch.distributed as dist
+    rank, world = world_info()
+    if world == 1:
+        return list(local)
+    out = [None] * world
+    dist.all_gather_object(out, list(local))
+    return [d for part in out for d in part]

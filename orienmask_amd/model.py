@@ -165,6 +165,20 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         o32, o16, o8 = torch.split(oriens, A * 2, dim=1)
         return (bboxes[0], o32), (bboxes[1], o16), (bboxes[2], o8)
 
+    # ------------------------------------------------------------------ measurement
+    def profile_enable(self, enable=True):
+        """Record one HIP event pair per layer on the launch stream during forward()."""
+        _lib.check(_lib.load().om_profile_enable(self._ensure_handle(), 1 if enable else 0), "om_profile_enable")
+
+    def profile_read(self):
+        """(list of (layer name, summed ms), number of forwards recorded); synchronises on the events."""
+        h = self._ensure_handle()
+        n = len(self._layers)
+        ms = (ctypes.c_float * n)()
+        nf = ctypes.c_int(0)
+        _lib.check(_lib.load().om_profile_read(h, ms, n, ctypes.byref(nf)), "om_profile_read")
+        return [(self._layers[i]["name"], float(ms[i])) for i in range(n)], nf.value
+
     def __del__(self):
         try:
             if getattr(self, "_handle", None) is not None:

@@ -1,0 +1,64 @@
+"""CPU, world_size 2 over gloo: the sharding and weight-broadcast plumbing of the N>1 path."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from orienmask_amd.dist import shard_range
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from orienmask_amd import dist as omd, lib as omlib, pack, synth
+    from orienmask_amd.model import OrienMaskYOLOFPNPlus
+    net = OrienMaskYOLOFPNPlus(3, 80).eval()
+    h = net._ensure_handle()
+    numel = omlib.load().om_model_weight_floats(h)
+    blob = None
+    if rank == 0:                               # only rank 0 has the real weights
+        net.load_state_dict(synth.synth_state_dict(9), strict=True)
+        blob = pack.pack_state_dict(net.state_dict(), net._layers, numel)
+    got = omd.broadcast_blob(blob, numel, torch.device("cpu"), src=0)
+    want = pack.pack_state_dict(synth.synth_state_dict(9), net._layers, numel)
+    ok_blob = bool(torch.equal(got, want))
+    start, stop = omd.shard_range(67, rank, world)
+    merged = omd.gather_detections([{"image": i} for i in range(start, stop)])
+    q.put((rank, ok_blob, start, stop, [m["image"] for m in merged]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 32, 255, 256):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_broadcast_and_merge(built):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in results] == [True, True]              # both ranks hold rank 0's blob
+    assert (results[0][2], results[0][3], results[1][2], results[1][3]) == (0, 34, 34, 67)
+    assert results[0][4] == list(range(67)) and results[1][4] == list(range(67))
