@@ -40,6 +40,7 @@ struct ConvArgs {
     const float* shift;     // [cout_pad]
     const float* res;       // optional NHWC view [B,Ho,Wo,cout], added after the activation
     float* out;
+    int* ticket = nullptr;  // device int zeroed before the launch (dynamic tile queue); nullptr = static grid
     int B, H, W, cin, in_pix_stride;
     int Ho, Wo, cout, cout_pad;
     int ks, stride;

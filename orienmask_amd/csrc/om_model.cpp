@@ -231,6 +231,7 @@ size_t om_forward_workspace_bytes(const om_model* m, int B, int H, int W) {
     if (!m || B <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32) return 0;
     size_t total = 0;
     for (size_t i = 0; i < m->bufs.size(); ++i) total += om::align_up(m->buf_floats((int)i, B, H, W) * sizeof(float), 256);
+    total += om::align_up(m->layers.size() * sizeof(int), 256);      // one tile-queue ticket per layer
     return total;
 }
 
@@ -246,13 +247,16 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
 
     std::vector<float*> base(m->bufs.size());
+    int* tickets = nullptr;
     {
         char* p = static_cast<char*>(workspace);
         for (size_t i = 0; i < m->bufs.size(); ++i) {
             base[i] = reinterpret_cast<float*>(p);
             p += om::align_up(m->buf_floats((int)i, B, H, W) * sizeof(float), 256);
         }
+        tickets = reinterpret_cast<int*>(p);
     }
+    OM_CHECK_HIP(hipMemsetAsync(tickets, 0, m->layers.size() * sizeof(int), stream));
     auto ptr_of = [&](const om::View& v) -> float* {
         switch (v.buf) {
             case om::BUF_BBOX32: return bbox32;
@@ -301,6 +305,7 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
         a.res_pix_stride = L.has_res ? m->pix_stride(L.res.buf) : 0;
         a.out_pix_stride = m->pix_stride(L.out.buf);
         a.out_mode = L.out_mode; a.up = L.up;
+        a.ticket = tickets + (&L - m->layers.data());
         int rc = om::launch_conv_igemm(a, stream);
         if (rc != OM_OK) {
             char msg[512];
