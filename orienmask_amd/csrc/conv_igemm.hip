@@ -165,36 +165,40 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p
             for (int j = 0; j < B_CH; ++j) sB[(lrow + 32 * j) * 8 + lsw] = rb[j];
         };
 
-        // ---- DMA path: descriptors and the per-step issue of the next operand tiles
+        // ---- DMA path: descriptors and the issue of ONE 1-KiB piece (8 rows x 128 B) per call
+        constexpr int NP = A_CH + B_CH;                     // pieces per wave per k-step
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         const float* in_base = p.in + (size_t)b_first * p.H * p.W * p.in_pix_stride;
         const int scol = lcol ^ ((lrow >> 1) & 7);          // logical chunk this lane fetches (LDS stays lane-linear)
-        auto issue_dma = [&](int s, int buf) {
+        const size_t in_left = ((size_t)p.total_in_pixels - (size_t)b_first * p.H * p.W) * p.in_pix_stride * 4;
+        const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_base), 0,
+                                                             in_left < 0x7FFFFFFFull ? (int)in_left : 0x7FFFFFFF, 0x00020000);
+        const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+        int n_kh = 0, n_kw = 0, n_cc = 0;                   // (tap row, tap col, cin chunk) of the step being fetched
+        auto advance = [&]() {
+            if (++n_cc == p.kc) {
+                n_cc = 0;
+                if (++n_kw == p.ks) { n_kw = 0; ++n_kh; }
+            }
+        };
+        auto issue_piece = [&](int piece, int buf, bool live) {
             if constexpr (DMA) {
-                const size_t in_left = ((size_t)p.total_in_pixels - (size_t)b_first * p.H * p.W) * p.in_pix_stride * 4;
-                const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_base), 0,
-                                                                     in_left < 0x7FFFFFFFull ? (int)in_left : 0x7FFFFFFF, 0x00020000);
-                const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
-                const int tap = s / p.kc;
-                const int cc = s - tap * p.kc;
-                const int kh = tap / p.ks;
-                const int kw = tap - kh * p.ks;
-                const int coff = cc * 32 + scol * 4;
-                f32x4* dstA = smem + buf * (BM + BN) * 8 + wave_u * 64;
-                f32x4* dstB = dstA + BM * 8;
-#pragma unroll
-                for (int j = 0; j < A_CH; ++j) {
-                    const int iy = iy0[j] + kh, ix = ix0[j] + kw;
-                    const bool ok = (((mokmask >> j) & 1u) != 0) & ((unsigned)iy < (unsigned)p.H) &
+                const int coff = n_cc * 32 + scol * 4;
+                f32x4* dst = smem + buf * (BM + BN) * 8 + wave_u * 64;
+                if (piece < A_CH) {
+                    const int j = piece;
+                    const int iy = iy0[j] + n_kh, ix = ix0[j] + n_kw;
+                    const bool ok = live & (((mokmask >> j) & 1u) != 0) & ((unsigned)iy < (unsigned)p.H) &
                                     ((unsigned)ix < (unsigned)p.W);      // bitwise: no branches around the loads
-                    const int voff = ok ? ((pixbase[j] + iy * p.W + ix) * p.in_pix_stride + coff) * 4 : (int)0x80000000;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(dstA + j * 256), 16, voff, 0, 0, 0);
+                    // branch-free: an invalid row just gets bit 31 set (>= num_records -> the DMA writes zeros)
+                    const int voff = (((pixbase[j] + iy * p.W + ix) * p.in_pix_stride + coff) * 4) | (ok ? 0 : (int)0x80000000);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(dst + j * 256), 16, voff, 0, 0, 0);
+                } else {
+                    const int j = piece - A_CH;
+                    const int tap = n_kh * p.ks + n_kw;
+                    const int voff = ((((n0 + lrow + 32 * j) * p.taps + tap) * p.cin + coff) * 4) | (live ? 0 : (int)0x80000000);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(dst + BM * 8 + j * 256), 16, voff, 0, 0, 0);
                 }
-                const int wbase = ((n0 + lrow) * p.taps + tap) * p.cin + coff;
-#pragma unroll
-                for (int j = 0; j < B_CH; ++j)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(dstB + j * 256), 16,
-                                                             (wbase + j * 32 * p.taps * p.cin) * 4, 0, 0, 0);
             }
         };
 
@@ -229,13 +233,72 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p
         };
 
         if constexpr (DMA) {
-            issue_dma(0, 0);
+            // Software pipeline with ONE barrier per k-step and nothing outside the MFMA stream:
+            //   slots 0..NP-1   : one DMA piece of step s+1 each
+            //   slot (q, t=1)   : ds_reads of fragment group q+1
+            //   end of slot 11  : barrier (this wave's DMA has landed, all reads of buffer s&1 are done)
+            //   slot 12         : ds_reads of step s+1's group 0 from the other buffer
+            // Inside a slot the address VALU, the DMA and the ds_reads are spread BETWEEN the slot's MFMAs
+            // (sched_group_barrier): a 64-cycle f32 MFMA hides ~10 issue slots, but only if the other
+            // instructions do not sit in one clump behind the last MFMA.
+            const f32x4* fragA = smem + (wm * WM + fi) * 8;
+            const f32x4* fragB = smem + BM * 8 + (wn * WN + fi) * 8;
+            f32x4 ca[TM], cb[TN], na[TM], nb[TN];
+            auto read_frags = [&](f32x4(&fa)[TM], f32x4(&fb)[TN], int buf, int q) {
+                const int ch = (2 * q + fk) ^ fsw;
+                const int bo = buf * (BM + BN) * 8;
+#pragma unroll
+                for (int a = 0; a < TM; ++a) fa[a] = fragA[bo + a * 32 * 8 + ch];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) fb[b] = fragB[bo + b * 32 * 8 + ch];
+            };
+#pragma unroll
+            for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 0, true);
+            advance();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            read_frags(ca, cb, 0, 0);
             for (int s = 0; s < p.ksteps; ++s) {
-                if (s + 1 < p.ksteps) issue_dma(s + 1, (s + 1) & 1);
-                compute(s & 1);
-                __syncthreads();          // also drains the LDS-DMA queue (vmcnt(0)) before anyone reads it
+                const int buf = s & 1;
+                const bool live = s + 1 < p.ksteps;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int slot = q * 4 + t;
+#pragma unroll
+                        for (int a = 0; a < TM; ++a)
+#pragma unroll
+                            for (int b = 0; b < TN; ++b)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[b][t], ca[a][t], acc[a][b], 0, 0, 0);
+                        if (t == 1 && q < 3) read_frags(na, nb, buf, q + 1);
+                        if (slot < NP) issue_piece(slot, buf ^ 1, live);
+                        if (slot == 12) read_frags(na, nb, buf ^ 1, 0);
+                        // interleave: MFMA, a few VALU/SALU, MFMA, ... then the DMA and the LDS reads
+#pragma unroll
+                        for (int i = 0; i < TM * TN; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // 1 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x006, (16 + TM * TN - 1) / (TM * TN), 0);  // VALU|SALU
+                            if (i == TM * TN - 2 || TM * TN == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);                    // DS reads
+                        if (slot == 11) {
+                            // the DMA of step s+1 must have landed before anyone reads it (do not rely on the
+                            // compiler to drain an LDS-DMA queue at a barrier)
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __syncthreads();
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) ca[a] = na[a];
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) cb[b] = nb[b];
+                }
+                advance();
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         } else {
             load_step(0);
             store_step(0);
@@ -368,6 +431,8 @@ static int launch_tile(IgemmParams p, int cout_pad, int blocks_per_cu, hipStream
     OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "conv: %lld tiles out of range", total);
     p.total_tiles = (int)total;
     long long grid = total;
+    static const int bpc_override = [] { const char* e = getenv("OM_CONV_BPC"); return e ? atoi(e) : 0; }();
+    if (bpc_override > 0) blocks_per_cu = bpc_override;
     if (p.ticket) grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
     if (use_dma())
         hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);

@@ -356,6 +356,12 @@ int om_conv2d(const float* in, int B, int H, int W, int cin, int in_pix_stride, 
     a.Ho = H / stride; a.Wo = W / stride; a.cout = cout; a.cout_pad = om::round_up(cout, 32);
     a.ks = ksize; a.stride = stride; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
     a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1;
+    // unit-test entry only: a library-owned ticket word so that the persistent tile queue (what om_forward
+    // uses, with tickets carved from the caller's workspace) is what gets tested and benchmarked
+    static int* g_ticket = nullptr;
+    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), 256));
+    OM_CHECK_HIP(hipMemsetAsync(g_ticket, 0, sizeof(int), static_cast<hipStream_t>(stream)));
+    a.ticket = g_ticket;
     return om::launch_conv_igemm(a, static_cast<hipStream_t>(stream));
 }
 
