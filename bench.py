@@ -142,13 +142,11 @@ def main():
 
     if rank == 0:
         specs = {s.name: s for s in arch.fpnplus_convs()}
+        kernel_of = dict(net.layer_kernels(B, H, W))
         tiles = {}
         for name, ms in layer_ms:
-            s = specs[name]
-            cpad = (s.cout + 31) // 32 * 32
-            kern = "stem" if name == "backbone.conv1" else ("igemm128" if cpad % 128 == 0 else "igemm64" if cpad % 64 == 0 else "igemm32")
-            wk = arch.layer_work(s, B, H, W)
-            t = tiles.setdefault(kern, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            wk = arch.layer_work(specs[name], B, H, W)
+            t = tiles.setdefault(kernel_of[name], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
             t["ms"] += ms / n_fw; t["flops"] += wk["flops"]; t["bytes"] += wk["bytes"]; t["launches"] += 1
         dom = max(tiles, key=lambda k: tiles[k]["ms"])
         d = tiles[dom]
@@ -158,7 +156,7 @@ def main():
         total_bytes = sum(t["bytes"] for t in tiles.values())
         roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
-                        kernel="conv_igemm_f32_kernel<128,128,64,64>" if dom == "igemm128" else dom,
+                        kernel=dom,
                         launches_per_step=d["launches"], avg_launch_ms=round(d["ms"] / d["launches"], 4),
                         kernel_ms_per_step=round(d["ms"], 3), forward_kernels_ms_per_step=round(fwd_ms, 3),
                         postprocess_ms_per_step=round(post_ms, 3),
@@ -172,7 +170,7 @@ def main():
                 print("%-28s %8.3f ms  %7.2f TF  %7.1f GB/s" % (name, ms / n_fw, wk["flops"] / (ms / n_fw * 1e-3) / 1e12,
                                                                wk["bytes"] / (ms / n_fw * 1e-3) / 1e9), file=sys.stderr)
             for k, t in sorted(tiles.items()):
-                print("%-10s %3d launches %8.3f ms %7.2f TF" % (k, t["launches"], t["ms"], t["flops"] / (t["ms"] * 1e-3) / 1e12),
+                print("%-34s %3d launches %8.3f ms %7.2f TF" % (k, t["launches"], t["ms"], t["flops"] / (t["ms"] * 1e-3) / 1e12),
                       file=sys.stderr)
         total_images = world * B * args.steps
         line = dict(metric="images/sec end-to-end (544^2, bs=32) forward+postprocess", value=round(total_images / elapsed, 2),

@@ -98,6 +98,9 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
  * (the reference measures with torch.cuda.Event pairs, utils/timer.py:70-82).  While enabled, every
  * om_forward records one event pair per layer; om_profile_read synchronises on them and returns the
  * summed milliseconds per layer (graph order of om_model_layer_info) and the number of forwards. */
+/* Tile shape (rows x channels per workgroup) of the conv kernel instantiation that runs layer `index` at
+ * this problem size; 0 x 0 for the stem kernel.  Lets a profile be grouped by kernel. */
+int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, int* bn);
 int om_profile_enable(om_model* m, int enable);
 int om_profile_read(om_model* m, float* layer_ms, int n_layers, int* n_forwards);
 

@@ -442,6 +442,12 @@ static int launch_tile(IgemmParams p, int cout_pad, int blocks_per_cu, hipStream
     return OM_OK;
 }
 
+void conv_tile_for(int M, int cout_pad, int* bm, int* bn) {
+    const TileChoice t = choose_tile(M, cout_pad);
+    *bm = t.bm;
+    *bn = t.bn;
+}
+
 int launch_conv_igemm(const ConvArgs& a, hipStream_t stream) {
     OM_REQUIRE(a.in && a.w && a.scale && a.shift && a.out, OM_EINVAL, "conv: null pointer");
     OM_REQUIRE(a.cin % 32 == 0 && a.cin >= 32, OM_EINVAL, "conv: cin=%d must be a multiple of 32", a.cin);

@@ -53,6 +53,7 @@ struct ConvArgs {
 };
 
 int launch_conv_igemm(const ConvArgs& a, hipStream_t stream);
+void conv_tile_for(int M, int cout_pad, int* bm, int* bn);   // tile shape launch_conv_igemm picks
 int launch_conv_stem(const float* in_nchw, int B, int H, int W, const float* w, const float* scale,
                      const float* shift, int cout, float* out_nhwc, hipStream_t stream);
 

@@ -318,6 +318,16 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
     return OM_OK;
 }
 
+int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, int* bn) {
+    OM_REQUIRE(m && bm && bn, OM_EINVAL, "om_layer_tile: null argument");
+    OM_REQUIRE(index >= 0 && index < (int)m->layers.size(), OM_EINVAL, "om_layer_tile: index %d", index);
+    const om::LayerDef& L = m->layers[index];
+    if (L.stem) { *bm = 0; *bn = 0; return OM_OK; }
+    const int Ho = H / L.in_div / L.info.stride, Wo = W / L.in_div / L.info.stride;
+    om::conv_tile_for(B * Ho * Wo, L.info.cout_pad, bm, bn);
+    return OM_OK;
+}
+
 int om_profile_enable(om_model* m, int enable) {
     OM_REQUIRE(m, OM_EINVAL, "om_profile_enable: null model");
     m->profiling = enable != 0;

@@ -49,6 +49,7 @@ SIGNATURES = {
     "om_model_load_weights": (_i, [_vp, _vp, _sz, _i]),
     "om_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "om_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "om_layer_tile": (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "om_profile_enable": (_i, [_vp, _i]),
     "om_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_float), _i, ctypes.POINTER(ctypes.c_int)]),
     "om_conv2d": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),

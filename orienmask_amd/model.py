@@ -170,6 +170,18 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         """Record one HIP event pair per layer on the launch stream during forward()."""
         _lib.check(_lib.load().om_profile_enable(self._ensure_handle(), 1 if enable else 0), "om_profile_enable")
 
+    def layer_kernels(self, B, H, W):
+        """Kernel instantiation that runs each layer at this size: 'conv_stem_kernel' or
+        'conv_igemm_f32_kernel<BM,BN>' (graph order)."""
+        h = self._ensure_handle()
+        out = []
+        for i, l in enumerate(self._layers):
+            bm, bn = ctypes.c_int(0), ctypes.c_int(0)
+            _lib.check(_lib.load().om_layer_tile(h, i, B, H, W, ctypes.byref(bm), ctypes.byref(bn)), "om_layer_tile")
+            out.append((l["name"], "conv_stem_kernel" if bm.value == 0 else
+                        "conv_igemm_f32_kernel<%d,%d>" % (bm.value, bn.value)))
+        return out
+
     def profile_read(self):
         """(list of (layer name, summed ms), number of forwards recorded); synchronises on the events."""
         h = self._ensure_handle()
