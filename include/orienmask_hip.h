@@ -54,6 +54,8 @@ typedef struct om_layer_info {
     int32_t has_bn;             /* 1: conv(bias=False)+BN+leaky;  0: conv(bias=True) only */
     int32_t leaky;
     int64_t w_off, scale_off, shift_off;
+    int64_t wino_off;           /* >= 0: Winograd F(2x2,3x3) weights U = G g G^T, [16][cout_pad][cin], for the
+                                   stride-1 3x3 layers; -1: none */
 } om_layer_info;
 
 /* Constants of OrienMaskYOLOPostProcess.__init__ (eval/orienmask_yolo_postprocess.py:9-37). */
@@ -100,7 +102,8 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
  * summed milliseconds per layer (graph order of om_model_layer_info) and the number of forwards. */
 /* Tile shape (rows x channels per workgroup) of the conv kernel instantiation that runs layer `index` at
  * this problem size; 0 x 0 for the stem kernel.  Lets a profile be grouped by kernel. */
-int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, int* bn);
+int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, int* bn, int* algo);
+/* algo: 0 = conv_stem_kernel, 1 = conv_igemm_f32_kernel<bm,bn>, 2 = wino_input_kernel + wino_gemm_kernel<bm,bn> */
 int om_profile_enable(om_model* m, int enable);
 int om_profile_read(om_model* m, float* layer_ms, int n_layers, int* n_forwards);
 
@@ -110,6 +113,13 @@ int om_profile_read(om_model* m, float* layer_ms, int n_layers, int* n_forwards)
 int om_conv2d(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* w,
               const float* scale, const float* shift, int cout, int ksize, int stride, int leaky,
               const float* res, int res_pix_stride, float* out, int out_pix_stride, om_stream stream);
+/* The same layer through Winograd F(2x2,3x3) (3x3, stride 1): u = G g G^T as [16][cout_pad][cin];
+ * scratch: om_conv2d_winograd_scratch_bytes(B,H,W,cin) bytes of device memory for the transformed input. */
+size_t om_conv2d_winograd_scratch_bytes(int B, int H, int W, int cin);
+int om_conv2d_winograd(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* u,
+                       const float* scale, const float* shift, int cout, int leaky, const float* res,
+                       int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
+                       om_stream stream);
 /* first layer: in [B,3,H,W] NCHW -> out [B,H,W,cout] NHWC, 3x3 stride 1. */
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale,
                    const float* shift, int cout, float* out, om_stream stream);

@@ -1,0 +1,361 @@
+// Winograd F(2x2, 3x3) convolution for gfx950 (stride-1 3x3 layers, 89 % of the forward's FLOPs).
+//
+//   Y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A        (Lavin & Gray 2015; 2.25x fewer multiplies)
+//
+// Same fused layer as conv_igemm.hip -- Conv2d(3x3, s1, p1) -> BatchNorm2d(eval) -> LeakyReLU(0.1)
+// (+ residual), /root/reference/model/base.py:104-137, /root/reference/model/backbone/darknet.py:14-15 --
+// evaluated in the transform domain:
+//
+//   wino_input_kernel   V[xi][tile][c] = (B^T d B)[xi] for every 4x4 input patch d (one patch per 2x2
+//                       output tile, zero padded); HBM-bound (reads X once, writes 4x its size).
+//   wino_gemm_kernel    16 independent GEMMs M_xi = V_xi (tiles x C) . U_xi (C x cout) on the f32 matrix
+//                       cores (v_mfma_f32_32x32x2_f32, exact fp32), with the inverse transform A^T M A
+//                       folded into the accumulator flush after each xi, so M never touches memory;
+//                       then the usual scale/shift/LeakyReLU/residual epilogue through LDS, four times
+//                       (one per output position of the 2x2 tile).
+//   U = G g G^T is computed once on the host in float64 (orienmask_amd/pack.py).
+//
+// The GEMM kernel is the slot-pipelined LDS-DMA loop of conv_igemm.hip with k = (xi, c): operands are
+// dense [rows][C] planes, so a DMA piece needs no address arithmetic at all (constant voffset per lane,
+// the channel chunk goes in the scalar offset, rows past the end are cut by the descriptor's size).
+// Numerics: F(2x2,3x3) in fp32 adds a few 1e-7 of relative error over direct convolution (the only
+// non-trivial constants are the 1/2 in G, applied in float64) -- far inside the 1e-4 parity budget.
+#include <cstdlib>
+
+#include "om_common.h"
+
+namespace om {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// ------------------------------------------------------------------------------------------------
+// input transform
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ in, float* __restrict__ V, int H,
+                                                         int W, int C, int pix_stride, int TH, int TW, int T) {
+    const int c4n = C >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = (int)(idx % c4n);
+    const long long tile = idx / c4n;
+    if (tile >= T) return;
+    const int b = (int)(tile / (TH * TW));
+    const int r = (int)(tile - (long long)b * TH * TW);
+    const int ty = r / TW, tx = r - ty * TW;
+    const float* base = in + (size_t)b * H * W * pix_stride + c4 * 4;
+    f32x4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = 2 * ty - 1 + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = 2 * tx - 1 + j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                v = *reinterpret_cast<const f32x4*>(base + ((size_t)y * W + x) * pix_stride);
+            d[i][j] = v;
+        }
+    }
+    // B^T d : rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
+    f32x4 t[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[0][j] = d[0][j] - d[2][j];
+        t[1][j] = d[1][j] + d[2][j];
+        t[2][j] = d[2][j] - d[1][j];
+        t[3][j] = d[1][j] - d[3][j];
+    }
+    const size_t plane = (size_t)T * C;
+    float* o = V + (size_t)tile * C + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 0) * plane) = t[i][0] - t[i][2];
+        *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 1) * plane) = t[i][1] + t[i][2];
+        *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 2) * plane) = t[i][2] - t[i][1];
+        *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 3) * plane) = t[i][1] - t[i][3];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM + inverse transform + epilogue
+// ------------------------------------------------------------------------------------------------
+struct WinoParams {
+    const float* V;       // [16][T][C]
+    const float* U;       // [16][cout_pad][C]
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* out;
+    int* ticket;
+    int T, TH, TW, C, kc;
+    int H, W, cout, cout_pad;
+    int n_tiles, total_tiles;
+    int leaky, res_pix_stride, out_pix_stride, vec_io;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NWN = BN / WN;
+    constexpr int A_CH = BM / 32, B_CH = BN / 32, NP = A_CH + B_CH;
+    constexpr int CH = BN / 4, RP = 256 / CH;
+    static_assert((BM / WM) * (BN / WN) == 4, "four waves per workgroup");
+    static_assert(BM * BN <= 2 * (BM + BN) * 32, "C tile must fit in the operand buffers");
+    __shared__ f32x4 smem[2 * (BM + BN) * 8 + 1];     // one LDS object (see conv_igemm.hip)
+    int* const s_ticket = reinterpret_cast<int*>(smem + 2 * (BM + BN) * 8);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int lrow = tid >> 3, lcol = tid & 7;
+    const int scol = lcol ^ ((lrow >> 1) & 7);
+    const int fi = lane & 31, fk = lane >> 5;
+    const int fsw = (fi >> 1) & 7;
+    const int ksteps = 16 * p.kc;
+    const size_t v_plane = (size_t)p.T * p.C, u_plane = (size_t)p.cout_pad * p.C;
+
+    for (;;) {
+        int tile;
+        if (p.ticket) {
+            if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+            __syncthreads();
+            tile = *s_ticket;
+        } else {
+            tile = blockIdx.x;
+        }
+        if (tile >= p.total_tiles) break;
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        const int tile_n = tile % p.n_tiles;
+        const int tile_m = tile / p.n_tiles;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+        const int rows_valid = min(BM, p.T - m0);
+
+        // per-lane byte offset of row 0's chunk; piece j adds 32 * j rows (kept as plain ints: passing an
+        // element of a captured array to the LDS-DMA builtin makes hipcc drop the kernel's host stub)
+        const int voff0 = (lrow * p.C + scol * 4) * 4;
+        const int voff_rows32 = 32 * p.C * 4;
+
+        int n_xi = 0, n_cc = 0;     // (transform index, channel chunk) of the step being fetched
+        auto advance = [&]() {
+            if (++n_cc == p.kc) { n_cc = 0; ++n_xi; }
+        };
+        auto issue_piece = [&](int piece, int buf, bool live) {
+            // rows beyond the valid range (M tail, or a dead prefetch) are cut by num_records -> zeros
+            const float* abase = p.V + (size_t)n_xi * v_plane + (size_t)m0 * p.C;
+            const float* bbase = p.U + (size_t)n_xi * u_plane + (size_t)n0 * p.C;
+            const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(abase), 0,
+                                                               live ? rows_valid * p.C * 4 : 0, 0x00020000);
+            const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bbase), 0, live ? BN * p.C * 4 : 0,
+                                                               0x00020000);
+            f32x4* dst = smem + buf * (BM + BN) * 8 + wave_u * 64;
+            const int soff = n_cc * 128;
+            if (piece < A_CH) {
+                const int vo = voff0 + piece * voff_rows32;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + piece * 256), 16, vo, soff, 0, 0);
+            } else {
+                const int vo = voff0 + (piece - A_CH) * voff_rows32;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(dst + BM * 8 + (piece - A_CH) * 256), 16, vo, soff,
+                                                         0, 0);
+            }
+        };
+
+        f32x16 acc[TM][TN], outa[2][2][TM][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[a][b][r] = 0.f;
+                    outa[0][0][a][b][r] = 0.f; outa[0][1][a][b][r] = 0.f;
+                    outa[1][0][a][b][r] = 0.f; outa[1][1][a][b][r] = 0.f;
+                }
+
+        const f32x4* fragA = smem + (wm * WM + fi) * 8;
+        const f32x4* fragB = smem + BM * 8 + (wn * WN + fi) * 8;
+        f32x4 ca[TM], cb[TN], na[TM], nb[TN];
+        auto read_frags = [&](f32x4(&fa)[TM], f32x4(&fb)[TN], int buf, int q) {
+            const int ch = (2 * q + fk) ^ fsw;
+            const int bo = buf * (BM + BN) * 8;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = fragA[bo + a * 32 * 8 + ch];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = fragB[bo + b * 32 * 8 + ch];
+        };
+
+#pragma unroll
+        for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 0, true);
+        advance();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        read_frags(ca, cb, 0, 0);
+        int xi = 0, cc = 0;
+        for (int s = 0; s < ksteps; ++s) {
+            const int buf = s & 1;
+            const bool live = s + 1 < ksteps;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int slot = q * 4 + t;
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[b][t], ca[a][t], acc[a][b], 0, 0, 0);
+                    if (t == 1 && q < 3) read_frags(na, nb, buf, q + 1);
+                    if (slot < NP) issue_piece(slot, buf ^ 1, live);
+                    if (slot == 12) read_frags(na, nb, buf ^ 1, 0);
+                    if (slot == 11) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int a = 0; a < TM; ++a) ca[a] = na[a];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) cb[b] = nb[b];
+            }
+            advance();
+            if (++cc == p.kc) {
+                // flush M_xi into the four outputs: Y[p][q] += A^T[p][i] * A^T[q][j] * M,  xi = 4 i + j,
+                // A^T = [[1, 1, 1, 0], [0, 1, -1, -1]]
+                const int i = xi >> 2, j = xi & 3;
+                const float ci0 = i < 3 ? 1.f : 0.f, ci1 = i == 0 ? 0.f : (i == 1 ? 1.f : -1.f);
+                const float cj0 = j < 3 ? 1.f : 0.f, cj1 = j == 0 ? 0.f : (j == 1 ? 1.f : -1.f);
+                const float c00 = ci0 * cj0, c01 = ci0 * cj1, c10 = ci1 * cj0, c11 = ci1 * cj1;
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        if (c00 != 0.f) outa[0][0][a][b] += acc[a][b] * c00;
+                        if (c01 != 0.f) outa[0][1][a][b] += acc[a][b] * c01;
+                        if (c10 != 0.f) outa[1][0][a][b] += acc[a][b] * c10;
+                        if (c11 != 0.f) outa[1][1][a][b] += acc[a][b] * c11;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+                    }
+                cc = 0;
+                ++xi;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // ---- epilogue: four output positions, each through the LDS C tile
+        f32x4* sC = smem;
+        const int n4 = tid % CH, r0 = tid / CH;
+        const int n = n0 + n4 * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+        const int nvalid = p.cout - n;
+        const bool vec = p.vec_io && nvalid >= 4;
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) {
+            const int py = pq >> 1, px = pq & 1;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int ml = wm * WM + a * 32 + fi;
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int c4 = (wn * WN + b * 32) / 4 + 2 * g + fk;
+                        const f32x16& o = outa[py][px][a][b];
+                        f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+                        sC[ml * CH + (c4 ^ (ml & 7))] = v;
+                    }
+            }
+            __syncthreads();
+#pragma unroll 2
+            for (int ps = 0; ps < BM / RP; ++ps) {
+                const int ml = ps * RP + r0;
+                const int m = m0 + ml;
+                if (m >= p.T || nvalid <= 0) continue;
+                const int bi = m / (p.TH * p.TW);
+                const int rr = m - bi * p.TH * p.TW;
+                const int ty = rr / p.TW, tx = rr - ty * p.TW;
+                const int y = 2 * ty + py, x = 2 * tx + px;
+                if (y >= p.H || x >= p.W) continue;
+                const size_t pix = ((size_t)bi * p.H + y) * p.W + x;
+                f32x4 v = sC[ml * CH + (n4 ^ (ml & 7))];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float tv = fmaf(v[k], sc[k], sh[k]);
+                    v[k] = p.leaky ? (tv > 0.f ? tv : tv * 0.1f) : tv;
+                }
+                float* o = p.out + pix * p.out_pix_stride + n;
+                if (p.res) {
+                    const float* rp = p.res + pix * p.res_pix_stride + n;
+                    if (vec) v += *reinterpret_cast<const f32x4*>(rp);
+                    else
+                        for (int k = 0; k < 4 && k < nvalid; ++k) v[k] += rp[k];
+                }
+                if (vec) *reinterpret_cast<f32x4*>(o) = v;
+                else
+                    for (int k = 0; k < 4 && k < nvalid; ++k) o[k] = v[k];
+            }
+            __syncthreads();
+        }
+        if (!p.ticket) break;
+    }
+}
+
+size_t wino_scratch_floats(int B, int H, int W, int C) {
+    const size_t T = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+    return 16 * T * C;
+}
+
+bool wino_enabled() {
+    static const int v = [] { const char* e = getenv("OM_WINOGRAD"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_wino_tile(WinoParams p, int blocks_per_cu, hipStream_t stream) {
+    const int m_tiles = (p.T + BM - 1) / BM;
+    p.n_tiles = p.cout_pad / BN;
+    const long long total = (long long)m_tiles * p.n_tiles;
+    OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "winograd: %lld tiles out of range", total);
+    p.total_tiles = (int)total;
+    long long grid = total;
+    if (p.ticket) grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
+    hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
+// a.w must point at the transformed weights U [16][cout_pad][cin]; scratch holds V (wino_scratch_floats).
+int launch_conv_winograd(const ConvArgs& a, float* scratch, hipStream_t stream) {
+    OM_REQUIRE(a.in && a.w && a.scale && a.shift && a.out && scratch, OM_EINVAL, "winograd: null pointer");
+    OM_REQUIRE(a.ks == 3 && a.stride == 1 && a.out_mode == 0, OM_EINVAL, "winograd: 3x3 stride-1 NHWC layers only");
+    OM_REQUIRE(a.cin % 32 == 0 && a.cin >= 32 && a.cout_pad % 64 == 0, OM_EINVAL, "winograd: cin=%d cout_pad=%d", a.cin,
+               a.cout_pad);
+    OM_REQUIRE(a.in_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0,
+               OM_EINVAL, "winograd: operands must be 16-byte aligned");
+    const int TH = (a.H + 1) / 2, TW = (a.W + 1) / 2;
+    const long long T = (long long)a.B * TH * TW;
+    OM_REQUIRE(T < (1ll << 31) && 16 * T * a.cin < (1ll << 40), OM_EINVAL, "winograd: problem too large");
+    const long long threads = T * (a.cin / 4);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a.in, scratch, a.H,
+                       a.W, a.cin, a.in_pix_stride, TH, TW, (int)T);
+    OM_CHECK_HIP(hipGetLastError());
+    WinoParams p;
+    p.V = scratch; p.U = a.w; p.scale = a.scale; p.shift = a.shift; p.res = a.res; p.out = a.out; p.ticket = a.ticket;
+    p.T = (int)T; p.TH = TH; p.TW = TW; p.C = a.cin; p.kc = a.cin / 32;
+    p.H = a.H; p.W = a.W; p.cout = a.cout; p.cout_pad = a.cout_pad;
+    p.n_tiles = 0; p.total_tiles = 0;
+    p.leaky = a.leaky; p.res_pix_stride = a.res_pix_stride; p.out_pix_stride = a.out_pix_stride;
+    p.vec_io = (a.out_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+                (!a.res || (a.res_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)))
+                   ? 1 : 0;
+    if (a.cout_pad % 128 == 0) return launch_wino_tile<64, 128, 32, 64>(p, 2, stream);
+    return launch_wino_tile<64, 64, 32, 32>(p, 3, stream);
+}
+
+}  // namespace om

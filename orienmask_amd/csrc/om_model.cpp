@@ -86,6 +86,12 @@ struct om_model {
         weight_floats = om::align_up(weight_floats, 4);
         L.info.scale_off = (int64_t)weight_floats; weight_floats += L.info.cout_pad;
         L.info.shift_off = (int64_t)weight_floats; weight_floats += L.info.cout_pad;
+        L.info.wino_off = -1;
+        if (ks == 3 && stride == 1 && !stem && L.info.cout_pad % 64 == 0 && cin % 32 == 0) {
+            weight_floats = om::align_up(weight_floats, 4);
+            L.info.wino_off = (int64_t)weight_floats;
+            weight_floats += (size_t)16 * L.info.cout_pad * cin;
+        }
         L.in = in; L.out = out; L.in_div = in_div; L.out_mode = out_mode; L.up = up; L.stem = stem;
         if (res) { L.res = *res; L.has_res = true; }
         layers.push_back(L);
@@ -177,6 +183,17 @@ struct om_model {
         add("orien_head.5", 256, A * 6, 1, 1, false, o, 4, View{om::BUF_ORIENS, 0}, nullptr, 2, 1);
     }
 
+    // largest transformed-input scratch any Winograd layer needs at this problem size
+    size_t wino_floats(int B, int H, int W) const {
+        size_t mx = 0;
+        for (const om::LayerDef& L : layers)
+            if (L.info.wino_off >= 0) {
+                const size_t f = om::wino_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin);
+                if (f > mx) mx = f;
+            }
+        return mx;
+    }
+
     size_t buf_floats(int i, int B, int H, int W) const {
         return (size_t)B * (H / bufs[i].div) * (W / bufs[i].div) * bufs[i].C;
     }
@@ -232,6 +249,7 @@ size_t om_forward_workspace_bytes(const om_model* m, int B, int H, int W) {
     size_t total = 0;
     for (size_t i = 0; i < m->bufs.size(); ++i) total += om::align_up(m->buf_floats((int)i, B, H, W) * sizeof(float), 256);
     total += om::align_up(m->layers.size() * sizeof(int), 256);      // one tile-queue ticket per layer
+    total += om::align_up(m->wino_floats(B, H, W) * sizeof(float), 256);   // Winograd transformed-input scratch
     return total;
 }
 
@@ -248,6 +266,7 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
 
     std::vector<float*> base(m->bufs.size());
     int* tickets = nullptr;
+    float* wino_scratch = nullptr;
     {
         char* p = static_cast<char*>(workspace);
         for (size_t i = 0; i < m->bufs.size(); ++i) {
@@ -255,6 +274,8 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
             p += om::align_up(m->buf_floats((int)i, B, H, W) * sizeof(float), 256);
         }
         tickets = reinterpret_cast<int*>(p);
+        p += om::align_up(m->layers.size() * sizeof(int), 256);
+        wino_scratch = reinterpret_cast<float*>(p);
     }
     OM_CHECK_HIP(hipMemsetAsync(tickets, 0, m->layers.size() * sizeof(int), stream));
     auto ptr_of = [&](const om::View& v) -> float* {
@@ -306,7 +327,13 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
         a.out_pix_stride = m->pix_stride(L.out.buf);
         a.out_mode = L.out_mode; a.up = L.up;
         a.ticket = tickets + (&L - m->layers.data());
-        int rc = om::launch_conv_igemm(a, stream);
+        int rc;
+        if (li.wino_off >= 0 && om::wino_enabled()) {
+            a.w = m->weights + li.wino_off;
+            rc = om::launch_conv_winograd(a, wino_scratch, stream);
+        } else {
+            rc = om::launch_conv_igemm(a, stream);
+        }
         if (rc != OM_OK) {
             char msg[512];
             std::snprintf(msg, sizeof(msg), "%s", om::g_err);
@@ -318,13 +345,18 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
     return OM_OK;
 }
 
-int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, int* bn) {
-    OM_REQUIRE(m && bm && bn, OM_EINVAL, "om_layer_tile: null argument");
+int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, int* bn, int* algo) {
+    OM_REQUIRE(m && bm && bn && algo, OM_EINVAL, "om_layer_tile: null argument");
     OM_REQUIRE(index >= 0 && index < (int)m->layers.size(), OM_EINVAL, "om_layer_tile: index %d", index);
     const om::LayerDef& L = m->layers[index];
-    if (L.stem) { *bm = 0; *bn = 0; return OM_OK; }
+    if (L.stem) { *bm = 0; *bn = 0; *algo = 0; return OM_OK; }
+    if (L.info.wino_off >= 0 && om::wino_enabled()) {
+        *bm = 64; *bn = L.info.cout_pad % 128 == 0 ? 128 : 64; *algo = 2;
+        return OM_OK;
+    }
     const int Ho = H / L.in_div / L.info.stride, Wo = W / L.in_div / L.info.stride;
     om::conv_tile_for(B * Ho * Wo, L.info.cout_pad, bm, bn);
+    *algo = 1;
     return OM_OK;
 }
 
@@ -373,6 +405,31 @@ int om_conv2d(const float* in, int B, int H, int W, int cin, int in_pix_stride, 
     OM_CHECK_HIP(hipMemsetAsync(g_ticket, 0, sizeof(int), static_cast<hipStream_t>(stream)));
     a.ticket = g_ticket;
     return om::launch_conv_igemm(a, static_cast<hipStream_t>(stream));
+}
+
+size_t om_conv2d_winograd_scratch_bytes(int B, int H, int W, int cin) {
+    if (B <= 0 || H <= 0 || W <= 0 || cin <= 0) return 0;
+    return om::align_up(om::wino_scratch_floats(B, H, W, cin) * sizeof(float), 256);
+}
+
+int om_conv2d_winograd(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* u,
+                       const float* scale, const float* shift, int cout, int leaky, const float* res,
+                       int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
+                       om_stream stream) {
+    OM_REQUIRE(B > 0 && H > 0 && W > 0, OM_EINVAL, "om_conv2d_winograd: bad shape");
+    OM_REQUIRE(scratch && scratch_bytes >= om_conv2d_winograd_scratch_bytes(B, H, W, cin), OM_ENOMEM,
+               "om_conv2d_winograd: scratch too small");
+    om::ConvArgs a;
+    a.in = in; a.w = u; a.scale = scale; a.shift = shift; a.res = res; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.cin = cin; a.in_pix_stride = in_pix_stride;
+    a.Ho = H; a.Wo = W; a.cout = cout; a.cout_pad = om::round_up(cout, 64);
+    a.ks = 3; a.stride = 1; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
+    a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1;
+    static int* g_ticket = nullptr;
+    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), 256));
+    OM_CHECK_HIP(hipMemsetAsync(g_ticket, 0, sizeof(int), static_cast<hipStream_t>(stream)));
+    a.ticket = g_ticket;
+    return om::launch_conv_winograd(a, static_cast<float*>(scratch), static_cast<hipStream_t>(stream));
 }
 
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale, const float* shift,

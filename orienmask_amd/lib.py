@@ -18,7 +18,8 @@ class LayerInfo(ctypes.Structure):
                 ("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("cout_pad", ctypes.c_int32),
                 ("ksize", ctypes.c_int32), ("stride", ctypes.c_int32),
                 ("has_bn", ctypes.c_int32), ("leaky", ctypes.c_int32),
-                ("w_off", ctypes.c_int64), ("scale_off", ctypes.c_int64), ("shift_off", ctypes.c_int64)]
+                ("w_off", ctypes.c_int64), ("scale_off", ctypes.c_int64), ("shift_off", ctypes.c_int64),
+                ("wino_off", ctypes.c_int64)]
 
 
 class PostCfg(ctypes.Structure):
@@ -49,7 +50,10 @@ SIGNATURES = {
     "om_model_load_weights": (_i, [_vp, _vp, _sz, _i]),
     "om_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "om_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "om_layer_tile": (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "om_layer_tile": (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                           ctypes.POINTER(ctypes.c_int)]),
+    "om_conv2d_winograd_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "om_conv2d_winograd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "om_profile_enable": (_i, [_vp, _i]),
     "om_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_float), _i, ctypes.POINTER(ctypes.c_int)]),
     "om_conv2d": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),

@@ -176,10 +176,11 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         h = self._ensure_handle()
         out = []
         for i, l in enumerate(self._layers):
-            bm, bn = ctypes.c_int(0), ctypes.c_int(0)
-            _lib.check(_lib.load().om_layer_tile(h, i, B, H, W, ctypes.byref(bm), ctypes.byref(bn)), "om_layer_tile")
-            out.append((l["name"], "conv_stem_kernel" if bm.value == 0 else
-                        "conv_igemm_f32_kernel<%d,%d>" % (bm.value, bn.value)))
+            bm, bn, algo = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+            _lib.check(_lib.load().om_layer_tile(h, i, B, H, W, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(algo)),
+                       "om_layer_tile")
+            out.append((l["name"], ("conv_stem_kernel", "conv_igemm_f32_kernel<%d,%d>", "wino_gemm_kernel<%d,%d>")[algo.value]
+                        % ((bm.value, bn.value) if algo.value else ())))
         return out
 
     def profile_read(self):

@@ -28,7 +28,8 @@ def graph_layers(handle):
         _lib.check(L.om_model_layer_info(handle, i, ctypes.byref(info)), "om_model_layer_info")
         out.append(dict(name=info.name.decode(), cin=info.cin, cout=info.cout, cout_pad=info.cout_pad,
                         ksize=info.ksize, stride=info.stride, has_bn=bool(info.has_bn), leaky=bool(info.leaky),
-                        w_off=info.w_off, scale_off=info.scale_off, shift_off=info.shift_off))
+                        w_off=info.w_off, scale_off=info.scale_off, shift_off=info.shift_off,
+                        wino_off=info.wino_off))
     return out
 
 
@@ -48,6 +49,19 @@ def unwrap_checkpoint(obj):
     if isinstance(obj, dict) and "state_dict" in obj and isinstance(obj["state_dict"], dict):
         return obj["state_dict"]
     return obj
+
+
+# Winograd F(2x2,3x3) kernel transform matrix (Lavin & Gray 2015): U = G g G^T
+_WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+
+
+def winograd_weights(w, cout_pad):
+    """[cout,cin,3,3] -> U [16][cout_pad][cin] float32 (rows >= cout zero), computed in float64."""
+    cout, cin = w.shape[0], w.shape[1]
+    u = torch.einsum("ir,ncrs,js->ijnc", _WINO_G, w.detach().double().cpu(), _WINO_G).reshape(16, cout, cin)
+    out = torch.zeros(16, cout_pad, cin, dtype=torch.float32)
+    out[:, :cout] = u.float()
+    return out
 
 
 def pack_state_dict(state_dict, layers, total_floats):
@@ -73,4 +87,6 @@ def pack_state_dict(state_dict, layers, total_floats):
         blob[l["w_off"]:l["w_off"] + cout * k * k * cin] = ohwi.reshape(-1)
         blob[l["scale_off"]:l["scale_off"] + cout] = scale.float()
         blob[l["shift_off"]:l["shift_off"] + cout] = shift.float()
+        if l.get("wino_off", -1) >= 0:
+            blob[l["wino_off"]:l["wino_off"] + 16 * cpad * cin] = winograd_weights(w, cpad).reshape(-1)
     return blob

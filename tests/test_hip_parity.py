@@ -88,6 +88,53 @@ def test_conv_layer_matches_torch(dev, case):
     assert _rel_err(got, want) < 2e-6, case
 
 
+WINO_CASES = [
+    # B, H, W, cin, cout, leaky, residual
+    (2, 16, 16, 32, 64, 1, True),
+    (1, 17, 17, 64, 128, 1, False),      # odd size: the last tile row/column is half outside
+    (3, 8, 12, 128, 256, 1, True),
+    (2, 34, 34, 128, 256, 0, False),
+    (5, 5, 7, 256, 512, 1, True),
+    (1, 68, 68, 32, 64, 1, True),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_winograd_layer_matches_torch(dev, case):
+    """Winograd F(2x2,3x3) path vs float64 direct convolution."""
+    from orienmask_amd.pack import winograd_weights
+    B, H, W, cin, cout, leaky, use_res = case
+    L = omlib.load()
+    g = torch.Generator().manual_seed(sum(case) + 7)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.2
+    res = torch.randn(B, cout, H, W, generator=g) if use_res else None
+    want = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+    want = want * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if leaky:
+        want = torch.where(want > 0, want, want * 0.1)
+    if use_res:
+        want = want + res.double()
+    cpad = (cout + 63) // 64 * 64
+    ud = winograd_weights(w, cpad).contiguous().to(dev)
+    sp = torch.zeros(cpad); sp[:cout] = scale
+    hp = torch.zeros(cpad); hp[:cout] = shift
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    sd_, hd = sp.to(dev), hp.to(dev)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None
+    out = torch.full((B, H, W, cout), float("nan"), device=dev)
+    scratch = torch.empty(L.om_conv2d_winograd_scratch_bytes(B, H, W, cin), dtype=torch.uint8, device=dev)
+    rc = L.om_conv2d_winograd(_p(xd), B, H, W, cin, cin, _p(ud), _p(sd_), _p(hd), cout, leaky,
+                              _p(rd) if use_res else None, cout if use_res else 0, _p(out), cout, _p(scratch),
+                              scratch.numel(), omlib.current_stream_ptr(dev))
+    omlib.check(rc, "om_conv2d_winograd")
+    got = out.cpu().permute(0, 3, 1, 2).double()
+    assert torch.isfinite(got).all()
+    assert _rel_err(got, want) < 5e-6, case
+
+
 def test_stem_matches_torch(dev):
     L = omlib.load()
     g = torch.Generator().manual_seed(3)

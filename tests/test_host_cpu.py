@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(built):
 
 
 def test_struct_layouts_match_header(built):
-    assert ctypes.sizeof(omlib.LayerInfo) == 64 + 7 * 4 + 4 + 3 * 8      # 4 bytes of padding before the int64s
+    assert ctypes.sizeof(omlib.LayerInfo) == 64 + 7 * 4 + 4 + 4 * 8      # 4 bytes of padding before the int64s
     assert ctypes.sizeof(omlib.PostCfg) == 4 * (1 + 3 + 3 + 2 + 1 + 9 + 9 + 9 + 1 + 2 + 2 + 1 + 1)
 
 
@@ -77,6 +77,14 @@ def test_pack_folds_batchnorm(built):
     assert torch.equal(blob[l["scale_off"]:l["scale_off"] + 256], torch.cat([torch.ones(255), torch.zeros(1)]))
     assert torch.equal(blob[l["shift_off"]:l["shift_off"] + 255], sd["bbox_head16.1.bias"])
     assert blob[l["w_off"] + 255 * 512:l["w_off"] + 256 * 512].abs().sum() == 0
+    assert l["wino_off"] == -1
+    # Winograd weights of a stride-1 3x3 layer: U = G g G^T; xi = 0 is g[0][0], xi = 15 is g[2][2],
+    # xi = 5 is the sum of all nine taps / 4
+    l = by_name["backbone.conv3.1.conv.1"]
+    assert l["wino_off"] >= 0 and by_name["backbone.conv3.0"]["wino_off"] == -1 and by_name["backbone.conv1"]["wino_off"] == -1
+    u = blob[l["wino_off"]:l["wino_off"] + 16 * 128 * 64].view(16, 128, 64)
+    assert torch.equal(u[0], w[:, :, 0, 0]) and torch.equal(u[15], w[:, :, 2, 2])
+    assert torch.allclose(u[5], w.double().sum((2, 3)).float() / 4, rtol=1e-6, atol=1e-8)
 
 
 def test_registry_builders_mirror_reference(built):
