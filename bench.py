@@ -10,10 +10,11 @@ synthetic 544x544 images already resident in HBM (BASELINE.json configs[2]).  Ea
 batch (weak scaling, no collective in the timed region); rank 0's packed weights are broadcast once
 over RCCL before timing.  Rank 0 prints ONE JSON line.
 
-roofline:     the dominant kernel is the f32-MFMA implicit-GEMM convolution (128x128 tile).  achieved =
-              algorithmic FLOPs of the layers it runs / their summed duration, measured live with HIP
-              events on the launch stream over the timed steps (om_profile_*); peak = 157.3 TFLOP/s
-              (f32-input MFMA, MI355X_MICROARCH.md).  The forward is FLOP-bound in fp32.
+roofline:     the dominant kernel (the Winograd GEMM on the f32 matrix cores).  achieved = ALGORITHMIC
+              (direct-convolution) FLOPs of the layers it runs / their summed duration, measured live with
+              HIP events on the launch stream over the timed steps (om_profile_*); peak = 157.3 TFLOP/s
+              (f32-input MFMA, MI355X_MICROARCH.md).  The forward is FLOP-bound in fp32 (SURVEY.md 8d);
+              Winograd executes 2.25x fewer multiplies, which is how frac can exceed 1 (executed_* fields).
 cpu_baseline: the CPU oracle (torch-CPU restatement of the reference, oracle/) on the host cores, on a
               bounded sample, N=1 only.  Checker code, timed beside the product, never part of it.
 """
@@ -143,35 +144,52 @@ def main():
     if rank == 0:
         specs = {s.name: s for s in arch.fpnplus_convs()}
         kernel_of = dict(net.layer_kernels(B, H, W))
-        tiles = {}
-        for name, ms in layer_ms:
+        kern = {}
+
+        def acc(name, ms, flops, exec_flops, byts):
+            t = kern.setdefault(name, dict(ms=0.0, flops=0.0, exec_flops=0.0, bytes=0.0, launches=0))
+            t["ms"] += ms; t["flops"] += flops; t["exec_flops"] += exec_flops; t["bytes"] += byts; t["launches"] += 1
+
+        for name, ms, pre in layer_ms:
             wk = arch.layer_work(specs[name], B, H, W)
-            t = tiles.setdefault(kernel_of[name], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-            t["ms"] += ms / n_fw; t["flops"] += wk["flops"]; t["bytes"] += wk["bytes"]; t["launches"] += 1
-        dom = max(tiles, key=lambda k: tiles[k]["ms"])
-        d = tiles[dom]
-        fwd_ms = sum(t["ms"] for t in tiles.values())
+            k = kernel_of[name]
+            wino = k.startswith("wino")
+            # Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36 -> executed = algorithmic / 2.25
+            acc(k, ms / n_fw, wk["flops"], wk["flops"] / 2.25 if wino else wk["flops"], wk["bytes"])
+            if wino:
+                acc("wino_input_kernel", pre / n_fw, 0.0, 0.0, 5.0 * 4 * B * (H // arch.layer_div(specs[name])) ** 2 * specs[name].cin)
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        d = kern[dom]
+        fwd_ms = sum(t["ms"] for t in kern.values())
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        total_flops = sum(t["flops"] for t in tiles.values())
-        total_bytes = sum(t["bytes"] for t in tiles.values())
+        executed = d["exec_flops"] / (d["ms"] * 1e-3) / 1e12
+        total_flops = sum(t["flops"] for t in kern.values())
+        total_bytes = sum(t["bytes"] for t in kern.values())
         roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
                         kernel=dom,
                         launches_per_step=d["launches"], avg_launch_ms=round(d["ms"] / d["launches"], 4),
-                        kernel_ms_per_step=round(d["ms"], 3), forward_kernels_ms_per_step=round(fwd_ms, 3),
-                        postprocess_ms_per_step=round(post_ms, 3),
+                        kernel_ms_per_step=round(d["ms"], 3),
+                        executed_tflops=round(executed, 2), executed_frac=round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+                        note="achieved counts ALGORITHMIC (direct-convolution) flops; the Winograd F(2x2,3x3) kernels "
+                             "execute 2.25x fewer multiplies, so frac may exceed 1 -- executed_* is what the matrix "
+                             "pipe actually ran (exact fp32 MFMA)",
+                        forward_kernels_ms_per_step=round(fwd_ms, 3), postprocess_ms_per_step=round(post_ms, 3),
                         forward_tflops=round(total_flops / (fwd_ms * 1e-3) / 1e12, 2),
                         forward_hbm_algorithmic_gbs=round(total_bytes / (fwd_ms * 1e-3) / 1e9, 1),
                         forward_hbm_frac=round(total_bytes / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                        binding="fp32 FLOPs (f32-input MFMA); HBM bound is ~9x further away (SURVEY.md 8d)")
+                        binding="fp32 FLOPs on the f32-input matrix cores; the HBM bound is several x further away")
         if args.layers:
-            for name, ms in layer_ms:
+            for name, ms, pre in layer_ms:
                 wk = arch.layer_work(specs[name], B, H, W)
-                print("%-28s %8.3f ms  %7.2f TF  %7.1f GB/s" % (name, ms / n_fw, wk["flops"] / (ms / n_fw * 1e-3) / 1e12,
-                                                               wk["bytes"] / (ms / n_fw * 1e-3) / 1e9), file=sys.stderr)
-            for k, t in sorted(tiles.items()):
-                print("%-34s %3d launches %8.3f ms %7.2f TF" % (k, t["launches"], t["ms"], t["flops"] / (t["ms"] * 1e-3) / 1e12),
-                      file=sys.stderr)
+                tot = (ms + pre) / n_fw
+                print("%-28s %8.3f ms (pre %6.3f)  %7.2f TF  %7.1f GB/s  %s" % (
+                    name, tot, pre / n_fw, wk["flops"] / (tot * 1e-3) / 1e12, wk["bytes"] / (tot * 1e-3) / 1e9,
+                    kernel_of[name]), file=sys.stderr)
+            for k, t in sorted(kern.items()):
+                print("%-34s %3d launches %8.3f ms %7.2f TF algorithmic %7.2f TF executed %7.1f GB/s" % (
+                    k, t["launches"], t["ms"], t["flops"] / (t["ms"] * 1e-3) / 1e12,
+                    t["exec_flops"] / (t["ms"] * 1e-3) / 1e12, t["bytes"] / (t["ms"] * 1e-3) / 1e9), file=sys.stderr)
         total_images = world * B * args.steps
         line = dict(metric="images/sec end-to-end (544^2, bs=32) forward+postprocess", value=round(total_images / elapsed, 2),
                     unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,

@@ -98,14 +98,16 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
 
 /* ---- measurement: per-layer durations with HIP events on the stream om_forward launches on
  * (the reference measures with torch.cuda.Event pairs, utils/timer.py:70-82).  While enabled, every
- * om_forward records one event pair per layer; om_profile_read synchronises on them and returns the
- * summed milliseconds per layer (graph order of om_model_layer_info) and the number of forwards. */
+ * om_forward records events around every kernel of every layer; om_profile_read synchronises on them and
+ * returns, per layer (graph order of om_model_layer_info) and summed over the recorded forwards, the
+ * milliseconds of the layer's main kernel (layer_ms) and of its pre-pass (layer_pre_ms: the Winograd input
+ * transform; 0 for single-kernel layers), plus the number of forwards. */
 /* Tile shape (rows x channels per workgroup) of the conv kernel instantiation that runs layer `index` at
  * this problem size; 0 x 0 for the stem kernel.  Lets a profile be grouped by kernel. */
 int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, int* bn, int* algo);
 /* algo: 0 = conv_stem_kernel, 1 = conv_igemm_f32_kernel<bm,bn>, 2 = wino_input_kernel + wino_gemm_kernel<bm,bn> */
 int om_profile_enable(om_model* m, int enable);
-int om_profile_read(om_model* m, float* layer_ms, int n_layers, int* n_forwards);
+int om_profile_read(om_model* m, float* layer_ms, float* layer_pre_ms, int n_layers, int* n_forwards);
 
 /* ---- one convolution (unit-test entry) ----------------------------------------------------- */
 /* in: [B,H,W,cin] NHWC (pixel stride in_pix_stride floats); w/scale/shift as in om_layer_info;

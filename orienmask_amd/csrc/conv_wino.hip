@@ -345,6 +345,7 @@ int launch_conv_winograd(const ConvArgs& a, float* scratch, hipStream_t stream) 
     hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a.in, scratch, a.H,
                        a.W, a.cin, a.in_pix_stride, TH, TW, (int)T);
     OM_CHECK_HIP(hipGetLastError());
+    if (a.mid_event) OM_CHECK_HIP(hipEventRecord(a.mid_event, stream));
     WinoParams p;
     p.V = scratch; p.U = a.w; p.scale = a.scale; p.shift = a.shift; p.res = a.res; p.out = a.out; p.ticket = a.ticket;
     p.T = (int)T; p.TH = TH; p.TW = TW; p.C = a.cin; p.kc = a.cin / 32;

@@ -41,6 +41,7 @@ struct ConvArgs {
     const float* res;       // optional NHWC view [B,Ho,Wo,cout], added after the activation
     float* out;
     int* ticket = nullptr;  // device int zeroed before the launch (dynamic tile queue); nullptr = static grid
+    hipEvent_t mid_event = nullptr;   // profiling: recorded between the two kernels of a Winograd layer
     int B, H, W, cin, in_pix_stride;
     int Ho, Wo, cout, cout_pad;
     int ks, stride;

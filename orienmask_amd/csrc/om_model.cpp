@@ -63,7 +63,7 @@ struct om_model {
     const float* weights = nullptr;
     // optional per-layer timing with HIP events on the launch stream (om_profile_*)
     bool profiling = false;
-    std::vector<hipEvent_t> ev_pool;     // 2 events per (recorded forward, layer)
+    std::vector<hipEvent_t> ev_pool;     // 3 events per (recorded forward, layer): start, mid, stop
     size_t ev_used = 0;
     int prof_forwards = 0;
 
@@ -290,18 +290,19 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
 
     for (const om::LayerDef& L : m->layers) {
         const om_layer_info& li = L.info;
-        hipEvent_t ev_stop = nullptr;
+        hipEvent_t ev_stop = nullptr, ev_mid = nullptr;
         if (m->profiling) {
-            if (m->ev_used + 2 > m->ev_pool.size()) {
-                for (int k = 0; k < 2; ++k) {
+            if (m->ev_used + 3 > m->ev_pool.size()) {
+                for (int k = 0; k < 3; ++k) {
                     hipEvent_t e;
                     OM_CHECK_HIP(hipEventCreate(&e));
                     m->ev_pool.push_back(e);
                 }
             }
             OM_CHECK_HIP(hipEventRecord(m->ev_pool[m->ev_used], stream));
-            ev_stop = m->ev_pool[m->ev_used + 1];
-            m->ev_used += 2;
+            ev_mid = m->ev_pool[m->ev_used + 1];
+            ev_stop = m->ev_pool[m->ev_used + 2];
+            m->ev_used += 3;
         }
         struct StopGuard {
             hipEvent_t e; hipStream_t s;
@@ -312,6 +313,7 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
         const float* shift = m->weights + li.shift_off;
         const int Hin = H / L.in_div, Win = W / L.in_div;
         if (L.stem) {
+            if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
             int rc = om::launch_conv_stem(x, B, Hin, Win, w, scale, shift, li.cout, ptr_of(L.out), stream);
             if (rc != OM_OK) return rc;
             continue;
@@ -330,8 +332,10 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
         int rc;
         if (li.wino_off >= 0 && om::wino_enabled()) {
             a.w = m->weights + li.wino_off;
+            a.mid_event = ev_mid;
             rc = om::launch_conv_winograd(a, wino_scratch, stream);
         } else {
+            if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));     // single-kernel layer: mid == start
             rc = om::launch_conv_igemm(a, stream);
         }
         if (rc != OM_OK) {
@@ -368,20 +372,22 @@ int om_profile_enable(om_model* m, int enable) {
     return OM_OK;
 }
 
-int om_profile_read(om_model* m, float* layer_ms, int n_layers, int* n_forwards) {
-    OM_REQUIRE(m && layer_ms && n_forwards, OM_EINVAL, "om_profile_read: null argument");
+int om_profile_read(om_model* m, float* layer_ms, float* layer_pre_ms, int n_layers, int* n_forwards) {
+    OM_REQUIRE(m && layer_ms && layer_pre_ms && n_forwards, OM_EINVAL, "om_profile_read: null argument");
     OM_REQUIRE(n_layers == (int)m->layers.size(), OM_EINVAL, "om_profile_read: n_layers=%d, graph has %zu", n_layers,
                m->layers.size());
-    OM_REQUIRE(m->ev_used == (size_t)m->prof_forwards * m->layers.size() * 2, OM_ESTATE,
+    OM_REQUIRE(m->ev_used == (size_t)m->prof_forwards * m->layers.size() * 3, OM_ESTATE,
                "om_profile_read: a profiled forward failed part-way");
-    for (int i = 0; i < n_layers; ++i) layer_ms[i] = 0.f;
+    for (int i = 0; i < n_layers; ++i) layer_ms[i] = layer_pre_ms[i] = 0.f;
     size_t e = 0;
     for (int f = 0; f < m->prof_forwards; ++f)
-        for (int i = 0; i < n_layers; ++i, e += 2) {
-            OM_CHECK_HIP(hipEventSynchronize(m->ev_pool[e + 1]));
-            float ms = 0.f;
-            OM_CHECK_HIP(hipEventElapsedTime(&ms, m->ev_pool[e], m->ev_pool[e + 1]));
-            layer_ms[i] += ms;
+        for (int i = 0; i < n_layers; ++i, e += 3) {
+            OM_CHECK_HIP(hipEventSynchronize(m->ev_pool[e + 2]));
+            float pre = 0.f, main = 0.f;
+            OM_CHECK_HIP(hipEventElapsedTime(&pre, m->ev_pool[e], m->ev_pool[e + 1]));
+            OM_CHECK_HIP(hipEventElapsedTime(&main, m->ev_pool[e + 1], m->ev_pool[e + 2]));
+            layer_pre_ms[i] += pre;
+            layer_ms[i] += main;
         }
     *n_forwards = m->prof_forwards;
     return OM_OK;

@@ -55,7 +55,8 @@ SIGNATURES = {
     "om_conv2d_winograd_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "om_conv2d_winograd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "om_profile_enable": (_i, [_vp, _i]),
-    "om_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_float), _i, ctypes.POINTER(ctypes.c_int)]),
+    "om_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _i,
+                             ctypes.POINTER(ctypes.c_int)]),
     "om_conv2d": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "om_conv2d_stem": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "om_postprocess_workspace_bytes": (_sz, [ctypes.POINTER(PostCfg), _i]),

@@ -184,13 +184,15 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         return out
 
     def profile_read(self):
-        """(list of (layer name, summed ms), number of forwards recorded); synchronises on the events."""
+        """(list of (layer name, main-kernel ms, pre-pass ms) summed over the recorded forwards, number of
+        forwards); synchronises on the events.  The pre-pass is the Winograd input transform."""
         h = self._ensure_handle()
         n = len(self._layers)
         ms = (ctypes.c_float * n)()
+        pre = (ctypes.c_float * n)()
         nf = ctypes.c_int(0)
-        _lib.check(_lib.load().om_profile_read(h, ms, n, ctypes.byref(nf)), "om_profile_read")
-        return [(self._layers[i]["name"], float(ms[i])) for i in range(n)], nf.value
+        _lib.check(_lib.load().om_profile_read(h, ms, pre, n, ctypes.byref(nf)), "om_profile_read")
+        return [(self._layers[i]["name"], float(ms[i]), float(pre[i])) for i in range(n)], nf.value
 
     def __del__(self):
         try:

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--shapes", default=",".join(SHAPES))
+    ap.add_argument("--wino", action="store_true", help="run the 3x3 stride-1 shapes through Winograd F(2x2,3x3)")
     args = ap.parse_args()
     L = omlib.load()
     dev = torch.device("cuda:0")
@@ -55,7 +56,23 @@ def main():
         out = torch.empty(B, Ho, Ho, cout, device=dev)
         st = omlib.current_stream_ptr(dev)
 
+        wino = args.wino and k == 3 and s == 1
+        if wino:
+            from orienmask_amd.pack import winograd_weights
+            cpad = (cout + 63) // 64 * 64
+            w = winograd_weights(torch.randn(cout, cin, 3, 3) * 0.05, cpad).to(dev)
+            sc = torch.ones(cpad, device=dev); sh = torch.zeros(cpad, device=dev)
+            scratch = torch.empty(L.om_conv2d_winograd_scratch_bytes(B, H, H, cin), dtype=torch.uint8, device=dev)
+
         def run():
+            if wino:
+                rc = L.om_conv2d_winograd(ctypes.c_void_p(x.data_ptr()), B, H, H, cin, cin, ctypes.c_void_p(w.data_ptr()),
+                                          ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(sh.data_ptr()), cout, 1,
+                                          ctypes.c_void_p(r.data_ptr()) if res else None, cout if res else 0,
+                                          ctypes.c_void_p(out.data_ptr()), cout, ctypes.c_void_p(scratch.data_ptr()),
+                                          scratch.numel(), st)
+                omlib.check(rc, "om_conv2d_winograd")
+                return
             rc = L.om_conv2d(ctypes.c_void_p(x.data_ptr()), B, H, H, cin, cin, ctypes.c_void_p(w.data_ptr()),
                              ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(sh.data_ptr()), cout, k, s, 1,
                              ctypes.c_void_p(r.data_ptr()) if res else None, cout if res else 0,
