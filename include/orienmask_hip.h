@@ -126,6 +126,18 @@ int om_conv2d_winograd(const float* in, int B, int H, int W, int cin, int in_pix
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale,
                    const float* shift, int cout, float* out, om_stream stream);
 
+/* ---- preprocess: FastCOCOTransform.__call__ + pad, fused ------------------------------
+ * Replaces /root/reference/data/transform.py:444-510 (permute, Resize = F.interpolate bilinear
+ * align_corners=False, Normalize = (x - mean) / std) and /root/reference/infer.py:21-32 (zero padding to a
+ * multiple of 32).  in: [N,h,w,3] float32 HWC; the image is resized to resize_h x resize_w, normalised and
+ * placed at (pad_top, pad_left) of the [N,3,out_h,out_w] NCHW output; everything else is pad_value. */
+int om_preprocess(const float* in_nhwc, int N, int h, int w, int resize_h, int resize_w, const float* mean3,
+                  const float* std3, int pad_top, int pad_left, int out_h, int out_w, float pad_value, float* out_nchw,
+                  om_stream stream);
+/* pad() alone on an NCHW tensor of `planes` = N*C planes. */
+int om_pad_nchw(const float* in, long long planes, int h, int w, int pad_top, int pad_left, int out_h, int out_w,
+                float pad_value, float* out, om_stream stream);
+
 /* ---- postprocess -------------------------------------------------------------------------- */
 size_t om_postprocess_workspace_bytes(const om_post_cfg* cfg, int B);
 /* out_bbox [B,nms_post,5] (cx,cy,w,h normalised, score); out_cls [B,nms_post] int64;

@@ -339,3 +339,32 @@ def bilinear_x4_restated(plane):
     top = fma(p[y0][:, x0], wx0b, (p[y0][:, x1] * wx1b).astype(np.float32))
     bot = fma(p[y1][:, x0], wx0b, (p[y1][:, x1] * wx1b).astype(np.float32))
     return fma(top, wy0b, (bot * wy1b).astype(np.float32))
+
+
+# --------------------------------------------------------------------------------------
+# preprocessing
+# --------------------------------------------------------------------------------------
+
+
+def fast_coco_transform(image_nhwc, size=None, mean=(0, 0, 0), std=(255, 255, 255)):
+    """FastCOCOTransform.__call__ with pipeline [Resize(size), Normalize(mean, std)]:
+    /root/reference/data/transform.py:455-461 (permute + contiguous), :470-473 (F.interpolate bilinear,
+    align_corners=False), :504-508 (sub_ mean, div_ std)."""
+    x = image_nhwc.detach().float().cpu().permute(0, 3, 1, 2).contiguous()
+    if size is not None:
+        x = F.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False)
+    m = torch.tensor(mean, dtype=torch.float32)
+    s = torch.tensor(std, dtype=torch.float32)
+    x.sub_(m[:, None, None]).div_(s[:, None, None])
+    return x
+
+
+def pad_to_divisor(image, size_divisor=32, pad_value=0):
+    """infer.pad, /root/reference/infer.py:21-32.  Returns (image, [left, right, top, down, H, W])."""
+    import math
+    height, width = image.shape[-2:]
+    new_height = int(math.ceil(height / size_divisor) * size_divisor)
+    new_width = int(math.ceil(width / size_divisor) * size_divisor)
+    left, top = (new_width - width) // 2, (new_height - height) // 2
+    right, down = new_width - width - left, new_height - height - top
+    return F.pad(image, [left, right, top, down], value=pad_value), [left, right, top, down, new_height, new_width]

@@ -59,6 +59,9 @@ SIGNATURES = {
                              ctypes.POINTER(ctypes.c_int)]),
     "om_conv2d": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "om_conv2d_stem": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "om_preprocess": (_i, [_vp, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                           _i, _i, _i, _i, _f, _vp, _vp]),
+    "om_pad_nchw": (_i, [_vp, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "om_postprocess_workspace_bytes": (_sz, [ctypes.POINTER(PostCfg), _i]),
     "om_postprocess": (_i, [ctypes.POINTER(PostCfg), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "om_nms_workspace_bytes": (_sz, [_i]),

@@ -77,6 +77,13 @@ def synth_image_batch(seed, batch, height=544, width=544):
     return torch.from_numpy(x)
 
 
+def synth_photo_batch(seed, batch, height, width):
+    """[n,h,w,3] float32 with integer values 0..255: what infer.py builds from cv2.imread + cvtColor
+    (/root/reference/infer.py:147-149) before FastCOCOTransform."""
+    rng = _rng(seed)
+    return torch.from_numpy(np.floor(rng.random((batch, height, width, 3)) * 256).astype(np.float32))
+
+
 def synth_heads(seed, batch, grid_sizes, num_anchors=3, num_classes=80, regime="mixed",
                 orien_scale=4):
     """Seeded head tensors in the model's output format, for postprocess-only tests.

@@ -1,0 +1,95 @@
+"""The reference's evaluation / inference loops on the HIP path.
+
+``Tester.test`` mirrors /root/reference/trainer/tester.py:26-62 (what is timed, under which names, and how
+fps is derived: 1000 * batch_size / mean batch ms); ``infer_loop`` mirrors the timed part of
+/root/reference/infer.py:124-188 (10 warm-up iterations, 'Load data' / 'Forward & Postprocess' timers).
+COCO metric computation (pycocotools) is outside the path; ``on_batch`` receives each batch's detections so
+a caller can plug it in.  Batches come from any iterable yielding ``(image[B,3,H,W], ..., batch_info)``
+tuples, e.g. ``SyntheticLoader``.
+"""
+import torch
+
+from . import timer as _timer
+from .dist import shard_range, world_info
+
+
+class SyntheticLoader:
+    """Deterministic stand-in for the COCO loader: n_images 544x544 images in batches (no dataset offline)."""
+
+    def __init__(self, n_images, batch_size, size=(544, 544), seed=0, device="cuda"):
+        from . import synth
+        self.batch_size = batch_size
+        rank, world = world_info()
+        start, stop = shard_range(n_images, rank, world)            # each rank evaluates its own slice
+        self._batches = []
+        for i, s in enumerate(range(start, stop, batch_size)):
+            n = min(batch_size, stop - s)
+            img = synth.synth_image_batch(seed + s, n, size[0], size[1])
+            info = [dict(id=s + k, height=size[0], width=size[1]) for k in range(n)]
+            self._batches.append((img, None, info))
+        self.device = device
+
+    def __len__(self):
+        return len(self._batches)
+
+    def __iter__(self):
+        return iter(self._batches)
+
+
+class Tester:
+    def __init__(self, model, postprocess, test_loader, device, on_batch=None):
+        self.model = model
+        self.postprocess = postprocess
+        self.test_loader = test_loader
+        self.device = device
+        self.on_batch = on_batch
+
+    def test(self, verbose=True):
+        _timer.reset()
+        _timer.cpu() if str(self.device) == "cpu" else _timer.cuda()
+        self.model.eval()
+        n_det = 0
+        with torch.no_grad():
+            for sample in self.test_loader:
+                image = sample[0].to(self.device)
+                batch_info = sample[2]
+                with _timer.timer("Network Forward"):
+                    predict = self.model(image)
+                with _timer.timer("Postprocess"):
+                    detections = self.postprocess(predict)
+                n_det += sum(int(d["bbox"].shape[0]) for d in detections)
+                if self.on_batch is not None:
+                    with _timer.timer("Convert Format"):
+                        self.on_batch(batch_info, detections)
+        log = _timer.get_all_elapsed_time()
+        bs = self.test_loader.batch_size
+        stats = {k: dict(ms_per_image=v / bs, fps=1000.0 * bs / v) for k, v in log.items()}
+        if verbose:
+            print("Speed Statistics (batch size = {})".format(bs))
+            for k, v in log.items():
+                print("%s: %.3fms (%.3ffps)" % (k, v / bs, 1000 * bs / v))
+        stats["detections"] = n_det
+        return stats
+
+
+def infer_loop(model, transform, postprocess, images, device, warmup=10, size_divisor=32):
+    """images: list of [h,w,3] float32 tensors (what cv2.imread + cvtColor give infer.py).
+    Returns (list of per-image detections, list of pad_info, timer log in ms)."""
+    _timer.reset()
+    _timer.cuda()
+    model.eval()
+    results, pads = [], []
+    with torch.no_grad():
+        if warmup and images:
+            x, _ = transform.padded(images[0].to(device).unsqueeze(0), size_divisor)
+            for _ in range(warmup):
+                postprocess(model(x))
+        with _timer.timer("Main Loop"):
+            for img in images:
+                with _timer.timer("Load data"):
+                    x, pad_info = transform.padded(img.to(device).unsqueeze(0), size_divisor)
+                with _timer.timer("Forward & Postprocess"):
+                    det = postprocess(model(x))
+                results.append(det[0])
+                pads.append(pad_info)
+    return results, pads, _timer.get_all_elapsed_time()

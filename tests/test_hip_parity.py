@@ -354,3 +354,77 @@ def test_nms_random_vs_oracle(dev):
         _, _, want = R.batched_nms(dt, ct, 0.45)
         _, _, got = batched_nms(dt.to(dev), ct.to(dev), threshold=0.45)
         assert got.cpu().tolist() == want.tolist(), n
+
+
+# ------------------------------------------------------------------------------------------------
+# preprocess
+# ------------------------------------------------------------------------------------------------
+def test_preprocess_matches_reference_golden(dev):
+    """om_preprocess (fused permute + bilinear resize + normalise + pad) vs the reference's own
+    FastCOCOTransform + infer.pad outputs: bit-exact (float ops in torch's order)."""
+    from orienmask_amd.transform import FastCOCOTransform, build_transform, pad
+    g = np.load(os.path.join(GOLDEN, "preprocess.npz"))
+    names = sorted(k[:-5] for k in g.files if k.endswith("_seed"))
+    for name in names:
+        n, h, w = (int(v) for v in g[name + "_shape"])
+        size = tuple(int(v) for v in g[name + "_size"])
+        img = synth.synth_photo_batch(int(g[name + "_seed"]), n, h, w).to(dev)
+        pipeline = [dict(type="Normalize", mean=(0, 0, 0), std=(255, 255, 255))]
+        if size != (h, w):
+            pipeline.insert(0, dict(type="Resize", size=size, interpolation="bilinear", align_corners=False))
+        tf = build_transform(dict(type="FastCOCOTransform", pipeline=pipeline, use_cuda=True))
+        assert isinstance(tf, FastCOCOTransform)
+        fused, info = tf.padded(img)                       # one kernel
+        two_step, info2 = pad(tf(img))                     # transform, then pad (the reference's call sequence)
+        assert info == info2 == g[name + "_pad"].tolist(), name
+        assert list(fused.shape) == g[name + "_outshape"].tolist(), name
+        assert torch.equal(fused, two_step), name
+        flat = fused.cpu().reshape(-1)
+        got = flat[torch.from_numpy(g[name + "_idx"])].numpy()
+        assert np.array_equal(got, g[name + "_samples"]), (name, np.abs(got - g[name + "_samples"]).max())
+        assert abs(flat.double().sum().item() - g[name + "_sum"][0]) <= 1e-9 * g[name + "_sum"][1]
+        if name + "_out" in g.files:
+            assert np.array_equal(fused.cpu().numpy(), g[name + "_out"]), name
+
+
+def test_preprocess_feeds_the_model(dev):
+    """infer.py's sequence on the HIP path: transform -> pad -> model -> postprocess, arbitrary image size."""
+    from orienmask_amd.transform import FastCOCOTransform
+    img = synth.synth_photo_batch(77, 1, 300, 420).to(dev)
+    tf = FastCOCOTransform([FastCOCOTransform.ShortEdgeResize(160, 256), FastCOCOTransform.Normalize((0, 0, 0), (255, 255, 255))])
+    x, info = tf.padded(img)
+    assert x.shape[2] % 32 == 0 and x.shape[3] % 32 == 0 and info[4:] == list(x.shape[2:])
+    want = R.pad_to_divisor(R.fast_coco_transform(img.cpu(), (160, 224)), 32, 0)[0]
+    assert torch.equal(x.cpu(), want)
+    sd = synth.synth_state_dict(5, obj_bias=-16.0, head_gain=4.0)
+    net = _hip_model(sd, dev)
+    with torch.no_grad():
+        out = net(x)
+    ref = R.forward(sd, want)
+    for (gb, go), (rb, ro) in zip(out, ref):
+        assert _rel_err(gb.cpu(), rb) < REL_TOL and _rel_err(go.cpu(), ro) < REL_TOL
+
+
+def test_tester_and_infer_loops(dev):
+    """The reference's two callers on the HIP path: Tester.test (tester.py:26-62) and the infer.py loop."""
+    from orienmask_amd.tester import SyntheticLoader, Tester, infer_loop
+    from orienmask_amd.transform import FastCOCOTransform
+    sd = synth.synth_state_dict(3, obj_bias=-16.0, head_gain=4.0)
+    net = _hip_model(sd, dev)
+    post = _hip_post((544, 544), dev)
+    seen = []
+    tester = Tester(net, post, SyntheticLoader(6, 4, seed=500), dev, on_batch=lambda info, dets: seen.append((info, dets)))
+    stats = tester.test(verbose=False)
+    assert set(stats) >= {"Network Forward", "Postprocess", "Convert Format", "detections"}
+    assert stats["Network Forward"]["fps"] > 0 and len(seen) == 2 and [len(s[1]) for s in seen] == [4, 2]
+    assert [i["id"] for s in seen for i in s[0]] == list(range(6))
+    tf = FastCOCOTransform([FastCOCOTransform.Resize((544, 544)), FastCOCOTransform.Normalize((0, 0, 0), (255, 255, 255))])
+    imgs = [synth.synth_photo_batch(900 + i, 1, 240 + 16 * i, 320)[0] for i in range(3)]
+    dets, pads, log = infer_loop(net, tf, post, imgs, dev, warmup=2)
+    assert len(dets) == 3 and all(p == [0, 0, 0, 0, 544, 544] for p in pads)
+    assert set(log) == {"Main Loop", "Load data", "Forward & Postprocess"}
+    # same image, same answer as the direct call sequence
+    x, _ = tf.padded(imgs[1].to(dev).unsqueeze(0))
+    with torch.no_grad():
+        again = post(net(x))[0]
+    assert torch.equal(again["bbox"], dets[1]["bbox"]) and torch.equal(again["mask"], dets[1]["mask"])

@@ -140,3 +140,35 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
                 assert "nms_ref" not in text and "libnms_ref" not in text, f
+
+
+def test_timer_api_mirrors_reference():
+    """utils/timer.py semantics: named timers, mean over uses, cpu()/cuda() switch, reset()."""
+    import time
+    from orienmask_amd import timer
+    timer.reset(); timer.cpu()
+    for _ in range(3):
+        with timer.timer("stage a"):
+            time.sleep(0.002)
+    with timer.timer("stage b"):
+        pass
+    log = timer.get_all_elapsed_time()
+    assert list(log) == ["stage a", "stage b"] and log["stage a"] >= 1.5 and log["stage b"] < 1.0
+    timer.reset()
+    assert timer.get_all_elapsed_time() == {}
+    timer.cuda()
+
+
+def test_transform_registry_and_pad_info(built):
+    from orienmask_amd import transform as T
+    cfg = dict(type="FastCOCOTransform", pipeline=[dict(type="Resize", size=(544, 544), interpolation="bilinear", align_corners=False),
+                                                   dict(type="Normalize", mean=(0, 0, 0), std=(255, 255, 255))])
+    keep = {k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()}
+    tf = T.build_transform(cfg)                       # /root/reference/config/base.py:158-164 goes in unchanged
+    assert cfg["pipeline"] == keep["pipeline"] and isinstance(tf._resize, T.FastCOCOTransform.Resize)
+    assert tf._resize.size == (544, 544) and tf._norm.std == [255.0] * 3
+    assert T.FastCOCOTransform.ShortEdgeResize(544, 800).target(480, 640) == (544, 725)
+    with pytest.raises(NotImplementedError):
+        T.FastCOCOTransform.Resize((544, 544), interpolation="nearest")
+    with pytest.raises(omlib.OrienMaskHipError):
+        tf(torch.zeros(1, 8, 8, 3))                   # CPU tensor: no fallback

@@ -102,3 +102,22 @@ def test_bilinear_restatement_matches_torch():
     if mism:
         import warnings
         warnings.warn("bilinear restatement differs from torch in %d of %d pixels (<= 4 ulp)" % (mism, want.size))
+
+
+def test_preprocess_matches_reference():
+    """FastCOCOTransform (Resize + Normalize) + infer.pad, generated from the reference's own code."""
+    g = np.load(os.path.join(GOLDEN, "preprocess.npz"))
+    names = sorted(k[:-5] for k in g.files if k.endswith("_seed"))
+    assert len(names) == 5
+    for name in names:
+        n, h, w = (int(v) for v in g[name + "_shape"])
+        size = tuple(int(v) for v in g[name + "_size"])
+        img = synth.synth_photo_batch(int(g[name + "_seed"]), n, h, w)
+        x = R.fast_coco_transform(img, size if size != (h, w) else None)
+        x, info = R.pad_to_divisor(x, 32, 0)
+        assert info == g[name + "_pad"].tolist(), name
+        assert list(x.shape) == g[name + "_outshape"].tolist(), name
+        flat = x.reshape(-1)
+        assert np.array_equal(flat[torch.from_numpy(g[name + "_idx"])].numpy(), g[name + "_samples"]), name
+        if name + "_out" in g.files:
+            assert np.array_equal(x.numpy(), g[name + "_out"]), name

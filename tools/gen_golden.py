@@ -180,5 +180,58 @@ def main():
               "%.0f KB" % (os.path.getsize(os.path.join(OUT, "fwd_%s.npz" % name)) / 1024))
 
 
+def preprocess_golden():
+    """G6: FastCOCOTransform (Resize + Normalize) and infer.pad run from the reference's own code.
+    data/transform.py needs cv2 / torchvision at import time only (module-level tables and the CPU
+    transforms), so they are stubbed; infer.py imports the whole application, so its `pad` function
+    is compiled from the file's AST and executed here (nothing of it is stored)."""
+    import ast
+    import math
+    cv2 = types.ModuleType("cv2")
+    for i, n in enumerate(("INTER_NEAREST", "INTER_LINEAR", "INTER_AREA", "INTER_CUBIC", "INTER_LANCZOS4")):
+        setattr(cv2, n, i)
+    sys.modules["cv2"] = cv2
+    for name in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional",
+                 "torchvision.transforms.transforms"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision.transforms.transforms"].Lambda = object
+    sys.modules["torchvision.transforms.transforms"].Compose = object
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_transform", "/root/reference/data/transform.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    T = mod.FastCOCOTransform
+    tree = ast.parse(open("/root/reference/infer.py").read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "pad"][0]
+    ns = {"math": math, "F": torch.nn.functional}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "infer.py:pad", "exec"), ns)
+    ref_pad = ns["pad"]
+    rec = {}
+    cases = [("vga", 2, 480, 640, (544, 544)), ("coco", 1, 427, 640, (544, 544)), ("small", 3, 97, 131, (96, 160)),
+             ("same", 1, 64, 96, None), ("odd", 1, 333, 500, (300, 451))]
+    for k, (name, n, h, w, size) in enumerate(cases):
+        img = synth.synth_photo_batch(31 + k, n, h, w)
+        x = img.permute(0, 3, 1, 2).contiguous()                      # FastCOCOTransform.__call__, transform.py:459
+        if size is not None:
+            x = T.Resize(size=size, interpolation="bilinear", align_corners=False)(x)
+        x = T.Normalize(mean=(0, 0, 0), std=(255, 255, 255))(x)
+        padded, info = ref_pad(x)
+        rec[name + "_seed"] = np.int64(31 + k); rec[name + "_shape"] = np.array([n, h, w])
+        rec[name + "_size"] = np.array(size if size is not None else (h, w))
+        rec[name + "_pad"] = np.array(info); rec[name + "_outshape"] = np.array(padded.shape)
+        flat = padded.reshape(-1)
+        idx = torch.linspace(0, flat.numel() - 1, 4096).long()
+        rec[name + "_idx"] = idx.numpy(); rec[name + "_samples"] = flat[idx].numpy()
+        rec[name + "_sum"] = np.array([flat.double().sum().item(), flat.double().abs().sum().item()])
+        if padded.numel() <= 200000:
+            rec[name + "_out"] = padded.numpy()
+    np.savez_compressed(os.path.join(OUT, "preprocess.npz"), **rec)
+    print("preprocess: %d cases, %.0f KB" % (len(cases), os.path.getsize(os.path.join(OUT, "preprocess.npz")) / 1024))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "preprocess":
+        preprocess_golden()
+    else:
+        main()
+        preprocess_golden()
