@@ -79,7 +79,10 @@ int om_version(void);
 const char* om_last_error(void);
 
 /* ---- model ------------------------------------------------------------------------------- */
-int om_model_create(om_model** out, int num_anchors, int num_classes);
+int om_model_create(om_model** out, int num_anchors, int num_classes);    /* OrienMaskYOLOFPNPlus */
+/* variant 0: OrienMaskYOLOFPNPlus (model/orienmask_yolo_fpnplus.py:9-90);
+ * variant 1: OrienMaskYOLO (model/orienmask_yolo.py:8-86: one route8 into a 192-channel neck4, no skips). */
+int om_model_create_variant(om_model** out, int variant, int num_anchors, int num_classes);
 void om_model_destroy(om_model* m);
 int om_model_num_layers(const om_model* m);
 int om_model_layer_info(const om_model* m, int index, om_layer_info* info);

@@ -104,6 +104,24 @@ def forward(sd, x, num_anchors=3, return_features=False):
     return out
 
 
+def forward_yolo(sd, x, num_anchors=3):
+    """OrienMaskYOLO.forward (the non-Plus model), /root/reference/model/orienmask_yolo.py:71-86:
+    oriens = orien_head(neck4(cat[route8(neck8), x4]))."""
+    with torch.no_grad():
+        x32, x16, x8, x4 = backbone(sd, x)
+        n32 = _seq(sd, "neck32", x32, 5)
+        n16 = _seq(sd, "neck16", torch.cat([_up(_cbl(sd, "route32.0", n32), 2), x16], 1), 5)
+        n8 = _seq(sd, "neck8", torch.cat([_up(_cbl(sd, "route16.0", n16), 2), x8], 1), 5)
+        b32 = _plain(sd, "bbox_head32.1", _cbl(sd, "bbox_head32.0", n32))
+        b16 = _plain(sd, "bbox_head16.1", _cbl(sd, "bbox_head16.0", n16))
+        b8 = _plain(sd, "bbox_head8.1", _cbl(sd, "bbox_head8.0", n8))
+        cat4 = torch.cat([_up(_cbl(sd, "route8.0", n8), 2), x4], 1)
+        o = _seq(sd, "orien_head", _seq(sd, "neck4", cat4, 5), 5)
+        o = _plain(sd, "orien_head.5", o)
+        o32, o16, o8 = torch.split(o, num_anchors * 2, dim=1)
+    return (b32, o32), (b16, o16), (b8, o8)
+
+
 # --------------------------------------------------------------------------------------
 # NMS
 # --------------------------------------------------------------------------------------

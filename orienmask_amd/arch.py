@@ -29,6 +29,18 @@ def _neck(prefix, cin, cout):
 
 def fpnplus_convs(num_anchors=3, num_classes=80):
     """Ordered list of the 90 convolutions of the FPNPlus model."""
+    return model_convs("OrienMaskYOLOFPNPlus", num_anchors, num_classes)
+
+
+def yolo_convs(num_anchors=3, num_classes=80):
+    """The 87 convolutions of the non-Plus OrienMaskYOLO (/root/reference/model/orienmask_yolo.py:8-86)."""
+    return model_convs("OrienMaskYOLO", num_anchors, num_classes)
+
+
+def model_convs(model, num_anchors=3, num_classes=80):
+    plus = model == "OrienMaskYOLOFPNPlus"
+    if not plus and model != "OrienMaskYOLO":
+        raise ValueError(model)
     convs = [ConvSpec("backbone.conv1", 3, 32, 3, 1, True)]
     for idx, ch, nblocks in DARKNET_STAGES:
         stage = "backbone.conv%d" % idx
@@ -39,17 +51,20 @@ def fpnplus_convs(num_anchors=3, num_classes=80):
     convs += _neck("neck32", 1024, 512)
     convs += _neck("neck16", 768, 256)
     convs += _neck("neck8", 384, 128)
-    convs += _neck("neck4", 256, 128)
+    convs += _neck("neck4", 256 if plus else 192, 128)
     convs.append(ConvSpec("route32.0", 512, 256, 1, 1, True))
     convs.append(ConvSpec("route16.0", 256, 128, 1, 1, True))
+    if not plus:
+        convs.append(ConvSpec("route8.0", 128, 64, 1, 1, True))
     bbox_dim = num_anchors * (5 + num_classes)
     for s, c in ((8, 128), (16, 256), (32, 512)):
         convs.append(ConvSpec("bbox_head%d.0" % s, c, c * 2, 3, 1, True))
         convs.append(ConvSpec("bbox_head%d.1" % s, c * 2, bbox_dim, 1, 1, False))
-    convs.append(ConvSpec("skip32.0", 512, 64, 1, 1, True))
-    convs.append(ConvSpec("skip16.0", 256, 64, 1, 1, True))
-    convs.append(ConvSpec("skip8.0", 128, 64, 1, 1, True))
-    convs.append(ConvSpec("skip4", 128, 64, 1, 1, True))
+    if plus:
+        convs.append(ConvSpec("skip32.0", 512, 64, 1, 1, True))
+        convs.append(ConvSpec("skip16.0", 256, 64, 1, 1, True))
+        convs.append(ConvSpec("skip8.0", 128, 64, 1, 1, True))
+        convs.append(ConvSpec("skip4", 128, 64, 1, 1, True))
     for i, (a, b, k) in enumerate([(128, 256, 3), (256, 128, 1), (128, 256, 3),
                                    (256, 128, 1), (128, 256, 3)]):
         convs.append(ConvSpec("orien_head.%d" % i, a, b, k, 1, True))
@@ -89,6 +104,8 @@ def layer_div(spec):
         return 2 ** (int(n[len("backbone.conv")]) - 1)
     if n.startswith("skip4") or n.startswith("neck4") or n.startswith("orien_head"):
         return 4
+    if n.startswith("route8"):
+        return 8
     for s in (32, 16, 8):
         if n.split(".")[0].endswith(str(s)):
             return s

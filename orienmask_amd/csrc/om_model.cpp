@@ -57,6 +57,7 @@ struct LayerDef {
 
 struct om_model {
     int num_anchors = 0, num_classes = 0;
+    int variant = 0;     // 0: OrienMaskYOLOFPNPlus, 1: OrienMaskYOLO (single route8 into a 192-channel neck4)
     std::vector<om::BufDef> bufs;
     std::vector<om::LayerDef> layers;
     size_t weight_floats = 0;
@@ -116,9 +117,10 @@ struct om_model {
         using om::View;
         const int A = num_anchors;
         // concat buffers: [route | backbone feature], [skip32 | skip16 | skip8 | skip4]
+        const bool plus = variant == 0;
         const int cat16 = new_buf(16, 256 + 512);
         const int cat8 = new_buf(8, 128 + 256);
-        const int cat4 = new_buf(4, 4 * 64);
+        const int cat4 = new_buf(4, plus ? 4 * 64 : 64 + 128);
 
         // ---- DarkNet-53
         View cur{new_buf(1, 32), 0};
@@ -137,7 +139,8 @@ struct om_model {
                 View mid = cbl(blk + "0", cur, ch * 2, ch, 1, div);
                 View dst{};
                 const bool last = j == nblocks[idx];
-                if (last && idx == 4) dst = View{cat8, 128};
+                if (last && idx == 3 && !plus) dst = View{cat4, 64};     // OrienMaskYOLO: x4 sits behind route8
+                else if (last && idx == 4) dst = View{cat8, 128};
                 else if (last && idx == 5) dst = View{cat16, 256};
                 else dst = View{new_buf(div, ch * 2), 0};
                 add(blk + "1", ch, ch * 2, 3, 1, true, mid, div, dst, &cur);
@@ -169,12 +172,16 @@ struct om_model {
             add(std::string(h.name) + ".1", h.c * 2, bbox_dim, 1, 1, false, t, h.div, View{h.out, 0});
         }
 
-        // ---- orientation branch (fpnplus.py:85-88)
-        add("skip32.0", 512, 64, 1, 1, true, n32, 32, View{cat4, 0}, nullptr, 1, 8);
-        add("skip16.0", 256, 64, 1, 1, true, n16, 16, View{cat4, 64}, nullptr, 1, 4);
-        add("skip8.0", 128, 64, 1, 1, true, n8, 8, View{cat4, 128}, nullptr, 1, 2);
-        add("skip4", 128, 64, 1, 1, true, x4, 4, View{cat4, 192});
-        View o = neck("neck4", View{cat4, 0}, 256, 128, 4);
+        // ---- orientation branch (fpnplus.py:85-88; orienmask_yolo.py:82-83 for the non-Plus model)
+        if (plus) {
+            add("skip32.0", 512, 64, 1, 1, true, n32, 32, View{cat4, 0}, nullptr, 1, 8);
+            add("skip16.0", 256, 64, 1, 1, true, n16, 16, View{cat4, 64}, nullptr, 1, 4);
+            add("skip8.0", 128, 64, 1, 1, true, n8, 8, View{cat4, 128}, nullptr, 1, 2);
+            add("skip4", 128, 64, 1, 1, true, x4, 4, View{cat4, 192});
+        } else {
+            add("route8.0", 128, 64, 1, 1, true, n8, 8, View{cat4, 0}, nullptr, 1, 2);
+        }
+        View o = neck("neck4", View{cat4, 0}, plus ? 256 : 192, 128, 4);
         o = cbl("orien_head.0", o, 128, 256, 3, 4);
         o = cbl("orien_head.1", o, 256, 128, 1, 4);
         o = cbl("orien_head.2", o, 128, 256, 3, 4);
@@ -205,13 +212,19 @@ int om_version(void) { return OM_VERSION; }
 const char* om_last_error(void) { return om::g_err; }
 
 int om_model_create(om_model** out, int num_anchors, int num_classes) {
+    return om_model_create_variant(out, 0, num_anchors, num_classes);
+}
+
+int om_model_create_variant(om_model** out, int variant, int num_anchors, int num_classes) {
     OM_REQUIRE(out, OM_EINVAL, "om_model_create: out is null");
+    OM_REQUIRE(variant == 0 || variant == 1, OM_EINVAL, "om_model_create_variant: variant %d (0 = FPNPlus, 1 = OrienMaskYOLO)", variant);
     OM_REQUIRE(num_anchors >= 1 && num_anchors <= 3 && num_classes >= 1 &&
                    num_anchors * (5 + num_classes) <= om::HEAD_PIX_STRIDE,
                OM_EINVAL, "om_model_create: unsupported head (anchors=%d classes=%d)", num_anchors, num_classes);
     om_model* m = new om_model();
     m->num_anchors = num_anchors;
     m->num_classes = num_classes;
+    m->variant = variant;
     m->build();
     *out = m;
     return OM_OK;

@@ -43,6 +43,7 @@ SIGNATURES = {
     "om_version": (_i, []),
     "om_last_error": (ctypes.c_char_p, []),
     "om_model_create": (_i, [ctypes.POINTER(_vp), _i, _i]),
+    "om_model_create_variant": (_i, [ctypes.POINTER(_vp), _i, _i, _i]),
     "om_model_destroy": (None, [_vp]),
     "om_model_num_layers": (_i, [_vp]),
     "om_model_layer_info": (_i, [_vp, _i, ctypes.POINTER(LayerInfo)]),

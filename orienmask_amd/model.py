@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import lib as _lib
 from . import pack as _pack
-from .arch import fpnplus_convs, state_dict_entries
+from .arch import model_convs, state_dict_entries
 
 HEAD_PIX_STRIDE = 256
 
@@ -43,6 +43,8 @@ def _descend(root, parts):
 
 
 class OrienMaskYOLOFPNPlus(nn.Module):
+    VARIANT = 0          # om_model_create_variant id
+
     def __init__(self, num_anchors, num_classes, pretrained=None, freeze_backbone=False,
                  backbone_batchnorm_eval=False):
         super().__init__()
@@ -51,7 +53,7 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         self.pretrained = pretrained
         self.freeze_backbone = freeze_backbone
         self.backbone_batchnorm_eval = backbone_batchnorm_eval
-        for spec in fpnplus_convs(num_anchors, num_classes):
+        for spec in model_convs(type(self).__name__, num_anchors, num_classes):
             for key, shape, role in state_dict_entries(spec):
                 *path, leaf = key.split(".")
                 node = _descend(self, path)
@@ -90,10 +92,11 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         if self._handle is None:
             L = _lib.load()
             h = ctypes.c_void_p()
-            _lib.check(L.om_model_create(ctypes.byref(h), self.num_anchors, self.num_classes), "om_model_create")
+            _lib.check(L.om_model_create_variant(ctypes.byref(h), self.VARIANT, self.num_anchors, self.num_classes),
+                       "om_model_create_variant")
             self._handle = h
             self._layers = _pack.graph_layers(h)
-            _pack.check_graph_matches_arch(self._layers, self.num_anchors, self.num_classes)
+            _pack.check_graph_matches_arch(self._layers, self.num_anchors, self.num_classes, type(self).__name__)
         return self._handle
 
     def invalidate_packed(self):
@@ -201,3 +204,10 @@ class OrienMaskYOLOFPNPlus(nn.Module):
                 self._handle = None
         except Exception:
             pass
+
+
+class OrienMaskYOLO(OrienMaskYOLOFPNPlus):
+    """The non-Plus model of the reference (/root/reference/model/orienmask_yolo.py:8-86):
+    one up-sampling route8 concatenated with x4 into a 192-channel neck4 instead of the four skips.
+    Same constructor, state_dict naming (506 keys), forward() contract and kernels; only the graph differs."""
+    VARIANT = 1

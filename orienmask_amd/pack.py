@@ -16,7 +16,7 @@ import ctypes
 import torch
 
 from . import lib as _lib
-from .arch import BN_EPS, fpnplus_convs
+from .arch import BN_EPS, model_convs
 
 
 def graph_layers(handle):
@@ -33,9 +33,9 @@ def graph_layers(handle):
     return out
 
 
-def check_graph_matches_arch(layers, num_anchors, num_classes):
+def check_graph_matches_arch(layers, num_anchors, num_classes, model="OrienMaskYOLOFPNPlus"):
     """The C++ graph and the Python layer table are written independently; they must agree."""
-    want = {s.name: s for s in fpnplus_convs(num_anchors, num_classes)}
+    want = {s.name: s for s in model_convs(model, num_anchors, num_classes)}
     got = {l["name"]: l for l in layers}
     if set(want) != set(got):
         raise _lib.OrienMaskHipError("graph/arch layer names differ: %s" % sorted(set(want) ^ set(got)))

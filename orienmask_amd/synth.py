@@ -13,7 +13,7 @@ is far from identity (a folded-BN bug cannot hide).
 import numpy as np
 import torch
 
-from .arch import fpnplus_convs, state_dict_entries, is_residual_tail
+from .arch import model_convs, state_dict_entries, is_residual_tail
 
 
 def _rng(seed):
@@ -21,7 +21,7 @@ def _rng(seed):
 
 
 def synth_state_dict(seed=0, num_anchors=3, num_classes=80, obj_bias=0.0, head_gain=1.0,
-                     coord_gain=0.3, orien_gain=0.2):
+                     coord_gain=0.3, orien_gain=0.2, model="OrienMaskYOLOFPNPlus"):
     """Seeded reference-format state_dict (CPU float32 tensors, 524 keys).
 
     A random-weight network's head outputs vary far more across channels than across
@@ -33,7 +33,7 @@ def synth_state_dict(seed=0, num_anchors=3, num_classes=80, obj_bias=0.0, head_g
     """
     rng = _rng(seed)
     sd = {}
-    for spec in fpnplus_convs(num_anchors, num_classes):
+    for spec in model_convs(model, num_anchors, num_classes):
         fan_in = spec.cin * spec.ksize * spec.ksize
         for key, shape, role in state_dict_entries(spec):
             if role == "conv_w":

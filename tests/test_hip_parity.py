@@ -205,6 +205,26 @@ def test_forward_matches_oracle_and_layouts(dev):
         assert _rel_err(go.cpu(), ro) < REL_TOL
 
 
+def test_yolo_variant_matches_reference_golden(dev):
+    """The non-Plus OrienMaskYOLO graph vs tensors the reference's own model produced."""
+    from orienmask_amd.model import OrienMaskYOLO
+    g = np.load(os.path.join(GOLDEN, "yolo_fwd.npz"))
+    for name in ("y96_b2", "y128x160_b1"):
+        wseed, xseed, batch, h, w = (int(v) for v in g[name + "_meta"])
+        sd = synth.synth_state_dict(wseed, obj_bias=-16.0, head_gain=4.0, model="OrienMaskYOLO")
+        net = OrienMaskYOLO(3, 80).eval()
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev)
+        with torch.no_grad():
+            out = net(synth.synth_image_batch(xseed, batch, h, w).to(dev))
+        got = dict(bbox32=out[0][0], bbox16=out[1][0], bbox8=out[2][0],
+                   oriens=torch.cat([out[0][1], out[1][1], out[2][1]], 1))
+        for k, t in got.items():
+            want = torch.from_numpy(g["%s_%s" % (name, k)])
+            assert t.shape == want.shape
+            assert _rel_err(t.cpu(), want) < REL_TOL, (name, k)
+
+
 def test_forward_is_batch_invariant(dev):
     """Size-independent property at the full 544x544 size: an image's outputs do not depend on what
     else is in the batch (bit-exact), and repeated runs are bit-identical."""

@@ -104,6 +104,20 @@ def test_bilinear_restatement_matches_torch():
         warnings.warn("bilinear restatement differs from torch in %d of %d pixels (<= 4 ulp)" % (mism, want.size))
 
 
+def test_yolo_forward_matches_reference():
+    """The non-Plus OrienMaskYOLO restatement vs the reference's own model."""
+    g = np.load(os.path.join(GOLDEN, "yolo_fwd.npz"))
+    for name in ("y96_b2", "y128x160_b1"):
+        wseed, xseed, batch, h, w = (int(v) for v in g[name + "_meta"])
+        sd = synth.synth_state_dict(wseed, obj_bias=-16.0, head_gain=4.0, model="OrienMaskYOLO")
+        assert len(sd) == 506
+        out = R.forward_yolo(sd, synth.synth_image_batch(xseed, batch, h, w))
+        got = dict(bbox32=out[0][0], bbox16=out[1][0], bbox8=out[2][0],
+                   oriens=torch.cat([out[0][1], out[1][1], out[2][1]], 1))
+        for k, t in got.items():
+            assert np.array_equal(t.numpy(), g["%s_%s" % (name, k)]), (name, k)
+
+
 def test_preprocess_matches_reference():
     """FastCOCOTransform (Resize + Normalize) + infer.pad, generated from the reference's own code."""
     g = np.load(os.path.join(GOLDEN, "preprocess.npz"))

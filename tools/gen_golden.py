@@ -180,6 +180,25 @@ def main():
               "%.0f KB" % (os.path.getsize(os.path.join(OUT, "fwd_%s.npz" % name)) / 1024))
 
 
+def yolo_golden():
+    """G7: the non-Plus OrienMaskYOLO (model/orienmask_yolo.py) forward on synthetic weights."""
+    cfg, rmodel, reval, rfunc = import_reference()
+    net = rmodel.OrienMaskYOLO(num_anchors=3, num_classes=80, pretrained=None).eval()
+    rec = {}
+    for name, wseed, size, batch, xseed in (("y96_b2", 41, (96, 96), 2, 42), ("y128x160_b1", 43, (128, 160), 1, 44)):
+        sd = synth.synth_state_dict(wseed, obj_bias=-16.0, head_gain=4.0, model="OrienMaskYOLO")
+        net.load_state_dict(sd, strict=True)                       # proves the 506 keys line up
+        x = synth.synth_image_batch(xseed, batch, size[0], size[1])
+        with torch.no_grad():
+            out = net(x)
+        rec[name + "_meta"] = np.array([wseed, xseed, batch, size[0], size[1]])
+        for k, t in (("bbox32", out[0][0]), ("bbox16", out[1][0]), ("bbox8", out[2][0]),
+                     ("oriens", torch.cat([out[0][1], out[1][1], out[2][1]], 1))):
+            rec["%s_%s" % (name, k)] = t.numpy()
+    np.savez_compressed(os.path.join(OUT, "yolo_fwd.npz"), **rec)
+    print("yolo_fwd: %.0f KB" % (os.path.getsize(os.path.join(OUT, "yolo_fwd.npz")) / 1024))
+
+
 def preprocess_golden():
     """G6: FastCOCOTransform (Resize + Normalize) and infer.pad run from the reference's own code.
     data/transform.py needs cv2 / torchvision at import time only (module-level tables and the CPU
@@ -232,6 +251,9 @@ def preprocess_golden():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "preprocess":
         preprocess_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "yolo":
+        yolo_golden()
     else:
         main()
+        yolo_golden()
         preprocess_golden()
