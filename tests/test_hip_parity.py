@@ -448,3 +448,24 @@ def test_tester_and_infer_loops(dev):
     with torch.no_grad():
         again = post(net(x))[0]
     assert torch.equal(again["bbox"], dets[1]["bbox"]) and torch.equal(again["mask"], dets[1]["mask"])
+
+
+def test_build_tester_from_checkpoint_file(dev, tmp_path):
+    """test.py's build_tester(config, checkpoint) on a reference-format .pth file."""
+    from orienmask_amd import builder
+    from orienmask_amd.tester import SyntheticLoader
+    sd = synth.synth_state_dict(3, obj_bias=-16.0, head_gain=4.0)
+    cfg = dict(model=dict(type="OrienMaskYOLOFPNPlus", num_anchors=3, num_classes=80, pretrained="checkpoints/pretrained.pth",
+                          freeze_backbone=False, backbone_batchnorm_eval=False))
+    path = str(tmp_path / "epoch100.pth")
+    torch.save(dict(epoch=100, state_dict=sd, optimizer={}, lr_scheduler={}, monitor_best=0.3, config=cfg), path)
+    test_cfg = dict(postprocess=dict(type="OrienMaskYOLOPostProcess", nms=dict(type="batched_nms", threshold=0.5),
+                                     **post_cfg((544, 544))))
+    tester = builder.build_tester(test_cfg, path, SyntheticLoader(2, 2, seed=700), device=dev)
+    stats = tester.test(verbose=False)
+    assert stats["detections"] > 0
+    x = synth.synth_image_batch(700, 2, 544, 544).to(dev)
+    with torch.no_grad():
+        direct = _hip_model(sd, dev)(x)
+        via_ckpt = tester.model(x)
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(direct, via_ckpt))

@@ -172,3 +172,29 @@ def test_transform_registry_and_pad_info(built):
         T.FastCOCOTransform.Resize((544, 544), interpolation="nearest")
     with pytest.raises(omlib.OrienMaskHipError):
         tf(torch.zeros(1, 8, 8, 3))                   # CPU tensor: no fallback
+
+
+def test_checkpoint_ingest_reference_format(tmp_path, built):
+    """a .pth as the reference's trainer writes it (trainer/base.py:143-152) -> packed blob."""
+    from orienmask_amd import builder, model as om_model
+    sd = synth.synth_state_dict(12)
+    cfg = dict(model=dict(type="OrienMaskYOLOFPNPlus", num_anchors=3, num_classes=80, pretrained="checkpoints/x.pth",
+                          freeze_backbone=False, backbone_batchnorm_eval=False))
+    ckpt = dict(epoch=100, state_dict=sd, optimizer={}, lr_scheduler={}, monitor_best=0.345, config=cfg)
+    path = str(tmp_path / "best_model.pth")
+    torch.save(ckpt, path)
+    got_sd, got_cfg = builder.load_checkpoint(path)
+    assert got_cfg == cfg and set(got_sd) == set(sd)
+    raw = str(tmp_path / "weights_only.pth")
+    torch.save(sd, raw)                                     # infer.py also accepts a bare state_dict
+    got_sd2, none_cfg = builder.load_checkpoint(raw)
+    assert none_cfg is None and all(torch.equal(got_sd2[k], sd[k]) for k in sd)
+    net = om_model.OrienMaskYOLOFPNPlus(3, 80)
+    net.load_state_dict(got_sd, strict=True)
+    h = net._ensure_handle()
+    total = omlib.load().om_model_weight_floats(h)
+    a = pack.pack_state_dict(net.state_dict(), net._layers, total)
+    b = pack.pack_state_dict({"state_dict": sd}, net._layers, total)
+    assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        builder.build_tester(dict(postprocess={}), raw, [], device=torch.device("cpu"))
