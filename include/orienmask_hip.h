@@ -151,6 +151,21 @@ int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbo
                    const float* oriens, int B, float* out_bbox, int64_t* out_cls, uint8_t* out_mask,
                    int32_t* out_count, int32_t* out_keep, void* workspace, size_t ws_bytes, om_stream stream);
 
+/* ---- COCO-format conversion ------------------------------------------------------------
+ * om_recover_bbox: COCOMetrics._recover_shape_bbox, /root/reference/eval/coco_eval.py:146-189.
+ *   bbox [K,stride] normalised (cx,cy,w,h,..) -> out_xywh [K,4] top-left x, y, w, h in original-image pixels.
+ *   collate_pad6 = (left,right,top,down,h,w) and pad6 = (top,down,left,right,h,w) are HOST arrays or NULL.
+ * om_recover_masks_rle: COCOMetrics._recover_shape_segm (:191-205: crop the paddings, flips, bilinear resize
+ *   to the original size, round) + the column-major run lengths of pycocotools' rleEncode (:120-122).
+ *   mask [K,H,W] u8 0/1; crop_* = total padding to strip on each side; counts [K][max_runs] u32 receives the
+ *   run lengths (first run counts zeros); n_runs [K] their number (> max_runs: buffer too small, counts of
+ *   that mask are undefined); resized_or_null: optional [K,orig_h,orig_w] u8 copy of the resized masks. */
+int om_recover_bbox(const float* bbox, int K, int stride, const int32_t* collate_pad6, const int32_t* pad6, int hflip,
+                    int vflip, int orig_h, int orig_w, float* out_xywh, om_stream stream);
+int om_recover_masks_rle(const uint8_t* mask, int K, int H, int W, int crop_top, int crop_down, int crop_left,
+                         int crop_right, int hflip, int vflip, int orig_h, int orig_w, uint32_t* counts, int max_runs,
+                         int32_t* n_runs, uint8_t* resized_or_null, om_stream stream);
+
 /* ---- NMS (CPU-backend semantics of the reference: IoU >= thresh suppresses, corners from
  *      cx +- w/2, keep returned in ascending input order; n <= 1024) ------------------------ */
 size_t om_nms_workspace_bytes(int n);

@@ -386,3 +386,99 @@ def pad_to_divisor(image, size_divisor=32, pad_value=0):
     left, top = (new_width - width) // 2, (new_height - height) // 2
     right, down = new_width - width - left, new_height - height - top
     return F.pad(image, [left, right, top, down], value=pad_value), [left, right, top, down, new_height, new_width]
+
+
+# --------------------------------------------------------------------------------------
+# COCO-format conversion
+# --------------------------------------------------------------------------------------
+
+
+def recover_shape_bbox(bbox, sample_info):
+    """COCOMetrics._recover_shape_bbox, /root/reference/eval/coco_eval.py:146-189."""
+    bx, by, bw, bh = bbox[:, :4].split(1, dim=-1)
+    if sample_info.get("collate_pad") is not None:
+        left, right, top, down, h, w = sample_info["collate_pad"]
+        nh = h - top - down
+        nw = w - left - right
+        bx = (bx * w - left) / nw
+        by = (by * h - top) / nh
+        bw = bw * w / nw
+        bh = bh * h / nh
+    if sample_info.get("pad") is not None:
+        top, down, left, right, h, w = sample_info["pad"]
+        nh = h - top - down
+        nw = w - left - right
+        bx = (bx * w - left) / nw
+        by = (by * h - top) / nh
+        bw = bw * w / nw
+        bh = bh * h / nh
+    if sample_info.get("hflip", False):
+        bx = 1 - bx
+    if sample_info.get("vflip", False):
+        by = 1 - by
+    oh, ow = sample_info["height"], sample_info["width"]
+    return torch.cat([(bx - bw / 2) * ow, (by - bh / 2) * oh, bw * ow, bh * oh], dim=-1)
+
+
+def recover_shape_segm(mask, sample_info):
+    """COCOMetrics._recover_shape_segm, /root/reference/eval/coco_eval.py:191-205."""
+    if sample_info.get("collate_pad") is not None:
+        left, right, top, down = sample_info["collate_pad"][:4]
+        mask = mask[:, top:-down if down else None, left:-right if right else None]
+    if sample_info.get("pad") is not None:
+        top, down, left, right = sample_info["pad"][:4]
+        mask = mask[:, top:-down if down else None, left:-right if right else None]
+    if sample_info.get("hflip", False):
+        mask = torch.flip(mask, dims=(2,))
+    if sample_info.get("vflip", False):
+        mask = torch.flip(mask, dims=(1,))
+    oh, ow = sample_info["height"], sample_info["width"]
+    mask = F.interpolate(mask.unsqueeze(0).float(), size=(oh, ow), mode="bilinear", align_corners=False)
+    return mask.squeeze(0).round().to(torch.uint8)
+
+
+def rle_counts(mask2d):
+    """Run lengths of pycocotools' rleEncode on a Fortran-ordered mask (call site coco_eval.py:120-122):
+    column-major scan, alternating runs starting with zeros.  pycocotools 2.x (unpinned in
+    /root/reference/requirements.txt:5) is not installed offline: this restates its published algorithm."""
+    flat = np.asarray(mask2d, dtype=np.uint8).T.reshape(-1)          # column-major
+    change = np.flatnonzero(np.diff(np.concatenate([[0], flat])))     # positions where the value flips (value before 0 is 0)
+    edges = np.concatenate([[0], change, [flat.size]])
+    return np.diff(edges).astype(np.int64).tolist()
+
+
+def rle_to_string(counts):
+    """pycocotools rleToString (maskApi.c): delta against the run two back, 5 bits per char. Parity unpinned."""
+    s = []
+    for i, c in enumerate(counts):
+        x = int(c)
+        if i > 2:
+            x -= int(counts[i - 2])
+        more = True
+        while more:
+            ch = x & 0x1F
+            x >>= 5
+            more = (x != -1) if (ch & 0x10) else (x != 0)
+            if more:
+                ch |= 0x20
+            s.append(chr(ch + 48))
+    return "".join(s)
+
+
+def rle_string_decode(s, n_pixels):
+    """Inverse of rle_to_string (pycocotools rleFrString), used for a round-trip property test."""
+    counts, p, i = [], 0, 0
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            c = ord(s[p]) - 48
+            x |= (c & 0x1F) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1; k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if i > 2:
+            x += counts[i - 2]
+        counts.append(x); i += 1
+    assert sum(counts) == n_pixels
+    return counts

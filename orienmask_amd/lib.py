@@ -65,6 +65,9 @@ SIGNATURES = {
     "om_pad_nchw": (_i, [_vp, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "om_postprocess_workspace_bytes": (_sz, [ctypes.POINTER(PostCfg), _i]),
     "om_postprocess": (_i, [ctypes.POINTER(PostCfg), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "om_recover_bbox": (_i, [_vp, _i, _i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _i, _i, _i, _i,
+                             _vp, _vp]),
+    "om_recover_masks_rle": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "om_nms_workspace_bytes": (_sz, [_i]),
     "om_nms": (_i, [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
 }

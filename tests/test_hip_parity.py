@@ -469,3 +469,53 @@ def test_build_tester_from_checkpoint_file(dev, tmp_path):
         direct = _hip_model(sd, dev)(x)
         via_ckpt = tester.model(x)
     assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(direct, via_ckpt))
+
+
+# ------------------------------------------------------------------------------------------------
+# COCO-format conversion
+# ------------------------------------------------------------------------------------------------
+def test_coco_format_matches_reference_golden(dev):
+    """om_recover_bbox / om_recover_masks_rle vs the reference's _recover_shape_bbox / _recover_shape_segm
+    outputs (bit-exact boxes and resized masks) and the oracle's run lengths / RLE strings."""
+    from orienmask_amd import coco_format as CF
+    from test_oracle_golden import _coco_cases
+    for name, info, masks, bbox, xywh, seg in _coco_cases():
+        got_xywh = CF.recover_shape_bbox(torch.from_numpy(bbox).to(dev), info).cpu().numpy()
+        assert np.array_equal(got_xywh, xywh), (name, np.abs(got_xywh - xywh).max())
+        rles, resized = CF.recover_masks_rle(torch.from_numpy(masks).to(dev), info, return_resized=True)
+        assert np.array_equal(resized.cpu().numpy().astype(bool), seg), name
+        for k, rle in enumerate(rles):
+            want_counts = R.rle_counts(seg[k])
+            assert rle["size"] == [info["height"], info["width"]]
+            assert rle["counts"] == R.rle_to_string(want_counts), (name, k)
+            assert R.rle_string_decode(rle["counts"], seg[k].size) == want_counts
+    # a mask with more runs than the first buffer guess takes the retry path
+    noisy = (torch.rand(1, 64, 64, generator=torch.Generator().manual_seed(1)) < 0.5)
+    info = dict(height=64, width=64)
+    rles = CF.recover_masks_rle(noisy.to(dev), info, max_runs=64)
+    assert rles[0]["counts"] == R.rle_to_string(R.rle_counts(R.recover_shape_segm(noisy, info)[0].numpy()))
+
+
+def test_coco_formatter_end_to_end(dev):
+    """Detections of the HIP postprocess -> COCO result dicts, vs the oracle on the same detections."""
+    from orienmask_amd.coco_format import COCOFormatter
+    pc = post_cfg((96, 128))
+    heads = synth.synth_heads(321, 2, pc["grid_size"], regime="mixed")
+    post = _hip_post((96, 128), dev)
+    dets = post(tuple((b.to(dev), o.to(dev)) for b, o in heads))
+    infos = [dict(id=11, height=120, width=160, collate_pad=[0, 0, 0, 0, 96, 128]),
+             dict(id=12, height=75, width=100, pad=[2, 2, 4, 4, 96, 128], hflip=True)]
+    cat2label = list(range(1, 81))
+    res = COCOFormatter(cat2label, with_mask=True).to_coco_format(infos, dets)
+    assert len(res["bbox"]) == len(res["segm"]) == sum(int(d["bbox"].shape[0]) for d in dets)
+    i = 0
+    for info, d in zip(infos, dets):
+        xywh = R.recover_shape_bbox(d["bbox"].cpu(), info)
+        seg = R.recover_shape_segm(d["mask"].cpu(), info).numpy()
+        for k in range(d["bbox"].shape[0]):
+            b, s = res["bbox"][i], res["segm"][i]
+            assert b["image_id"] == s["image_id"] == info["id"] and b["category_id"] == cat2label[int(d["cls"][k])]
+            assert b["bbox"] == xywh[k].tolist() and abs(b["score"] - float(d["bbox"][k, 4])) == 0
+            assert s["segmentation"] == {"size": [info["height"], info["width"]],
+                                         "counts": R.rle_to_string(R.rle_counts(seg[k]))}
+            i += 1

@@ -135,3 +135,30 @@ def test_preprocess_matches_reference():
         assert np.array_equal(flat[torch.from_numpy(g[name + "_idx"])].numpy(), g[name + "_samples"]), name
         if name + "_out" in g.files:
             assert np.array_equal(x.numpy(), g[name + "_out"]), name
+
+
+def _coco_cases():
+    import json
+    g = np.load(os.path.join(GOLDEN, "coco_format.npz"))
+    for name in sorted(k[:-3] for k in g.files if k.endswith("_hw")):
+        H, W = (int(v) for v in g[name + "_hw"])
+        info = json.loads(str(g[name + "_info"]))
+        masks = unpack_masks(g[name + "_mask"], (g[name + "_bbox"].shape[0], H, W))
+        seg = unpack_masks(g[name + "_seg"], g[name + "_segshape"])
+        yield name, info, masks, g[name + "_bbox"], g[name + "_xywh"], seg
+
+
+def test_coco_format_recover_matches_reference():
+    """_recover_shape_bbox / _recover_shape_segm restatements vs the reference's static methods; RLE properties."""
+    n = 0
+    for name, info, masks, bbox, xywh, seg in _coco_cases():
+        assert np.array_equal(R.recover_shape_bbox(torch.from_numpy(bbox), info).numpy(), xywh), name
+        got = R.recover_shape_segm(torch.from_numpy(masks), info).numpy()
+        assert np.array_equal(got.astype(bool), seg), name
+        for k in range(got.shape[0]):
+            c = R.rle_counts(got[k])
+            assert sum(c) == got[k].size and sum(c[1::2]) == int(got[k].sum())
+            s = R.rle_to_string(c)
+            assert R.rle_string_decode(s, got[k].size) == c          # string packing round-trips
+        n += 1
+    assert n == 5

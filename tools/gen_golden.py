@@ -199,6 +199,43 @@ def yolo_golden():
     print("yolo_fwd: %.0f KB" % (os.path.getsize(os.path.join(OUT, "yolo_fwd.npz")) / 1024))
 
 
+def coco_format_golden():
+    """G8: COCOMetrics._recover_shape_bbox / _recover_shape_segm run from the reference (static methods)."""
+    cfg, rmodel, reval, rfunc = import_reference()
+    from eval.coco_eval import COCOMetrics
+    rng = np.random.Generator(np.random.PCG64(61))
+    cases = [
+        ("plain", (544, 544), dict(height=480, width=640)),
+        ("collate", (544, 544), dict(height=427, width=640, collate_pad=[0, 0, 0, 0, 544, 544])),
+        ("padded", (320, 352), dict(height=300, width=333, collate_pad=[9, 10, 10, 10, 320, 352])),
+        ("both", (160, 192), dict(height=97, width=131, collate_pad=[8, 8, 0, 0, 160, 192], pad=[5, 6, 7, 8, 160, 176])),
+        ("flips", (96, 128), dict(height=211, width=150, hflip=True, vflip=True, pad=[3, 0, 0, 4, 96, 128])),
+    ]
+    rec = {}
+    for name, (H, W), info in cases:
+        K = 7
+        # blobby masks: thresholded smooth noise
+        yy, xx = np.mgrid[0:H, 0:W]
+        masks = np.zeros((K, H, W), dtype=bool)
+        for k in range(K):
+            cy, cx = rng.random(2) * [H, W]
+            ry, rx = (0.05 + 0.3 * rng.random(2)) * [H, W]
+            masks[k] = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1) ^ (rng.random((H, W)) < 0.02)
+        bbox = np.concatenate([rng.random((K, 2)), rng.random((K, 2)) * 0.5, rng.random((K, 1))], 1).astype(np.float32)
+        xywh = COCOMetrics._recover_shape_bbox(torch.from_numpy(bbox[:, :4]), info)
+        seg = COCOMetrics._recover_shape_segm(torch.from_numpy(masks), info)
+        rec[name + "_hw"] = np.array([H, W]); rec[name + "_info"] = np.array(json_dumps(info))
+        rec[name + "_mask"] = pack_masks(masks); rec[name + "_bbox"] = bbox
+        rec[name + "_xywh"] = xywh.numpy(); rec[name + "_seg"] = pack_masks(seg.numpy()); rec[name + "_segshape"] = np.array(seg.shape)
+    np.savez_compressed(os.path.join(OUT, "coco_format.npz"), **rec)
+    print("coco_format: %d cases, %.0f KB" % (len(cases), os.path.getsize(os.path.join(OUT, "coco_format.npz")) / 1024))
+
+
+def json_dumps(obj):
+    import json
+    return json.dumps(obj)
+
+
 def preprocess_golden():
     """G6: FastCOCOTransform (Resize + Normalize) and infer.pad run from the reference's own code.
     data/transform.py needs cv2 / torchvision at import time only (module-level tables and the CPU
@@ -253,7 +290,10 @@ if __name__ == "__main__":
         preprocess_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "yolo":
         yolo_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "coco":
+        coco_format_golden()
     else:
         main()
         yolo_golden()
+        coco_format_golden()
         preprocess_golden()
