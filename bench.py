@@ -68,6 +68,42 @@ def cpu_baseline(sd, x_cpu, target_seconds=12.0):
                        "%d threads" % (reps, cores))
 
 
+def measure_neighbours(dev, dets, B):
+    """Side measurements of the two rows next to the path; not part of `value`."""
+    from orienmask_amd import synth
+    from orienmask_amd.coco_format import COCOFormatter
+    from orienmask_amd.transform import FastCOCOTransform
+    out = {}
+    tf = FastCOCOTransform([FastCOCOTransform.Resize((544, 544)), FastCOCOTransform.Normalize((0, 0, 0), (255, 255, 255))])
+    img = synth.synth_photo_batch(5, B, 480, 640).to(dev)
+    for _ in range(3):
+        tf.padded(img)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        x, _ = tf.padded(img)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    byts = img.numel() * 4 + x.numel() * 4
+    out["preprocess"] = dict(kernel="preprocess_kernel", workload="%d x 480x640x3 float HWC -> [%d,3,544,544]" % (B, B),
+                             ms=round(ms, 4), images_per_s=round(B / ms * 1e3, 1), bound="hbm", unit="GB/s",
+                             achieved=round(byts / ms / 1e6, 1), peak=PEAK_HBM_GBS, frac=round(byts / ms / 1e6 / PEAK_HBM_GBS, 4))
+    fmt = COCOFormatter(list(range(1, 81)), with_mask=True)
+    infos = [dict(id=i, height=480, width=640, collate_pad=[0, 0, 0, 0, 544, 544]) for i in range(len(dets))]
+    fmt.to_coco_format(infos[:2], dets[:2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = min(8, len(dets))
+    res = fmt.to_coco_format(infos[:n], dets[:n])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["coco_format"] = dict(kernels="recover_bbox_kernel + recover_rle_kernel", workload="%d images x %d masks 544x544 -> 480x640 RLE"
+                              % (n, len(res["segm"]) // max(n, 1)), ms_per_image=round(dt / n * 1e3, 3),
+                              note="wall time incl. the host-side string packing; the reference copies 29.6 MB of masks per image to the host instead")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +112,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (metric is quoted at 32)")
     ap.add_argument("--size", type=int, default=544)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the preprocess / COCO-format side measurements")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
     args = ap.parse_args()
 
@@ -202,6 +239,8 @@ def main():
                                 per_gpu_batch=B, image_size=[H, W], detections_per_image=round(sum(int(d_["bbox"].shape[0]) for d_ in dets) / B, 1),
                                 parallelism="batch shard x%d, one RCCL weight broadcast, no collective in the step" % world),
                     roofline=roofline)
+        if not args.no_extras:
+            line["extras"] = measure_neighbours(dev, dets, B)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, x_cpu)
         print(json.dumps(line))
