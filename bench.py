@@ -202,8 +202,19 @@ def main():
         executed = d["exec_flops"] / (d["ms"] * 1e-3) / 1e12
         total_flops = sum(t["flops"] for t in kern.values())
         total_bytes = sum(t["bytes"] for t in kern.values())
+        traffic, traffic_src = None, None
+        try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.sh)
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
+            key = [k for k in pmc if k.replace(" ", "").startswith(dom.rstrip(">").replace(" ", ""))]
+            if key and B == 32 and H == 544:
+                traffic = round(pmc[key[0]]["hbm_bytes_per_launch_corrected"])
+                traffic_src = ("profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate "
+                               "rocprofv3 --pmc passes of this bench at bs=32 (FETCH_SIZE doubled per MI355X_MICROARCH.md)")
+        except Exception:
+            pass
         roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                        frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
+                        algorithmic_bytes_per_launch=round(d["bytes"] / d["launches"]),
                         kernel=dom,
                         launches_per_step=d["launches"], avg_launch_ms=round(d["ms"] / d["launches"], 4),
                         kernel_ms_per_step=round(d["ms"], 3),

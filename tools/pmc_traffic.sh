@@ -1,0 +1,36 @@
+#!/bin/bash
+# HBM traffic of the bench's kernels from PMC counters (two separate passes, kernel-trace only):
+#   gpurun -- 'bash tools/pmc_traffic.sh'
+# Writes gpurun_out/pmc_traffic.json: per kernel name, launches, FETCH_SIZE and WRITE_SIZE sums (KiB as rocprofv3
+# reports them).  On gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads: double it
+# (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is used as reported.
+set -e
+R=$PWD
+export TMPDIR=/tmp
+cd /tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $R/gpurun_out/pmc_$C
+  rocprofv3 --kernel-trace --output-format csv --pmc $C -d $R/gpurun_out/pmc_$C -o pmc -- \
+    python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_$C.err || true
+done
+cd $R
+python - <<'PY'
+import csv, glob, collections, json
+out = collections.OrderedDict()
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob("gpurun_out/pmc_%s/**/*counter_collection.csv" % c, recursive=True)[0]
+    per = collections.defaultdict(lambda: [set(), 0.0])
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != c: continue
+        name = r["Kernel_Name"].split("(")[0].replace("void om::", "").replace("om::", "")
+        per[name][0].add(r["Dispatch_Id"]); per[name][1] += float(r["Counter_Value"])
+    for name, (ids, tot) in per.items():
+        d = out.setdefault(name, {})
+        d["launches"] = len(ids); d[c + "_sum"] = tot; d[c + "_per_launch"] = tot / len(ids)
+for name, d in out.items():
+    if "FETCH_SIZE_per_launch" in d and "WRITE_SIZE_per_launch" in d:
+        d["hbm_bytes_per_launch_corrected"] = (2.0 * d["FETCH_SIZE_per_launch"] + d["WRITE_SIZE_per_launch"]) * 1024.0
+json.dump(out, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
+for name, d in out.items():
+    print("%-60s launches %4d  fetch/launch %10.1f KiB  write/launch %10.1f KiB" % (name[:60], d.get("launches", 0), d.get("FETCH_SIZE_per_launch", 0), d.get("WRITE_SIZE_per_launch", 0)))
+PY
