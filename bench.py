@@ -193,7 +193,7 @@ def main():
             wino = k.startswith("wino")
             # Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36 -> executed = algorithmic / 2.25
             acc(k, ms / n_fw, wk["flops"], wk["flops"] / 2.25 if wino else wk["flops"], wk["bytes"])
-            if wino:
+            if k.startswith("wino_gemm"):
                 acc("wino_input_kernel", pre / n_fw, 0.0, 0.0, 5.0 * 4 * B * (H // arch.layer_div(specs[name])) ** 2 * specs[name].cin)
         dom = max(kern, key=lambda k: kern[k]["ms"])
         d = kern[dom]

@@ -108,7 +108,8 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
 /* Tile shape (rows x channels per workgroup) of the conv kernel instantiation that runs layer `index` at
  * this problem size; 0 x 0 for the stem kernel.  Lets a profile be grouped by kernel. */
 int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, int* bn, int* algo);
-/* algo: 0 = conv_stem_kernel, 1 = conv_igemm_f32_kernel<bm,bn>, 2 = wino_input_kernel + wino_gemm_kernel<bm,bn> */
+/* algo: 0 = conv_stem_kernel, 1 = conv_igemm_f32_kernel<bm,bn>, 2 = wino_input_kernel + wino_gemm_kernel<bm,bn>,
+ *       3 = wino_fused_kernel<bn> (input transform fused into the GEMM's loader) */
 int om_profile_enable(om_model* m, int enable);
 int om_profile_read(om_model* m, float* layer_ms, float* layer_pre_ms, int n_layers, int* n_forwards);
 

@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 // GEMM + inverse transform + epilogue
 // ------------------------------------------------------------------------------------------------
 struct WinoParams {
+    const float* X;       // fused variant: NHWC input view [B,H,W,C] (pixel stride in_pix_stride)
+    int in_pix_stride, total_in_pixels;
     const float* V;       // [16][T][C]
     const float* U;       // [16][cout_pad][C]
     const float* scale;
@@ -305,10 +307,296 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fused variant: the input transform happens in the GEMM's A-operand loader, V never exists in memory.
+//   V_xi[tile][c] = sum over the 2 x 2 patch pixels B^T row i / column j select, with +-1 signs
+// Each thread owns two tile rows x one 16-byte channel chunk: 4 buffer loads (zero padded by the descriptor)
+// -> 3 vector add/subs -> one ds_write_b128, software-pipelined TWO steps ahead through a 3-deep ring of A
+// buffers so that no load is waited for less than ~4 slots after its issue; the weights keep the LDS-DMA path.
+// Removes wino_input_kernel (9 % of the step, pure HBM traffic) at the price of 4x more L2 reads of X.
+// ------------------------------------------------------------------------------------------------
+template <int BN, int WN>
+__global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoParams p) {
+    constexpr int BM = 64, WM = 32;
+    constexpr int TN = WN / 32;
+    constexpr int NWN = BN / WN;
+    constexpr int B_CH = BN / 32;
+    constexpr int CH = BN / 4, RP = 256 / CH;
+    static_assert((BM / WM) * (BN / WN) == 4, "four waves per workgroup");
+    constexpr int A_BUF = BM * 8, B_BUF = BN * 8;                 // f32x4 units
+    static_assert(BM * BN / 4 <= 3 * A_BUF + 2 * B_BUF, "C tile must fit in the operand buffers");
+    __shared__ f32x4 smem[3 * A_BUF + 2 * B_BUF + 1];
+    int* const s_ticket = reinterpret_cast<int*>(smem + 3 * A_BUF + 2 * B_BUF);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int lrow = tid >> 3, lcol = tid & 7;
+    const int lsw = lcol ^ ((lrow >> 1) & 7);
+    const int scol = lsw;                                         // DMA source chunk (weights)
+    const int fi = lane & 31, fk = lane >> 5;
+    const int fsw = (fi >> 1) & 7;
+    const int ksteps = 16 * p.kc;
+    const size_t u_plane = (size_t)p.cout_pad * p.C;
+
+    for (;;) {
+        int tile;
+        if (p.ticket) {
+            if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+            __syncthreads();
+            tile = *s_ticket;
+        } else {
+            tile = blockIdx.x;
+        }
+        if (tile >= p.total_tiles) break;
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        const int tile_n = tile % p.n_tiles;
+        const int tile_m = tile / p.n_tiles;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+        // ---- per-thread patch geometry of its two tile rows
+        const int tiles_per_img = p.TH * p.TW;
+        const int b_first = (m0 < p.T ? m0 : p.T - 1) / tiles_per_img;
+        int pixrel[2];
+        unsigned vmask[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int m = m0 + lrow + 32 * j;
+            const bool mok = m < p.T;
+            if (!mok) m = p.T - 1;
+            const int b = m / tiles_per_img;
+            const int rr = m - b * tiles_per_img;
+            const int ty = rr / p.TW, tx = rr - ty * p.TW;
+            pixrel[j] = ((b - b_first) * p.H + 2 * ty - 1) * p.W + 2 * tx - 1;
+            unsigned vm = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool ok = mok & ((unsigned)(2 * ty - 1 + r) < (unsigned)p.H) & ((unsigned)(2 * tx - 1 + c) < (unsigned)p.W);
+                    vm |= (ok ? 1u : 0u) << (r * 4 + c);
+                }
+            vmask[j] = vm;
+        }
+        const float* in_base = p.X + (size_t)b_first * p.H * p.W * p.in_pix_stride;
+        const size_t in_left = ((size_t)p.total_in_pixels - (size_t)b_first * p.H * p.W) * p.in_pix_stride * 4;
+        const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_base), 0,
+                                                             in_left < 0x7FFFFFFFull ? (int)in_left : 0x7FFFFFFF, 0x00020000);
+        const int lcol16 = lcol * 16;
+        const int stride4 = p.in_pix_stride * 4;
+
+        // B^T row i (and column j) of the input transform: +-d[ra] +- d[rb]
+        //   i : 0 -> d0 - d2, 1 -> d1 + d2, 2 -> d2 - d1, 3 -> d1 - d3
+        auto sel_a = [](int i) { return i == 0 ? 0 : 1; };
+        auto sel_b = [](int i) { return i == 3 ? 3 : 2; };
+        auto sgn_a = [](int i) { return i == 2 ? -1.f : 1.f; };
+        auto sgn_b = [](int i) { return (i == 0 || i == 3) ? -1.f : 1.f; };
+
+        f32x4 L[4];                       // the four patch pixels of the row being fetched
+        int a_xi = 0, a_cc = 0;           // (transform index, channel chunk) of the A step being fetched
+        int n_xi = 0, n_cc = 0;           // ... of the B (weights) step being fetched
+        auto adv = [&](int& xi, int& cc) {
+            if (++cc == p.kc) { cc = 0; ++xi; }
+        };
+        auto load_row = [&](int j, int k, bool live) {      // k-th of the 4 patch pixels of tile row j
+            const int i = a_xi >> 2, jj = a_xi & 3;
+            const int r = (k & 2) ? sel_b(i) : sel_a(i);
+            const int c = (k & 1) ? sel_b(jj) : sel_a(jj);
+            const bool ok = live & (((vmask[j] >> (r * 4 + c)) & 1u) != 0);
+            const int voff = ((pixrel[j] + r * p.W + c) * stride4 + lcol16) | (ok ? 0 : (int)0x80000000);
+            L[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, a_cc * 128, 0));
+        };
+        auto write_row = [&](int j, int abuf) {
+            const int i = a_xi >> 2, jj = a_xi & 3;
+            const float sa = sgn_a(i), sb = sgn_b(i), ca_ = sgn_a(jj), cb_ = sgn_b(jj);
+            const f32x4 top = L[0] * ca_ + L[1] * cb_;
+            const f32x4 bot = L[2] * ca_ + L[3] * cb_;
+            smem[abuf * A_BUF + (lrow + 32 * j) * 8 + lsw] = top * sa + bot * sb;
+        };
+        auto issue_b = [&](int piece, int bbuf, bool live) {
+            const float* bbase = p.U + (size_t)n_xi * u_plane + (size_t)n0 * p.C;
+            const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bbase), 0, live ? BN * p.C * 4 : 0, 0x00020000);
+            f32x4* dst = smem + 3 * A_BUF + bbuf * B_BUF + wave_u * 64 + piece * 256;
+            const int vo = ((lrow + 32 * piece) * p.C + scol * 4) * 4;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)dst, 16, vo, n_cc * 128, 0, 0);
+        };
+
+        f32x16 acc[TN], outa[2][2][TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[b][r] = 0.f;
+                outa[0][0][b][r] = 0.f; outa[0][1][b][r] = 0.f; outa[1][0][b][r] = 0.f; outa[1][1][b][r] = 0.f;
+            }
+
+        const f32x4* fragA = smem + (wm * WM + fi) * 8;
+        const f32x4* fragB = smem + 3 * A_BUF + (wn * WN + fi) * 8;
+        f32x4 ca, cb[TN], na, nb[TN];
+        auto read_frags = [&](f32x4& fa, f32x4(&fb)[TN], int abuf, int bbuf, int q) {
+            const int ch = (2 * q + fk) ^ fsw;
+            fa = fragA[abuf * A_BUF + ch];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = fragB[bbuf * B_BUF + b * 32 * 8 + ch];
+        };
+
+        // ---- prologue: A of step 0 (both rows) and step 1 (row 0), row 1 of step 1 left in flight; B of step 0
+#pragma unroll
+        for (int piece = 0; piece < B_CH; ++piece) issue_b(piece, 0, true);
+        adv(n_xi, n_cc);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) load_row(j, k, true);
+            write_row(j, 0);
+        }
+        adv(a_xi, a_cc);                                    // A fetch state = step 1
+        {
+            const bool live1 = 1 < ksteps;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) load_row(0, k, live1);
+            write_row(0, 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) load_row(1, k, live1);   // consumed at slot 0 of step 0
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the B DMA of step 0 is older than the 4 loads still in flight
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(ca, cb, 0, 0, 0);
+
+        int abuf = 0;          // A ring slot of the step being computed
+        int xi = 0, cc = 0;
+        for (int s = 0; s < ksteps; ++s) {
+            const int bbuf = s & 1;
+            const int abuf1 = abuf == 2 ? 0 : abuf + 1;     // step s+1
+            const int abuf2 = abuf1 == 2 ? 0 : abuf1 + 1;   // step s+2
+            const bool live1 = s + 1 < ksteps, live2 = s + 2 < ksteps;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int slot = q * 4 + t;
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[b][t], ca[t], acc[b], 0, 0, 0);
+                    if (slot == 0) {
+                        write_row(1, abuf1);                // row 1 of step s+1 (loaded during the previous step)
+                        adv(a_xi, a_cc);                    // A fetch state = step s+2
+                    }
+                    if (slot >= 1 && slot <= 4) load_row(0, slot - 1, live2);
+                    if (slot < B_CH) issue_b(slot, bbuf ^ 1, live1);
+                    if (t == 1 && q < 3) read_frags(na, nb, abuf, bbuf, q + 1);
+                    if (slot == 7) write_row(0, abuf2);
+                    if (slot >= 8 && slot <= 11) load_row(1, slot - 8, live2);
+                    if (slot == 11) {
+                        // B DMA of step s+1 and every ds_write so far are done; the 4 row-1 loads stay in flight
+                        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    if (slot == 12) read_frags(na, nb, abuf1, bbuf ^ 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                ca = na;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) cb[b] = nb[b];
+            }
+            adv(n_xi, n_cc);
+            abuf = abuf1;
+            if (++cc == p.kc) {
+                const int i = xi >> 2, j = xi & 3;
+                const float ci0 = i < 3 ? 1.f : 0.f, ci1 = i == 0 ? 0.f : (i == 1 ? 1.f : -1.f);
+                const float cj0 = j < 3 ? 1.f : 0.f, cj1 = j == 0 ? 0.f : (j == 1 ? 1.f : -1.f);
+                const float c00 = ci0 * cj0, c01 = ci0 * cj1, c10 = ci1 * cj0, c11 = ci1 * cj1;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    if (c00 != 0.f) outa[0][0][b] += acc[b] * c00;
+                    if (c01 != 0.f) outa[0][1][b] += acc[b] * c01;
+                    if (c10 != 0.f) outa[1][0][b] += acc[b] * c10;
+                    if (c11 != 0.f) outa[1][1][b] += acc[b] * c11;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+                }
+                cc = 0;
+                ++xi;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // ---- epilogue: four output positions, each through the LDS C tile
+        f32x4* sC = smem;
+        const int n4 = tid % CH, r0 = tid / CH;
+        const int n = n0 + n4 * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+        const int nvalid = p.cout - n;
+        const bool vec = p.vec_io && nvalid >= 4;
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) {
+            const int py = pq >> 1, px = pq & 1;
+            const int ml0 = wm * WM + fi;
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c4 = (wn * WN + b * 32) / 4 + 2 * g + fk;
+                    const f32x16 o = outa[py][px][b];
+                    f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+                    sC[ml0 * CH + (c4 ^ (ml0 & 7))] = v;
+                }
+            __syncthreads();
+#pragma unroll 2
+            for (int ps = 0; ps < BM / RP; ++ps) {
+                const int ml = ps * RP + r0;
+                const int m = m0 + ml;
+                if (m >= p.T || nvalid <= 0) continue;
+                const int bi = m / tiles_per_img;
+                const int rr = m - bi * tiles_per_img;
+                const int ty = rr / p.TW, tx = rr - ty * p.TW;
+                const int y = 2 * ty + py, x = 2 * tx + px;
+                if (y >= p.H || x >= p.W) continue;
+                const size_t pix = ((size_t)bi * p.H + y) * p.W + x;
+                f32x4 v = sC[ml * CH + (n4 ^ (ml & 7))];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float tv = fmaf(v[k], sc[k], sh[k]);
+                    v[k] = p.leaky ? (tv > 0.f ? tv : tv * 0.1f) : tv;
+                }
+                float* o = p.out + pix * p.out_pix_stride + n;
+                if (p.res) {
+                    const float* rp = p.res + pix * p.res_pix_stride + n;
+                    if (vec) v += *reinterpret_cast<const f32x4*>(rp);
+                    else
+                        for (int k = 0; k < 4 && k < nvalid; ++k) v[k] += rp[k];
+                }
+                if (vec) *reinterpret_cast<f32x4*>(o) = v;
+                else
+                    for (int k = 0; k < 4 && k < nvalid; ++k) o[k] = v[k];
+            }
+            __syncthreads();
+        }
+        if (!p.ticket) break;
+    }
+}
+
 size_t wino_scratch_floats(int B, int H, int W, int C) {
     const size_t T = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
     return 16 * T * C;
 }
+
+// The fused loader wins where the transform kernel's HBM round trip is large next to the GEMM (cin <= 64:
+// conv2.1, conv3.x); for wider layers the separate transform + pure-DMA GEMM is faster (measured: 136^2 128->256
+// 1.88 vs 1.79 ms, 34^2 256->512 0.575 vs 0.522 ms).  OM_WINO_FUSED=0/1 forces one variant everywhere.
+static bool wino_fused(int cin) {
+    static const int v = [] { const char* e = getenv("OM_WINO_FUSED"); return e ? atoi(e) : -1; }();
+    return v < 0 ? cin <= 64 : v != 0;
+}
+
+bool wino_fused_for(int cin) { return wino_fused(cin); }
 
 bool wino_enabled() {
     static const int v = [] { const char* e = getenv("OM_WINOGRAD"); return e ? atoi(e) : 1; }();
@@ -329,6 +617,20 @@ static int launch_wino_tile(WinoParams p, int blocks_per_cu, hipStream_t stream)
     return OM_OK;
 }
 
+template <int BN, int WN>
+static int launch_wino_fused(WinoParams p, int blocks_per_cu, hipStream_t stream) {
+    const int m_tiles = (p.T + 63) / 64;
+    p.n_tiles = p.cout_pad / BN;
+    const long long total = (long long)m_tiles * p.n_tiles;
+    OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "winograd: %lld tiles out of range", total);
+    p.total_tiles = (int)total;
+    long long grid = total;
+    if (p.ticket) grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
+    hipLaunchKernelGGL((wino_fused_kernel<BN, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
 // a.w must point at the transformed weights U [16][cout_pad][cin]; scratch holds V (wino_scratch_floats).
 int launch_conv_winograd(const ConvArgs& a, float* scratch, hipStream_t stream) {
     OM_REQUIRE(a.in && a.w && a.scale && a.shift && a.out && scratch, OM_EINVAL, "winograd: null pointer");
@@ -341,12 +643,15 @@ int launch_conv_winograd(const ConvArgs& a, float* scratch, hipStream_t stream) 
     const int TH = (a.H + 1) / 2, TW = (a.W + 1) / 2;
     const long long T = (long long)a.B * TH * TW;
     OM_REQUIRE(T < (1ll << 31) && 16 * T * a.cin < (1ll << 40), OM_EINVAL, "winograd: problem too large");
+    const bool fused = wino_fused(a.cin);
     const long long threads = T * (a.cin / 4);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a.in, scratch, a.H,
+    if (!fused)
+        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a.in, scratch, a.H,
                        a.W, a.cin, a.in_pix_stride, TH, TW, (int)T);
     OM_CHECK_HIP(hipGetLastError());
     if (a.mid_event) OM_CHECK_HIP(hipEventRecord(a.mid_event, stream));
     WinoParams p;
+    p.X = a.in; p.in_pix_stride = a.in_pix_stride; p.total_in_pixels = a.B * a.H * a.W;
     p.V = scratch; p.U = a.w; p.scale = a.scale; p.shift = a.shift; p.res = a.res; p.out = a.out; p.ticket = a.ticket;
     p.T = (int)T; p.TH = TH; p.TW = TW; p.C = a.cin; p.kc = a.cin / 32;
     p.H = a.H; p.W = a.W; p.cout = a.cout; p.cout_pad = a.cout_pad;
@@ -355,6 +660,10 @@ int launch_conv_winograd(const ConvArgs& a, float* scratch, hipStream_t stream) 
     p.vec_io = (a.out_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
                 (!a.res || (a.res_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)))
                    ? 1 : 0;
+    if (fused) {
+        if (a.cout_pad % 128 == 0) return launch_wino_fused<128, 64>(p, 2, stream);
+        return launch_wino_fused<64, 32>(p, 3, stream);
+    }
     if (a.cout_pad % 128 == 0) return launch_wino_tile<64, 128, 32, 64>(p, 2, stream);
     return launch_wino_tile<64, 64, 32, 32>(p, 3, stream);
 }

@@ -58,7 +58,8 @@ void conv_tile_for(int M, int cout_pad, int* bm, int* bn);
 // Winograd F(2x2,3x3) path (conv_wino.hip): a.w = U [16][cout_pad][cin]
 int launch_conv_winograd(const ConvArgs& a, float* scratch, hipStream_t stream);
 size_t wino_scratch_floats(int B, int H, int W, int C);
-bool wino_enabled();   // tile shape launch_conv_igemm picks
+bool wino_enabled();
+bool wino_fused_for(int cin);     // true: the input transform is fused into the GEMM's loader   // tile shape launch_conv_igemm picks
 int launch_conv_stem(const float* in_nchw, int B, int H, int W, const float* w, const float* scale,
                      const float* shift, int cout, float* out_nhwc, hipStream_t stream);
 

@@ -368,7 +368,8 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
     const om::LayerDef& L = m->layers[index];
     if (L.stem) { *bm = 0; *bn = 0; *algo = 0; return OM_OK; }
     if (L.info.wino_off >= 0 && om::wino_enabled()) {
-        *bm = 64; *bn = L.info.cout_pad % 128 == 0 ? 128 : 64; *algo = 2;
+        *bm = 64; *bn = L.info.cout_pad % 128 == 0 ? 128 : 64;
+        *algo = om::wino_fused_for(L.info.cin) ? 3 : 2;
         return OM_OK;
     }
     const int Ho = H / L.in_div / L.info.stride, Wo = W / L.in_div / L.info.stride;
