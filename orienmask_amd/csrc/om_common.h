@@ -59,6 +59,7 @@ void conv_tile_for(int M, int cout_pad, int* bm, int* bn);
 int launch_conv_winograd(const ConvArgs& a, float* scratch, hipStream_t stream);
 size_t wino_scratch_floats(int B, int H, int W, int C);
 bool wino_enabled();
+int wino_bn(long long T, int cout_pad);   // N tile of the (unfused) Winograd GEMM at this size
 bool wino_fused_for(int cin);     // true: the input transform is fused into the GEMM's loader   // tile shape launch_conv_igemm picks
 int launch_conv_stem(const float* in_nchw, int B, int H, int W, const float* w, const float* scale,
                      const float* shift, int cout, float* out_nhwc, hipStream_t stream);

@@ -368,8 +368,11 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
     const om::LayerDef& L = m->layers[index];
     if (L.stem) { *bm = 0; *bn = 0; *algo = 0; return OM_OK; }
     if (L.info.wino_off >= 0 && om::wino_enabled()) {
-        *bm = 64; *bn = L.info.cout_pad % 128 == 0 ? 128 : 64;
+        const int Hl = H / L.in_div, Wl = W / L.in_div;
         *algo = om::wino_fused_for(L.info.cin) ? 3 : 2;
+        *bm = 64;
+        *bn = *algo == 3 ? (L.info.cout_pad % 128 == 0 ? 128 : 64)
+                         : om::wino_bn((long long)B * ((Hl + 1) / 2) * ((Wl + 1) / 2), L.info.cout_pad);
         return OM_OK;
     }
     const int Ho = H / L.in_div / L.info.stride, Wo = W / L.in_div / L.info.stride;
