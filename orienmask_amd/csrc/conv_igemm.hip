@@ -476,7 +476,9 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t stream) {
     p.vec_io = (a.out_mode != 2 && a.out_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
                 (!a.res || (a.res_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)))
                    ? 1 : 0;
-    const TileChoice t = choose_tile(p.M, a.cout_pad);
+    TileChoice t = choose_tile(p.M, a.cout_pad);
+    static const int force_tile = [] { const char* e = getenv("OM_CONV_TILE"); return e ? atoi(e) : 0; }();   // e.g. 64128
+    if (force_tile > 0 && a.cout_pad % (force_tile % 1000) == 0) t = TileChoice{force_tile / 1000, force_tile % 1000};
     if (t.bm == 128 && t.bn == 128) return launch_tile<128, 128, 64, 64>(p, a.cout_pad, 2, stream);
     if (t.bm == 64 && t.bn == 128) return launch_tile<64, 128, 32, 64>(p, a.cout_pad, 3, stream);
     if (t.bm == 128 && t.bn == 64) return launch_tile<128, 64, 64, 32>(p, a.cout_pad, 3, stream);

@@ -433,72 +433,95 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
 __device__ __forceinline__ float bil_row(float v0, float v1, float w0, float w1) { return fmaf(v0, w0, v1 * w1); }
 
 __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
+    // One thread = a block of 16 x (up to) 4 output pixels that share their two source rows: output rows
+    // 4j-2 .. 4j+1 interpolate between source rows j-1 and j (phases 0.125, 0.375, 0.625, 0.875), so the 24 loads
+    // and the horizontal taps are done once per block instead of once per row.
     const int det = blockIdx.y;
     const int b = det / p.cfg.nms_post, k = det - b * p.cfg.nms_post;
     if (k >= p.out_count[b]) return;
     const int H = p.cfg.image_h, W = p.cfg.image_w;
     const int groups = W / MASK_PX;
+    const int oh = H / 4, ow = W / 4;
     const int item = blockIdx.x * 256 + threadIdx.x;
-    if (item >= H * groups) return;
-    const int y = item / groups, g = item - y * groups;
+    if (item >= (oh + 1) * groups) return;
+    const int jy = item / groups, g = item - jy * groups;      // source rows jy-1 and jy
     const float* dp = p.det_par + (size_t)det * 8;
     const float cx = dp[0], cy = dp[1], tx = dp[2], ty = dp[3], gax = dp[4], gay = dp[5];
     const int chan = __float_as_int(dp[6]), s = __float_as_int(dp[7]);
     const float nW = (float)p.cfg.grid_w[s], nH = (float)p.cfg.grid_h[s];
-    const int oh = H / 4, ow = W / 4;
     const int nch = p.cfg.num_scales * p.cfg.anchors_per_scale * 2;
     const float* px = p.oriens + ((size_t)b * nch + chan) * oh * ow;
     const float* py = px + (size_t)oh * ow;
 
-    // vertical taps (generic, clamped like torch: src >= 0, i1 = min(i0 + 1, n - 1))
-    const float sy = fmaxf(((float)y + 0.5f) * 0.25f - 0.5f, 0.0f);
-    const int y0 = (int)sy;
-    const int y1 = y0 + (y0 < oh - 1 ? 1 : 0);
-    const float wy1 = sy - (float)y0, wy0 = 1.0f - wy1;
-    const float base_y = ((float)y / (float)H) * nH;                      // postprocess.py:40-41
-
+    // source rows (clamped at the borders exactly like torch: src >= 0, i1 = min(i0 + 1, n - 1))
+    const int r0 = max(jy - 1, 0), r1 = min(jy, oh - 1);
     // six source columns 4g-1 .. 4g+4 cover the 16 outputs; clamp the loads at the borders
     float ax[2][6], ay[2][6];
     const int c_first = 4 * g - 1;
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
         const int col = min(max(c_first + c, 0), ow - 1);
-        ax[0][c] = px[(size_t)y0 * ow + col]; ax[1][c] = px[(size_t)y1 * ow + col];
-        ay[0][c] = py[(size_t)y0 * ow + col]; ay[1][c] = py[(size_t)y1 * ow + col];
+        ax[0][c] = px[(size_t)r0 * ow + col]; ax[1][c] = px[(size_t)r1 * ow + col];
+        ay[0][c] = py[(size_t)r0 * ow + col]; ay[1][c] = py[(size_t)r1 * ow + col];
     }
     const bool left_edge = (g == 0);
-    unsigned packed[4] = {0, 0, 0, 0};
+    // horizontal taps of both source rows, both planes (row(y) = fmaf(v[x0], wx0, v[x1] * wx1))
+    float hx[2][MASK_PX], hy[2][MASK_PX];
 #pragma unroll
     for (int e = 0; e < MASK_PX; ++e) {
         const int ph = e & 3, j = e >> 2;
-        // phase -> (local column of x0, weight of x1): src = j + ph/4 - 0.375 (relative to column 4g)
         const int c0 = j + (ph < 2 ? 0 : 1);
         float wx1 = ph == 0 ? 0.625f : ph == 1 ? 0.875f : ph == 2 ? 0.125f : 0.375f;
-        float v00x, v01x, v10x, v11x, v00y, v01y, v10y, v11y;
-        if (e < 2) {
-            // outputs 0 and 1 of the first group clamp to src = 0: x0 = 0, weight of x1 = 0
-            wx1 = left_edge ? 0.0f : wx1;
-            v00x = left_edge ? ax[0][1] : ax[0][0]; v01x = left_edge ? ax[0][2] : ax[0][1];
-            v10x = left_edge ? ax[1][1] : ax[1][0]; v11x = left_edge ? ax[1][2] : ax[1][1];
-            v00y = left_edge ? ay[0][1] : ay[0][0]; v01y = left_edge ? ay[0][2] : ay[0][1];
-            v10y = left_edge ? ay[1][1] : ay[1][0]; v11y = left_edge ? ay[1][2] : ay[1][1];
-        } else {
-            v00x = ax[0][c0]; v01x = ax[0][c0 + 1]; v10x = ax[1][c0]; v11x = ax[1][c0 + 1];
-            v00y = ay[0][c0]; v01y = ay[0][c0 + 1]; v10y = ay[1][c0]; v11y = ay[1][c0 + 1];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float v0x, v1x, v0y, v1y;
+            if (e < 2) {
+                // outputs 0 and 1 of the first group clamp to src = 0: x0 = 0, weight of x1 = 0
+                v0x = left_edge ? ax[r][1] : ax[r][0]; v1x = left_edge ? ax[r][2] : ax[r][1];
+                v0y = left_edge ? ay[r][1] : ay[r][0]; v1y = left_edge ? ay[r][2] : ay[r][1];
+            } else {
+                v0x = ax[r][c0]; v1x = ax[r][c0 + 1];
+                v0y = ay[r][c0]; v1y = ay[r][c0 + 1];
+            }
+            const float w1 = (e < 2 && left_edge) ? 0.0f : wx1;
+            const float w0 = 1.0f - w1;
+            hx[r][e] = fmaf(v0x, w0, v1x * w1);
+            hy[r][e] = fmaf(v0y, w0, v1y * w1);
         }
-        const float wx0 = 1.0f - wx1;
-        const float vx = fmaf(bil_row(v00x, v01x, wx0, wx1), wy0, bil_row(v10x, v11x, wx0, wx1) * wy1);
-        const float vy = fmaf(bil_row(v00y, v01y, wx0, wx1), wy0, bil_row(v10y, v11y, wx0, wx1) * wy1);
-        const int x = g * MASK_PX + e;
-        const float base_x = ((float)x / (float)W) * nW;
-        const float Px = (vx * gax) / 2.0f + base_x;                      // postprocess.py:142-143
-        const float Py = (vy * gay) / 2.0f + base_y;
-        const bool inside = (fabsf(Px - cx) < tx) && (fabsf(Py - cy) < ty);
-        packed[e >> 2] |= (inside ? 1u : 0u) << ((e & 3) * 8);
     }
-    uint4 o;
-    o.x = packed[0]; o.y = packed[1]; o.z = packed[2]; o.w = packed[3];
-    *reinterpret_cast<uint4*>(p.out_mask + ((size_t)det * H + y) * W + (size_t)g * MASK_PX) = o;
+    // the (up to) four output rows of this block
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int y = 4 * jy - 2 + q;
+        if (y < 0 || y >= H) continue;
+        // y = 4 jy - 2 + q: src = y/4 - 0.375 -> upper source row jy-1, weight of the lower row 0.125, 0.375,
+        // 0.625, 0.875 for q = 0..3.  Rows 0 and 1 clamp to src = 0: weight 0 on the second row.
+        float wy1 = q == 0 ? 0.125f : q == 1 ? 0.375f : q == 2 ? 0.625f : 0.875f;
+        const bool top_edge = (y < 2);
+        if (top_edge) wy1 = 0.0f;
+        const float wy0 = 1.0f - wy1;
+        const float base_y = ((float)y / (float)H) * nH;
+        unsigned packed[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < MASK_PX; ++e) {
+            // top edge (jy == 0): both source rows are row 0 and the second weight is 0, like torch's clamped tap
+            const float tx0 = top_edge ? hx[1][e] : hx[0][e];
+            const float bx0 = hx[1][e];
+            const float ty0 = top_edge ? hy[1][e] : hy[0][e];
+            const float by0 = hy[1][e];
+            const float vx = fmaf(tx0, wy0, bx0 * wy1);
+            const float vy = fmaf(ty0, wy0, by0 * wy1);
+            const int x = g * MASK_PX + e;
+            const float base_x = ((float)x / (float)W) * nW;
+            const float Px = (vx * gax) / 2.0f + base_x;                  // postprocess.py:142-143
+            const float Py = (vy * gay) / 2.0f + base_y;
+            const bool inside = (fabsf(Px - cx) < tx) && (fabsf(Py - cy) < ty);
+            packed[e >> 2] |= (inside ? 1u : 0u) << ((e & 3) * 8);
+        }
+        uint4 o;
+        o.x = packed[0]; o.y = packed[1]; o.z = packed[2]; o.w = packed[3];
+        *reinterpret_cast<uint4*>(p.out_mask + ((size_t)det * H + y) * W + (size_t)g * MASK_PX) = o;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -628,7 +651,7 @@ int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbo
     OM_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(om::post_select_kernel, dim3(B), dim3(om::SEL_THREADS), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
-    const int items = cfg->image_h * (cfg->image_w / om::MASK_PX);
+    const int items = (cfg->image_h / 4 + 1) * (cfg->image_w / om::MASK_PX);
     hipLaunchKernelGGL(om::post_mask_kernel, dim3((items + 255) / 256, B * cfg->nms_post), dim3(256), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
