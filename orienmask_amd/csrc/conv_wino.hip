@@ -103,9 +103,11 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
     constexpr int A_CH = BM / 32, B_CH = BN / 32, NP = A_CH + B_CH;
     constexpr int CH = BN / 4, RP = 256 / CH;
     static_assert((BM / WM) * (BN / WN) == 4, "four waves per workgroup");
-    static_assert(BM * BN <= 2 * (BM + BN) * 32, "C tile must fit in the operand buffers");
-    __shared__ f32x4 smem[2 * (BM + BN) * 8 + 1];     // one LDS object (see conv_igemm.hip)
-    int* const s_ticket = reinterpret_cast<int*>(smem + 2 * (BM + BN) * 8);
+    constexpr int NBUF = 3;         // operand ring: the DMA runs TWO k-steps ahead (a step is only 16*TM*TN MFMAs, far
+                                    // shorter than an HBM round trip), waited for with a counted vmcnt(NP)
+    static_assert(BM * BN <= NBUF * (BM + BN) * 32, "C tile must fit in the operand buffers");
+    __shared__ f32x4 smem[NBUF * (BM + BN) * 8 + 1];     // one LDS object (see conv_igemm.hip)
+    int* const s_ticket = reinterpret_cast<int*>(smem + NBUF * (BM + BN) * 8);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -191,13 +193,18 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
 #pragma unroll
         for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 0, true);
         advance();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+#pragma unroll
+        for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 1, 1 < ksteps);
+        advance();                                          // fetch state = step 2
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NP) : "memory");   // step 0 landed, step 1 may still fly
+        __builtin_amdgcn_s_barrier();
         read_frags(ca, cb, 0, 0);
         int xi = 0, cc = 0;
+        int buf = 0;
         for (int s = 0; s < ksteps; ++s) {
-            const int buf = s & 1;
-            const bool live = s + 1 < ksteps;
+            const int buf1 = buf == NBUF - 1 ? 0 : buf + 1;      // step s+1
+            const int buf2 = buf1 == NBUF - 1 ? 0 : buf1 + 1;    // step s+2 (last read during step s-1)
+            const bool live2 = s + 2 < ksteps;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -209,11 +216,13 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
                         for (int b = 0; b < TN; ++b)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[b][t], ca[a][t], acc[a][b], 0, 0, 0);
                     if (t == 1 && q < 3) read_frags(na, nb, buf, q + 1);
-                    if (slot < NP) issue_piece(slot, buf ^ 1, live);
-                    if (slot == 12) read_frags(na, nb, buf ^ 1, 0);
+                    if (slot < NP) issue_piece(slot, buf2, live2);
+                    if (slot == 12) read_frags(na, nb, buf1, 0);
                     if (slot == 11) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __syncthreads();
+                        // everything older than this step's NP pieces has landed = the operands of step s+1;
+                        // all my reads of the current buffer are done (lgkmcnt) -> raw barrier, no compiler fence
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NP) : "memory");
+                        __builtin_amdgcn_s_barrier();
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -222,6 +231,7 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
 #pragma unroll
                 for (int b = 0; b < TN; ++b) cb[b] = nb[b];
             }
+            buf = buf1;
             advance();
             if (++cc == p.kc) {
                 // flush M_xi into the four outputs: Y[p][q] += A^T[p][i] * A^T[q][j] * M,  xi = 4 i + j,
