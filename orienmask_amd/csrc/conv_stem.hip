@@ -77,6 +77,20 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+
+int launch_zero_words(void* ptr, size_t n_words, hipStream_t stream) {
+    OM_REQUIRE(ptr && (reinterpret_cast<uintptr_t>(ptr) & 3) == 0, OM_EINVAL, "zero_words: null or unaligned pointer");
+    if (n_words == 0) return OM_OK;
+    const size_t blocks = (n_words + 255) / 256;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, stream,
+                       static_cast<unsigned*>(ptr), n_words);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
 int launch_conv_stem(const float* in_nchw, int B, int H, int W, const float* w, const float* scale,
                      const float* shift, int cout, float* out_nhwc, hipStream_t stream) {
     OM_REQUIRE(in_nchw && w && scale && shift && out_nhwc, OM_EINVAL, "stem: null pointer");

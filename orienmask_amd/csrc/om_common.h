@@ -61,6 +61,9 @@ size_t wino_scratch_floats(int B, int H, int W, int C);
 bool wino_enabled();
 int wino_bn(long long T, int cout_pad);   // N tile of the (unfused) Winograd GEMM at this size
 bool wino_fused_for(int cin);     // true: the input transform is fused into the GEMM's loader   // tile shape launch_conv_igemm picks
+// Clears n 32-bit words with a kernel.  The library never uses hipMemsetAsync: a memset node captured
+// into a hipGraph was observed (ROCm 7.2, DESIGN.md "hipGraph") to leave part of the range uncleared on replay.
+int launch_zero_words(void* ptr, size_t n_words, hipStream_t stream);
 int launch_conv_stem(const float* in_nchw, int B, int H, int W, const float* w, const float* scale,
                      const float* shift, int cout, float* out_nhwc, hipStream_t stream);
 

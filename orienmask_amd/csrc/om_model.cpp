@@ -290,7 +290,7 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
         p += om::align_up(m->layers.size() * sizeof(int), 256);
         wino_scratch = reinterpret_cast<float*>(p);
     }
-    OM_CHECK_HIP(hipMemsetAsync(tickets, 0, m->layers.size() * sizeof(int), stream));
+    if (int rc = om::launch_zero_words(tickets, m->layers.size(), stream)) return rc;
     auto ptr_of = [&](const om::View& v) -> float* {
         switch (v.buf) {
             case om::BUF_BBOX32: return bbox32;
@@ -425,7 +425,7 @@ int om_conv2d(const float* in, int B, int H, int W, int cin, int in_pix_stride, 
     // uses, with tickets carved from the caller's workspace) is what gets tested and benchmarked
     static int* g_ticket = nullptr;
     if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), 256));
-    OM_CHECK_HIP(hipMemsetAsync(g_ticket, 0, sizeof(int), static_cast<hipStream_t>(stream)));
+    if (int rc = om::launch_zero_words(g_ticket, 1, static_cast<hipStream_t>(stream))) return rc;
     a.ticket = g_ticket;
     return om::launch_conv_igemm(a, static_cast<hipStream_t>(stream));
 }
@@ -450,7 +450,7 @@ int om_conv2d_winograd(const float* in, int B, int H, int W, int cin, int in_pix
     a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1;
     static int* g_ticket = nullptr;
     if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), 256));
-    OM_CHECK_HIP(hipMemsetAsync(g_ticket, 0, sizeof(int), static_cast<hipStream_t>(stream)));
+    if (int rc = om::launch_zero_words(g_ticket, 1, static_cast<hipStream_t>(stream))) return rc;
     a.ticket = g_ticket;
     return om::launch_conv_winograd(a, static_cast<float*>(scratch), static_cast<hipStream_t>(stream));
 }

@@ -646,7 +646,7 @@ int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbo
     p.det_par = reinterpret_cast<float*>(base + w.det_par);
     p.out_bbox = out_bbox; p.out_cls = out_cls; p.out_mask = out_mask; p.out_count = out_count; p.out_keep = out_keep;
 
-    OM_CHECK_HIP(hipMemsetAsync(p.hist1, 0, (size_t)B * om::L1_BINS * sizeof(unsigned), stream));
+    if (int rc = om::launch_zero_words(p.hist1, (size_t)B * om::L1_BINS, stream)) return rc;
     hipLaunchKernelGGL(om::post_decode_kernel, dim3(p.ntiles, B), dim3(256), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(om::post_select_kernel, dim3(B), dim3(om::SEL_THREADS), 0, stream, p);
@@ -669,7 +669,7 @@ int om_nms(const float* dets, int n, float thresh, int64_t* keep, int32_t* n_kee
     OM_REQUIRE(n >= 0 && n <= om::NMS_MAXN, OM_EINVAL, "om_nms: n=%d, at most %d boxes supported", n, om::NMS_MAXN);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (n == 0) {
-        OM_CHECK_HIP(hipMemsetAsync(n_keep, 0, sizeof(int32_t), stream));
+        return om::launch_zero_words(n_keep, 1, stream);
         return OM_OK;
     }
     OM_REQUIRE(ws_bytes >= om_nms_workspace_bytes(n), OM_ENOMEM, "om_nms: workspace %zu bytes < %zu needed", ws_bytes,

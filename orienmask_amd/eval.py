@@ -158,6 +158,11 @@ class OrienMaskYOLOPostProcess:
     def apply(self, predict):
         """Returns list[dict(bbox [K,5] f32, mask [K,H,W] bool, cls [K] i64)], K <= nms_post, per image
         (/root/reference/eval/orienmask_yolo_postprocess.py:66-124,146-166)."""
+        return self.collect(self.launch(predict))
+
+    def launch(self, predict):
+        """Enqueue the three postprocess kernels on the current stream; no host synchronisation (capturable in a
+        hipGraph).  Returns the raw output buffers for `collect`."""
         for p in predict:
             _lib.require_cuda_tensor(p[0], "bbox head", torch.float32)
             _lib.require_cuda_tensor(p[1], "orientation head", torch.float32)
@@ -189,7 +194,12 @@ class OrienMaskYOLOPostProcess:
                                   ctypes.c_void_p(out_count.data_ptr()), ctypes.c_void_p(out_keep.data_ptr()),
                                   ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream_ptr(dev))
         _lib.check(rc, "om_postprocess")
-        counts = out_count.cpu().tolist()          # the one host sync of the batch
+        return out_bbox, out_cls, out_mask, out_count, out_keep, (bboxes, oriens)     # keep the inputs alive
+
+    def collect(self, outs):
+        """The one host synchronisation of the batch: read the per-image counts, slice the outputs."""
+        out_bbox, out_cls, out_mask, out_count, out_keep = outs[:5]
+        counts = out_count.cpu().tolist()
         mask_bool = out_mask.view(torch.bool)
         self.last_keep = [out_keep[b, :k] for b, k in enumerate(counts)]
         return [{"bbox": out_bbox[b, :k], "mask": mask_bool[b, :k], "cls": out_cls[b, :k]}

@@ -1,0 +1,50 @@
+"""hipGraph capture of the hot path (forward + postprocess kernels) for a fixed input shape.
+
+Capture goes through torch's stream capture (`torch.cuda.CUDAGraph`), which records every kernel the C ABI
+launches on the capturing stream.  The library is capture-safe: no allocation, no synchronisation, no memcpy and
+no memset on the hot path -- counters are cleared by a kernel (`launch_zero_words`), because a captured
+`hipMemsetAsync` node left part of its range uncleared when the graph was replayed (ROCm 7.2; DESIGN.md "hipGraph").
+
+    pipe = GraphedPipeline(model, postprocess, example_input)     # warms up, then captures
+    detections = pipe(image)                                      # copy-in, one graph launch, one D2H of the counts
+
+The tensors in `detections` are views of graph-owned buffers: the next call overwrites them (clone to keep).
+
+Measured on MI355X (tools/graph_bench.py) replay and eager take the same time at every batch size
+(B=1 5.25 ms, B=4 7.55 ms, B=32 34.2 ms): the ~130 launches are issued far ahead of the GPU, so the step is
+GPU-bound even at B=1 and the graph only removes host work (useful when the host thread is busy with decoding).
+The reference has no equivalent (it runs eager torch ops); results are bit-identical to the eager call sequence
+`postprocess(model(image))` (tests/test_hip_parity.py::test_graphed_pipeline_matches_eager).
+"""
+import torch
+
+
+class GraphedPipeline:
+    def __init__(self, model, postprocess, example_input, warmup=3):
+        if not example_input.is_cuda:
+            raise RuntimeError("GraphedPipeline needs a CUDA example input (no CPU fallback)")
+        self.model = model.eval()
+        self.post = postprocess
+        self.static_in = example_input.detach().clone().contiguous()
+        dev = self.static_in.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):                       # allocates workspaces and packed weights outside the capture
+                self._launch()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self._launch()
+
+    def _launch(self):
+        pred = self.model(self.static_in)
+        self._outs = self.post.launch(pred)               # kernels only: no host synchronisation
+
+    def __call__(self, image):
+        if image.shape != self.static_in.shape:
+            raise ValueError("captured for shape %s, got %s" % (tuple(self.static_in.shape), tuple(image.shape)))
+        self.static_in.copy_(image, non_blocking=True)
+        self.graph.replay()
+        return self.post.collect(self._outs)

@@ -519,3 +519,28 @@ def test_coco_formatter_end_to_end(dev):
             assert s["segmentation"] == {"size": [info["height"], info["width"]],
                                          "counts": R.rle_to_string(R.rle_counts(seg[k]))}
             i += 1
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_graphed_pipeline_matches_eager(dev, batch):
+    """hipGraph replay of forward + postprocess == the eager call sequence, bit for bit.  Replays run back to back
+    on fresh inputs with no eager call on the same workspaces in between (an eager call re-clears the tile-queue
+    tickets and the radix histograms, which once hid a replay that did not), and the eager side is a second
+    model / postprocess instance."""
+    from orienmask_amd.graph import GraphedPipeline
+    sd = synth.synth_state_dict(3, obj_bias=-16.0, head_gain=4.0)
+    net, net_ref = _hip_model(sd, dev), _hip_model(sd, dev)
+    post, post_ref = _hip_post((544, 544), dev), _hip_post((544, 544), dev)
+    xs = [synth.synth_image_batch(801 + i, batch, 544, 544).to(dev) for i in range(3)]
+    pipe = GraphedPipeline(net, post, xs[0])
+    got = []
+    for x in (xs[0], xs[1], xs[2], xs[1]):
+        got.append([{k: v.clone() for k, v in d.items()} for d in pipe(x)])
+    for x, g_list in zip((xs[0], xs[1], xs[2], xs[1]), got):
+        with torch.no_grad():
+            want = post_ref(net_ref(x))
+        assert len(g_list) == len(want) == batch
+        for g, w in zip(g_list, want):
+            assert torch.equal(g["bbox"], w["bbox"]) and torch.equal(g["cls"], w["cls"]) and torch.equal(g["mask"], w["mask"])
+    with pytest.raises(ValueError):
+        pipe(torch.zeros(batch + 1, 3, 544, 544, device=dev))
