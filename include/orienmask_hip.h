@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OM_VERSION 100          /* 0.1.0 */
+#define OM_VERSION 110          /* 0.1.1: fp16-activation path (om_*_f16), om_layer_info.w16_off */
 
 #define OM_OK 0
 #define OM_EINVAL (-1)          /* bad argument (null pointer, shape not supported) */
@@ -56,6 +56,9 @@ typedef struct om_layer_info {
     int64_t w_off, scale_off, shift_off;
     int64_t wino_off;           /* >= 0: Winograd F(2x2,3x3) weights U = G g G^T, [16][cout_pad][cin], for the
                                    stride-1 3x3 layers; -1: none */
+    int64_t w16_off;            /* fp16 path: offset IN HALFS into the fp16 weight blob (om_model_load_weights_f16):
+                                   [cout_pad][ksize*ksize][cin] fp16, or, when cin == 32, [cout_pad][(k*k+1)/2][64]
+                                   (two taps per 64-half row, the odd last tap zero); -1: the stem (always fp32) */
 } om_layer_info;
 
 /* Constants of OrienMaskYOLOPostProcess.__init__ (eval/orienmask_yolo_postprocess.py:9-37). */
@@ -99,6 +102,20 @@ size_t om_forward_workspace_bytes(const om_model* m, int B, int H, int W);
 int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, float* bbox16, float* bbox8,
                float* oriens, void* workspace, size_t ws_bytes, om_stream stream);
 
+/* ---- fp16 activations, fp32 accumulate (BASELINE.json configs[4]; no reduced-precision path exists in the
+ * reference -- the arithmetic is defined by oracle/orienmask_ref.py:forward_f16) -------------------------------
+ * Activations between layers and the convolution weights are IEEE fp16; sums, BatchNorm scale/shift, LeakyReLU and the
+ * residual add are fp32, rounded once per layer at the store; the stem reads the fp32 image; the four head tensors are
+ * written fp32 exactly as om_forward writes them.  Needs BOTH blobs: om_model_load_weights (scale/shift, stem) and
+ * om_model_load_weights_f16 (the fp16 weights laid out per om_layer_info.w16_off, om_model_weight_halfs() halfs). */
+size_t om_model_weight_halfs(const om_model* m);
+int om_model_load_weights_f16(om_model* m, const void* packed_f16_dev, size_t bytes);
+size_t om_forward_f16_workspace_bytes(const om_model* m, int B, int H, int W);
+int om_forward_f16(om_model* m, const float* x, int B, int H, int W, float* bbox32, float* bbox16, float* bbox8,
+                   float* oriens, void* workspace, size_t ws_bytes, om_stream stream);
+/* tile of conv_igemm_f16_kernel<bm,bn> that runs layer `index` (0 x 0: stem) */
+int om_layer_tile_f16(const om_model* m, int index, int B, int H, int W, int* bm, int* bn);
+
 /* ---- measurement: per-layer durations with HIP events on the stream om_forward launches on
  * (the reference measures with torch.cuda.Event pairs, utils/timer.py:70-82).  While enabled, every
  * om_forward records events around every kernel of every layer; om_profile_read synchronises on them and
@@ -126,6 +143,13 @@ int om_conv2d_winograd(const float* in, int B, int H, int W, int cin, int in_pix
                        const float* scale, const float* shift, int cout, int leaky, const float* res,
                        int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
                        om_stream stream);
+/* fp16 layer (unit-test entry): in/res/w fp16 (w laid out as om_layer_info.w16_off describes), scale/shift fp32,
+ * out fp16 NHWC, or fp32 NHWC when out_f32 = 1; pixel strides in elements of the respective type. */
+int om_conv2d_f16(const void* in, int B, int H, int W, int cin, int in_pix_stride, const void* w, const float* scale,
+                  const float* shift, int cout, int ksize, int stride, int leaky, const void* res, int res_pix_stride,
+                  void* out, int out_pix_stride, int out_f32, om_stream stream);
+int om_conv2d_stem_f16(const float* in, int B, int H, int W, const float* w, const float* scale, const float* shift,
+                       int cout, void* out, om_stream stream);
 /* first layer: in [B,3,H,W] NCHW -> out [B,H,W,cout] NHWC, 3x3 stride 1. */
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale,
                    const float* shift, int cout, float* out, om_stream stream);

@@ -31,21 +31,46 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # --------------------------------------------------------------------------------------
 
 
-def _cbl(sd, name, x, stride=1):
-    """conv(bias=False) -> BatchNorm2d(eval, eps=1e-5) -> LeakyReLU(0.1).
-    /root/reference/model/base.py:104-137 (ConvBNRelu), :278-279 (conv_bn_leaky)."""
+_MODE = {"f16": False}     # True inside forward_f16(): fp16 activations and weights, fp32 accumulate
+
+
+def _r16(t):
+    """Round to the nearest IEEE fp16 value, keep float32 storage (saturating like the device store would not:
+    values beyond 65504 become inf, exactly what a fp16 store does)."""
+    return t.half().float()
+
+
+def _cbl(sd, name, x, stride=1, res=None):
+    """conv(bias=False) -> BatchNorm2d(eval, eps=1e-5) -> LeakyReLU(0.1) (+ residual).
+    /root/reference/model/base.py:104-137 (ConvBNRelu), :278-279 (conv_bn_leaky); the residual add is
+    /root/reference/model/backbone/darknet.py:14-15 (x + conv(x), commutative in IEEE arithmetic).
+
+    fp16 mode (no reference counterpart; defines what om_forward_f16 computes): the input holds fp16 values, the
+    weights are rounded to fp16 (not for the stem, which reads the fp32 image), the sum is fp32, BatchNorm is the
+    folded fp32 scale/shift of orienmask_amd/pack.py, LeakyReLU and the residual add are fp32, one rounding to fp16."""
     w = sd[name + ".conv_block.0.weight"]
-    x = F.conv2d(x, w, None, stride, w.shape[-1] // 2)
     p = name + ".conv_block.1."
+    if _MODE["f16"]:
+        if name != "backbone.conv1":
+            w = _r16(w)
+        y = F.conv2d(x, w, None, stride, w.shape[-1] // 2)
+        scale = (sd[p + "weight"].double() / torch.sqrt(sd[p + "running_var"].double() + 1e-5))
+        shift = (sd[p + "bias"].double() - sd[p + "running_mean"].double() * scale).float()
+        y = y * scale.float().view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        y = F.leaky_relu(y, 0.1)
+        return _r16(y if res is None else y + res)
+    x = F.conv2d(x, w, None, stride, w.shape[-1] // 2)
     x = F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"],
                      sd[p + "bias"], False, 0.1, 1e-5)
-    return F.leaky_relu(x, 0.1)
+    x = F.leaky_relu(x, 0.1)
+    return x if res is None else res + x
 
 
 def _plain(sd, name, x):
     """Final 1x1 conv of a head: bias, no BN, no activation.
-    /root/reference/model/orienmask_yolo_fpnplus.py:60,71."""
-    return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"])
+    /root/reference/model/orienmask_yolo_fpnplus.py:60,71.  fp16 mode: fp16 weights, fp32 sum + bias, fp32 result."""
+    w = sd[name + ".weight"]
+    return F.conv2d(x, _r16(w) if _MODE["f16"] else w, sd[name + ".bias"])
 
 
 def _stage(sd, idx, x, nblocks):
@@ -55,8 +80,7 @@ def _stage(sd, idx, x, nblocks):
     x = _cbl(sd, p + ".0", x, stride=2)
     for j in range(1, nblocks + 1):
         y = _cbl(sd, "%s.%d.conv.0" % (p, j), x)
-        y = _cbl(sd, "%s.%d.conv.1" % (p, j), y)
-        x = x + y
+        x = _cbl(sd, "%s.%d.conv.1" % (p, j), y, res=x)
     return x
 
 
@@ -102,6 +126,19 @@ def forward(sd, x, num_anchors=3, return_features=False):
     if return_features:
         return out, dict(x32=x32, x16=x16, x8=x8, x4=x4, neck32=n32, neck16=n16, neck8=n8, oriens=o)
     return out
+
+
+def forward_f16(sd, x, num_anchors=3, return_features=False, model="OrienMaskYOLOFPNPlus"):
+    """The fp16-activation configuration (BASELINE.json configs[4], SURVEY.md 8d "Config 5"): the same graph with
+    every activation and convolution weight rounded to fp16 and fp32 accumulation (see _cbl).  The reference has no
+    such path, so this function is a PORT-level definition, not a pinned restatement: "parity unpinned" for fp16."""
+    _MODE["f16"] = True
+    try:
+        if model == "OrienMaskYOLO":
+            return forward_yolo(sd, x, num_anchors)
+        return forward(sd, x, num_anchors, return_features)
+    finally:
+        _MODE["f16"] = False
 
 
 def forward_yolo(sd, x, num_anchors=3):

@@ -19,9 +19,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int STEM_TX = 32, STEM_TY = 8, STEM_CO = 32;
 
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// OutT = float: the f32 path; OutT = _Float16: the fp16-activation path (same arithmetic, rounded once at the store)
+template <typename OutT>
 __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                         const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, float* __restrict__ out,
+                                                        const float* __restrict__ shift, OutT* __restrict__ out,
                                                         int H, int W) {
     __shared__ float patch[3][STEM_TY + 2][STEM_TX + 2];
     const int tid = threadIdx.x;
@@ -72,8 +76,15 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
             o[k] = v > 0.f ? v : v * 0.1f;
         }
         const int gy = y0 + ty, gx = x0 + px;
-        if (gy < H && gx < W)
-            *reinterpret_cast<f32x4*>(out + (((size_t)b * H + gy) * W + gx) * STEM_CO + quad * 4) = o;
+        if (gy < H && gx < W) {
+            OutT* dst = out + (((size_t)b * H + gy) * W + gx) * STEM_CO + quad * 4;
+            if constexpr (sizeof(OutT) == 4) {
+                *reinterpret_cast<f32x4*>(dst) = o;
+            } else {
+                const f16x4 h = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+                *reinterpret_cast<f16x4*>(dst) = h;
+            }
+        }
     }
 }
 
@@ -97,7 +108,19 @@ int launch_conv_stem(const float* in_nchw, int B, int H, int W, const float* w, 
     OM_REQUIRE(cout == STEM_CO, OM_EINVAL, "stem: cout=%d, only 32 supported", cout);
     OM_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0, OM_EINVAL, "stem: bad shape B=%d H=%d W=%d", B, H, W);
     dim3 grid((W + STEM_TX - 1) / STEM_TX, (H + STEM_TY - 1) / STEM_TY, B);
-    hipLaunchKernelGGL(conv_stem_kernel, grid, dim3(256), 0, stream, in_nchw, w, scale, shift, out_nhwc, H, W);
+    hipLaunchKernelGGL(conv_stem_kernel<float>, grid, dim3(256), 0, stream, in_nchw, w, scale, shift, out_nhwc, H, W);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
+int launch_conv_stem_f16(const float* in_nchw, int B, int H, int W, const float* w, const float* scale,
+                         const float* shift, int cout, void* out_nhwc_f16, hipStream_t stream) {
+    OM_REQUIRE(in_nchw && w && scale && shift && out_nhwc_f16, OM_EINVAL, "stem: null pointer");
+    OM_REQUIRE(cout == STEM_CO, OM_EINVAL, "stem: cout=%d, only 32 supported", cout);
+    OM_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0, OM_EINVAL, "stem: bad shape B=%d H=%d W=%d", B, H, W);
+    dim3 grid((W + STEM_TX - 1) / STEM_TX, (H + STEM_TY - 1) / STEM_TY, B);
+    hipLaunchKernelGGL(conv_stem_kernel<_Float16>, grid, dim3(256), 0, stream, in_nchw, w, scale, shift,
+                       static_cast<_Float16*>(out_nhwc_f16), H, W);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }

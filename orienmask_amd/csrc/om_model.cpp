@@ -62,6 +62,8 @@ struct om_model {
     std::vector<om::LayerDef> layers;
     size_t weight_floats = 0;
     const float* weights = nullptr;
+    size_t weight_halfs = 0;             // fp16 copy of the convolution weights (om_model_load_weights_f16)
+    const _Float16* weights16 = nullptr;
     // optional per-layer timing with HIP events on the launch stream (om_profile_*)
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;     // 3 events per (recorded forward, layer): start, mid, stop
@@ -92,6 +94,11 @@ struct om_model {
             weight_floats = om::align_up(weight_floats, 4);
             L.info.wino_off = (int64_t)weight_floats;
             weight_floats += (size_t)16 * L.info.cout_pad * cin;
+        }
+        L.info.w16_off = -1;
+        if (!stem) {
+            L.info.w16_off = (int64_t)weight_halfs;
+            weight_halfs = om::align_up(weight_halfs + om::conv_f16_weight_halfs(L.info.cout_pad, ks, cin), 8);
         }
         L.in = in; L.out = out; L.in_div = in_div; L.out_mode = out_mode; L.up = up; L.stem = stem;
         if (res) { L.res = *res; L.has_res = true; }
@@ -257,47 +264,54 @@ int om_model_load_weights(om_model* m, const void* packed_dev, size_t bytes, int
     return OM_OK;
 }
 
-size_t om_forward_workspace_bytes(const om_model* m, int B, int H, int W) {
+static size_t forward_workspace_bytes(const om_model* m, int B, int H, int W, bool f16) {
     if (!m || B <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32) return 0;
+    const size_t esz = f16 ? 2 : 4;
     size_t total = 0;
-    for (size_t i = 0; i < m->bufs.size(); ++i) total += om::align_up(m->buf_floats((int)i, B, H, W) * sizeof(float), 256);
+    for (size_t i = 0; i < m->bufs.size(); ++i) total += om::align_up(m->buf_floats((int)i, B, H, W) * esz, 256);
     total += om::align_up(m->layers.size() * sizeof(int), 256);      // one tile-queue ticket per layer
-    total += om::align_up(m->wino_floats(B, H, W) * sizeof(float), 256);   // Winograd transformed-input scratch
+    if (!f16) total += om::align_up(m->wino_floats(B, H, W) * sizeof(float), 256);   // Winograd transformed-input scratch
     return total;
 }
 
-int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, float* bbox16, float* bbox8,
-               float* oriens, void* workspace, size_t ws_bytes, om_stream stream_) {
+size_t om_forward_workspace_bytes(const om_model* m, int B, int H, int W) { return forward_workspace_bytes(m, B, H, W, false); }
+size_t om_forward_f16_workspace_bytes(const om_model* m, int B, int H, int W) { return forward_workspace_bytes(m, B, H, W, true); }
+
+static int forward_impl(om_model* m, const float* x, int B, int H, int W, float* bbox32, float* bbox16, float* bbox8,
+                        float* oriens, void* workspace, size_t ws_bytes, om_stream stream_, bool f16) {
     OM_REQUIRE(m && x && bbox32 && bbox16 && bbox8 && oriens && workspace, OM_EINVAL, "om_forward: null argument");
     OM_REQUIRE(m->weights, OM_ESTATE, "om_forward: call om_model_load_weights first");
+    OM_REQUIRE(!f16 || m->weights16, OM_ESTATE, "om_forward_f16: call om_model_load_weights_f16 first");
     OM_REQUIRE(B > 0 && H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, OM_EINVAL,
                "om_forward: B=%d H=%d W=%d (H and W must be positive multiples of 32)", B, H, W);
-    OM_REQUIRE(ws_bytes >= om_forward_workspace_bytes(m, B, H, W), OM_ENOMEM,
-               "om_forward: workspace %zu bytes < %zu needed", ws_bytes, om_forward_workspace_bytes(m, B, H, W));
+    const size_t need = forward_workspace_bytes(m, B, H, W, f16);
+    OM_REQUIRE(ws_bytes >= need, OM_ENOMEM, "om_forward: workspace %zu bytes < %zu needed", ws_bytes, need);
     OM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, OM_EINVAL, "om_forward: workspace not 256-byte aligned");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const size_t esz = f16 ? 2 : 4;
 
-    std::vector<float*> base(m->bufs.size());
+    std::vector<char*> base(m->bufs.size());
     int* tickets = nullptr;
     float* wino_scratch = nullptr;
     {
         char* p = static_cast<char*>(workspace);
         for (size_t i = 0; i < m->bufs.size(); ++i) {
-            base[i] = reinterpret_cast<float*>(p);
-            p += om::align_up(m->buf_floats((int)i, B, H, W) * sizeof(float), 256);
+            base[i] = p;
+            p += om::align_up(m->buf_floats((int)i, B, H, W) * esz, 256);
         }
         tickets = reinterpret_cast<int*>(p);
         p += om::align_up(m->layers.size() * sizeof(int), 256);
         wino_scratch = reinterpret_cast<float*>(p);
     }
     if (int rc = om::launch_zero_words(tickets, m->layers.size(), stream)) return rc;
-    auto ptr_of = [&](const om::View& v) -> float* {
+    // element pointer of a view: workspace buffers hold esz-byte elements, the four outputs are always fp32
+    auto ptr_of = [&](const om::View& v) -> void* {
         switch (v.buf) {
             case om::BUF_BBOX32: return bbox32;
             case om::BUF_BBOX16: return bbox16;
             case om::BUF_BBOX8: return bbox8;
             case om::BUF_ORIENS: return oriens;
-            default: return base[v.buf] + v.ch_off;
+            default: return base[v.buf] + (size_t)v.ch_off * esz;
         }
     };
 
@@ -327,29 +341,48 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
         const int Hin = H / L.in_div, Win = W / L.in_div;
         if (L.stem) {
             if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
-            int rc = om::launch_conv_stem(x, B, Hin, Win, w, scale, shift, li.cout, ptr_of(L.out), stream);
+            int rc = f16 ? om::launch_conv_stem_f16(x, B, Hin, Win, w, scale, shift, li.cout, ptr_of(L.out), stream)
+                         : om::launch_conv_stem(x, B, Hin, Win, w, scale, shift, li.cout,
+                                                static_cast<float*>(ptr_of(L.out)), stream);
             if (rc != OM_OK) return rc;
             continue;
         }
-        om::ConvArgs a;
-        a.in = ptr_of(L.in); a.w = w; a.scale = scale; a.shift = shift;
-        a.res = L.has_res ? ptr_of(L.res) : nullptr;
-        a.out = ptr_of(L.out);
-        a.B = B; a.H = Hin; a.W = Win; a.cin = li.cin; a.in_pix_stride = m->pix_stride(L.in.buf);
-        a.Ho = Hin / li.stride; a.Wo = Win / li.stride; a.cout = li.cout; a.cout_pad = li.cout_pad;
-        a.ks = li.ksize; a.stride = li.stride; a.leaky = li.leaky;
-        a.res_pix_stride = L.has_res ? m->pix_stride(L.res.buf) : 0;
-        a.out_pix_stride = m->pix_stride(L.out.buf);
-        a.out_mode = L.out_mode; a.up = L.up;
-        a.ticket = tickets + (&L - m->layers.data());
         int rc;
-        if (li.wino_off >= 0 && om::wino_enabled()) {
-            a.w = m->weights + li.wino_off;
-            a.mid_event = ev_mid;
-            rc = om::launch_conv_winograd(a, wino_scratch, stream);
+        if (f16) {
+            om::ConvArgsH a;
+            a.in = ptr_of(L.in); a.w = m->weights16 + li.w16_off; a.scale = scale; a.shift = shift;
+            a.res = L.has_res ? ptr_of(L.res) : nullptr;
+            a.out = ptr_of(L.out);
+            a.B = B; a.H = Hin; a.W = Win; a.cin = li.cin; a.in_pix_stride = m->pix_stride(L.in.buf);
+            a.Ho = Hin / li.stride; a.Wo = Win / li.stride; a.cout = li.cout; a.cout_pad = li.cout_pad;
+            a.ks = li.ksize; a.stride = li.stride; a.leaky = li.leaky;
+            a.res_pix_stride = L.has_res ? m->pix_stride(L.res.buf) : 0;
+            a.out_pix_stride = m->pix_stride(L.out.buf);
+            a.out_mode = L.out_mode; a.up = L.up;
+            a.out_f32 = L.out.buf < 0 ? 1 : 0;
+            a.ticket = tickets + (&L - m->layers.data());
+            if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
+            rc = om::launch_conv_igemm_f16(a, stream);
         } else {
-            if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));     // single-kernel layer: mid == start
-            rc = om::launch_conv_igemm(a, stream);
+            om::ConvArgs a;
+            a.in = static_cast<const float*>(ptr_of(L.in)); a.w = w; a.scale = scale; a.shift = shift;
+            a.res = L.has_res ? static_cast<const float*>(ptr_of(L.res)) : nullptr;
+            a.out = static_cast<float*>(ptr_of(L.out));
+            a.B = B; a.H = Hin; a.W = Win; a.cin = li.cin; a.in_pix_stride = m->pix_stride(L.in.buf);
+            a.Ho = Hin / li.stride; a.Wo = Win / li.stride; a.cout = li.cout; a.cout_pad = li.cout_pad;
+            a.ks = li.ksize; a.stride = li.stride; a.leaky = li.leaky;
+            a.res_pix_stride = L.has_res ? m->pix_stride(L.res.buf) : 0;
+            a.out_pix_stride = m->pix_stride(L.out.buf);
+            a.out_mode = L.out_mode; a.up = L.up;
+            a.ticket = tickets + (&L - m->layers.data());
+            if (li.wino_off >= 0 && om::wino_enabled()) {
+                a.w = m->weights + li.wino_off;
+                a.mid_event = ev_mid;
+                rc = om::launch_conv_winograd(a, wino_scratch, stream);
+            } else {
+                if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));     // single-kernel layer: mid == start
+                rc = om::launch_conv_igemm(a, stream);
+            }
         }
         if (rc != OM_OK) {
             char msg[512];
@@ -359,6 +392,37 @@ int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, 
         }
     }
     if (m->profiling) ++m->prof_forwards;
+    return OM_OK;
+}
+
+int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, float* bbox16, float* bbox8,
+               float* oriens, void* workspace, size_t ws_bytes, om_stream stream) {
+    return forward_impl(m, x, B, H, W, bbox32, bbox16, bbox8, oriens, workspace, ws_bytes, stream, false);
+}
+
+int om_forward_f16(om_model* m, const float* x, int B, int H, int W, float* bbox32, float* bbox16, float* bbox8,
+                   float* oriens, void* workspace, size_t ws_bytes, om_stream stream) {
+    return forward_impl(m, x, B, H, W, bbox32, bbox16, bbox8, oriens, workspace, ws_bytes, stream, true);
+}
+
+size_t om_model_weight_halfs(const om_model* m) { return m ? m->weight_halfs : 0; }
+
+int om_model_load_weights_f16(om_model* m, const void* packed_f16_dev, size_t bytes) {
+    OM_REQUIRE(m && packed_f16_dev, OM_EINVAL, "om_model_load_weights_f16: null argument");
+    OM_REQUIRE(bytes == m->weight_halfs * 2, OM_EINVAL, "om_model_load_weights_f16: blob is %zu bytes, the graph needs %zu",
+               bytes, m->weight_halfs * 2);
+    OM_REQUIRE((reinterpret_cast<uintptr_t>(packed_f16_dev) & 15) == 0, OM_EINVAL, "om_model_load_weights_f16: blob not 16-byte aligned");
+    m->weights16 = static_cast<const _Float16*>(packed_f16_dev);
+    return OM_OK;
+}
+
+int om_layer_tile_f16(const om_model* m, int index, int B, int H, int W, int* bm, int* bn) {
+    OM_REQUIRE(m && bm && bn, OM_EINVAL, "om_layer_tile_f16: null argument");
+    OM_REQUIRE(index >= 0 && index < (int)m->layers.size(), OM_EINVAL, "om_layer_tile_f16: index %d", index);
+    const om::LayerDef& L = m->layers[index];
+    if (L.stem) { *bm = 0; *bn = 0; return OM_OK; }
+    const int Ho = H / L.in_div / L.info.stride, Wo = W / L.in_div / L.info.stride;
+    om::conv_tile_for_f16(B * Ho * Wo, L.info.cout_pad, L.info.cin, bm, bn);
     return OM_OK;
 }
 
@@ -453,6 +517,29 @@ int om_conv2d_winograd(const float* in, int B, int H, int W, int cin, int in_pix
     if (int rc = om::launch_zero_words(g_ticket, 1, static_cast<hipStream_t>(stream))) return rc;
     a.ticket = g_ticket;
     return om::launch_conv_winograd(a, static_cast<float*>(scratch), static_cast<hipStream_t>(stream));
+}
+
+int om_conv2d_f16(const void* in, int B, int H, int W, int cin, int in_pix_stride, const void* w, const float* scale,
+                  const float* shift, int cout, int ksize, int stride, int leaky, const void* res, int res_pix_stride,
+                  void* out, int out_pix_stride, int out_f32, om_stream stream) {
+    OM_REQUIRE(B > 0 && H > 0 && W > 0 && stride >= 1 && H % stride == 0 && W % stride == 0, OM_EINVAL,
+               "om_conv2d_f16: bad shape");
+    om::ConvArgsH a;
+    a.in = in; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.cin = cin; a.in_pix_stride = in_pix_stride;
+    a.Ho = H / stride; a.Wo = W / stride; a.cout = cout; a.cout_pad = om::round_up(cout, 32);
+    a.ks = ksize; a.stride = stride; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
+    a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1; a.out_f32 = out_f32;
+    static int* g_ticket = nullptr;
+    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), 256));
+    if (int rc = om::launch_zero_words(g_ticket, 1, static_cast<hipStream_t>(stream))) return rc;
+    a.ticket = g_ticket;
+    return om::launch_conv_igemm_f16(a, static_cast<hipStream_t>(stream));
+}
+
+int om_conv2d_stem_f16(const float* in, int B, int H, int W, const float* w, const float* scale, const float* shift,
+                       int cout, void* out, om_stream stream) {
+    return om::launch_conv_stem_f16(in, B, H, W, w, scale, shift, cout, out, static_cast<hipStream_t>(stream));
 }
 
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale, const float* shift,

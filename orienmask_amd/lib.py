@@ -19,7 +19,7 @@ class LayerInfo(ctypes.Structure):
                 ("ksize", ctypes.c_int32), ("stride", ctypes.c_int32),
                 ("has_bn", ctypes.c_int32), ("leaky", ctypes.c_int32),
                 ("w_off", ctypes.c_int64), ("scale_off", ctypes.c_int64), ("shift_off", ctypes.c_int64),
-                ("wino_off", ctypes.c_int64)]
+                ("wino_off", ctypes.c_int64), ("w16_off", ctypes.c_int64)]
 
 
 class PostCfg(ctypes.Structure):
@@ -53,6 +53,13 @@ SIGNATURES = {
     "om_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "om_layer_tile": (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                            ctypes.POINTER(ctypes.c_int)]),
+    "om_model_weight_halfs": (_sz, [_vp]),
+    "om_model_load_weights_f16": (_i, [_vp, _vp, _sz]),
+    "om_forward_f16_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "om_forward_f16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "om_layer_tile_f16": (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "om_conv2d_f16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "om_conv2d_stem_f16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "om_conv2d_winograd_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "om_conv2d_winograd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "om_profile_enable": (_i, [_vp, _i]),

@@ -78,6 +78,8 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         self._handle = None
         self._layers = None
         self._packed = None          # device blob currently bound to the handle
+        self._packed16 = None        # fp16 convolution weights (precision == "f16")
+        self.precision = "f32"
         self._packed_device = None
         self._workspace = {}         # (device, B, H, W) -> uint8 tensor
         if pretrained is not None:
@@ -102,6 +104,7 @@ class OrienMaskYOLOFPNPlus(nn.Module):
     def invalidate_packed(self):
         """Call after mutating parameters in place; load_state_dict/.to() do it themselves."""
         self._packed = None
+        self._packed16 = None
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
@@ -122,6 +125,30 @@ class OrienMaskYOLOFPNPlus(nn.Module):
             blob = _pack.pack_state_dict(self.state_dict(), self._layers, total).to(device)
             self.bind_packed(blob)
         return self._packed
+
+    # ------------------------------------------------------------------ fp16-activation configuration
+    def set_precision(self, precision):
+        """'f32' (default; the parity path) or 'f16': fp16 activations and convolution weights, fp32 accumulation,
+        fp32 head tensors (BASELINE.json configs[4]; include/orienmask_hip.h: om_forward_f16)."""
+        if precision not in ("f32", "f16"):
+            raise ValueError("precision must be 'f32' or 'f16', got %r" % (precision,))
+        self.precision = precision
+        return self
+
+    def packed_weights_f16(self, device):
+        h = self._ensure_handle()
+        if self._packed16 is None or self._packed16.device != device:
+            total = _lib.load().om_model_weight_halfs(h)
+            self.bind_packed_f16(_pack.pack_state_dict_f16(self.state_dict(), self._layers, total).to(device))
+        return self._packed16
+
+    def bind_packed_f16(self, blob):
+        h = self._ensure_handle()
+        _lib.require_cuda_tensor(blob, "packed fp16 weights", torch.float16)
+        with torch.cuda.device(blob.device):
+            _lib.check(_lib.load().om_model_load_weights_f16(h, ctypes.c_void_p(blob.data_ptr()), blob.numel() * 2),
+                       "om_model_load_weights_f16")
+        self._packed16 = blob
 
     def bind_packed(self, blob):
         """Bind an already packed device blob (used after an RCCL broadcast of rank 0's blob)."""
@@ -146,11 +173,14 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         dev = x.device
         L = _lib.load()
         self.packed_weights(dev)
+        f16 = self.precision == "f16"
+        if f16:
+            self.packed_weights_f16(dev)
         h = self._handle
-        key = (dev, B, H, W)
+        key = (dev, B, H, W, f16)
         ws = self._workspace.get(key)
         if ws is None:
-            nbytes = L.om_forward_workspace_bytes(h, B, H, W)
+            nbytes = (L.om_forward_f16_workspace_bytes if f16 else L.om_forward_workspace_bytes)(h, B, H, W)
             self._workspace.clear()
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self._workspace[key] = ws
@@ -159,7 +189,7 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         heads = [torch.empty((B, H // s, W // s, HEAD_PIX_STRIDE), dtype=torch.float32, device=dev) for s in (32, 16, 8)]
         oriens = torch.empty((B, 6 * A, H // 4, W // 4), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rc = L.om_forward(h, ctypes.c_void_p(x.data_ptr()), B, H, W,
+            rc = (L.om_forward_f16 if f16 else L.om_forward)(h, ctypes.c_void_p(x.data_ptr()), B, H, W,
                               ctypes.c_void_p(heads[0].data_ptr()), ctypes.c_void_p(heads[1].data_ptr()),
                               ctypes.c_void_p(heads[2].data_ptr()), ctypes.c_void_p(oriens.data_ptr()),
                               ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream_ptr(dev))
@@ -178,6 +208,14 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         'conv_igemm_f32_kernel<BM,BN>' (graph order)."""
         h = self._ensure_handle()
         out = []
+        if self.precision == "f16":
+            for i, l in enumerate(self._layers):
+                bm, bn = ctypes.c_int(0), ctypes.c_int(0)
+                _lib.check(_lib.load().om_layer_tile_f16(h, i, B, H, W, ctypes.byref(bm), ctypes.byref(bn)),
+                           "om_layer_tile_f16")
+                out.append((l["name"], "conv_igemm_f16_kernel<%d,%d>" % (bm.value, bn.value) if bm.value
+                            else "conv_stem_kernel<f16>"))
+            return out
         for i, l in enumerate(self._layers):
             bm, bn, algo = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
             _lib.check(_lib.load().om_layer_tile(h, i, B, H, W, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(algo)),

@@ -29,7 +29,7 @@ def graph_layers(handle):
         out.append(dict(name=info.name.decode(), cin=info.cin, cout=info.cout, cout_pad=info.cout_pad,
                         ksize=info.ksize, stride=info.stride, has_bn=bool(info.has_bn), leaky=bool(info.leaky),
                         w_off=info.w_off, scale_off=info.scale_off, shift_off=info.shift_off,
-                        wino_off=info.wino_off))
+                        wino_off=info.wino_off, w16_off=info.w16_off))
     return out
 
 
@@ -89,4 +89,33 @@ def pack_state_dict(state_dict, layers, total_floats):
         blob[l["shift_off"]:l["shift_off"] + cout] = shift.float()
         if l.get("wino_off", -1) >= 0:
             blob[l["wino_off"]:l["wino_off"] + 16 * cpad * cin] = winograd_weights(w, cpad).reshape(-1)
+    return blob
+
+
+def conv_weights_f16(w, cout_pad):
+    """[cout,cin,k,k] -> fp16 rows of the fp16 path: [cout_pad][k*k][cin], or for cin == 32 two taps per 64-half row,
+    [cout_pad][(k*k+1)/2][64] with the odd last tap zero (include/orienmask_hip.h: om_layer_info.w16_off)."""
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    ohwi = w.detach().float().cpu().permute(0, 2, 3, 1).reshape(cout, k * k, cin)
+    if cin == 32:
+        taps = (k * k + 1) // 2 * 2
+        padded = torch.zeros(cout, taps, cin)
+        padded[:, :k * k] = ohwi
+        ohwi = padded
+    out = torch.zeros(cout_pad, ohwi.shape[1] * cin, dtype=torch.float16)
+    out[:cout] = ohwi.reshape(cout, -1).half()
+    return out
+
+
+def pack_state_dict_f16(state_dict, layers, total_halfs):
+    """CPU float16 tensor of total_halfs elements: the convolution weights of every layer but the stem, rounded to
+    fp16 (scale / shift / the stem stay in the float32 blob of pack_state_dict)."""
+    sd = unwrap_checkpoint(state_dict)
+    blob = torch.zeros(total_halfs, dtype=torch.float16)
+    for l in layers:
+        if l["w16_off"] < 0:
+            continue
+        w = sd[l["name"] + (".conv_block.0.weight" if l["has_bn"] else ".weight")]
+        rows = conv_weights_f16(w, l["cout_pad"]).reshape(-1)
+        blob[l["w16_off"]:l["w16_off"] + rows.numel()] = rows
     return blob

@@ -20,11 +20,11 @@ def test_library_exports_every_declared_symbol(built):
     L = omlib.load()
     for name in declared:
         assert hasattr(L, name)
-    assert L.om_version() == 100
+    assert L.om_version() == 110
 
 
 def test_struct_layouts_match_header(built):
-    assert ctypes.sizeof(omlib.LayerInfo) == 64 + 7 * 4 + 4 + 4 * 8      # 4 bytes of padding before the int64s
+    assert ctypes.sizeof(omlib.LayerInfo) == 64 + 7 * 4 + 4 + 5 * 8      # 4 bytes of padding before the int64s
     assert ctypes.sizeof(omlib.PostCfg) == 4 * (1 + 3 + 3 + 2 + 1 + 9 + 9 + 9 + 1 + 2 + 2 + 1 + 1)
 
 
