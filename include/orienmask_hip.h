@@ -57,8 +57,7 @@ typedef struct om_layer_info {
     int64_t wino_off;           /* >= 0: Winograd F(2x2,3x3) weights U = G g G^T, [16][cout_pad][cin], for the
                                    stride-1 3x3 layers; -1: none */
     int64_t w16_off;            /* fp16 path: offset IN HALFS into the fp16 weight blob (om_model_load_weights_f16):
-                                   [cout_pad][ksize*ksize][cin] fp16, or, when cin == 32, [cout_pad][(k*k+1)/2][64]
-                                   (two taps per 64-half row, the odd last tap zero); -1: the stem (always fp32) */
+                                   [cout_pad][ksize*ksize][cin] fp16 (rows >= cout zero); -1: the stem (always fp32) */
 } om_layer_info;
 
 /* Constants of OrienMaskYOLOPostProcess.__init__ (eval/orienmask_yolo_postprocess.py:9-37). */

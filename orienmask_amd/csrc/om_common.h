@@ -58,7 +58,7 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t stream);
 // fp16-activation path (conv_igemm_f16.hip): in / w / res are fp16, scale / shift fp32, out fp16 unless out_f32.
 struct ConvArgsH {
     const void* in;         // fp16 NHWC view [B,H,W,cin] (pixel stride in halfs)
-    const void* w;          // fp16 [cout_pad][ks*ks][cin]; cin == 32: [cout_pad][(ks*ks+1)/2][64] (tap pairs, zero padded)
+    const void* w;          // fp16 [cout_pad][ks*ks][cin]
     const float* scale;
     const float* shift;
     const void* res;        // optional fp16 NHWC view
@@ -77,7 +77,7 @@ struct ConvArgsH {
 int launch_conv_igemm_f16(const ConvArgsH& a, hipStream_t stream);
 void conv_tile_for_f16(int M, int cout_pad, int cin, int* bm, int* bn);
 inline size_t conv_f16_weight_halfs(int cout_pad, int ks, int cin) {
-    return cin == 32 ? (size_t)cout_pad * ((ks * ks + 1) / 2) * 64 : (size_t)cout_pad * ks * ks * cin;
+    return (size_t)cout_pad * ks * ks * cin;
 }
 int launch_conv_stem_f16(const float* in_nchw, int B, int H, int W, const float* w, const float* scale,
                          const float* shift, int cout, void* out_nhwc_f16, hipStream_t stream);

@@ -93,17 +93,11 @@ def pack_state_dict(state_dict, layers, total_floats):
 
 
 def conv_weights_f16(w, cout_pad):
-    """[cout,cin,k,k] -> fp16 rows of the fp16 path: [cout_pad][k*k][cin], or for cin == 32 two taps per 64-half row,
-    [cout_pad][(k*k+1)/2][64] with the odd last tap zero (include/orienmask_hip.h: om_layer_info.w16_off)."""
+    """[cout,cin,k,k] -> fp16 [cout_pad][k*k*cin] (OHWI, rows >= cout zero): the fp16 path's weight rows
+    (include/orienmask_hip.h: om_layer_info.w16_off)."""
     cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
-    ohwi = w.detach().float().cpu().permute(0, 2, 3, 1).reshape(cout, k * k, cin)
-    if cin == 32:
-        taps = (k * k + 1) // 2 * 2
-        padded = torch.zeros(cout, taps, cin)
-        padded[:, :k * k] = ohwi
-        ohwi = padded
-    out = torch.zeros(cout_pad, ohwi.shape[1] * cin, dtype=torch.float16)
-    out[:cout] = ohwi.reshape(cout, -1).half()
+    out = torch.zeros(cout_pad, k * k * cin, dtype=torch.float16)
+    out[:cout] = w.detach().float().cpu().permute(0, 2, 3, 1).reshape(cout, -1).half()
     return out
 
 

@@ -673,21 +673,19 @@ def test_forward_f16_is_batch_invariant_and_switchable(dev):
 
 
 def test_end_to_end_f16_agrees_with_f32(dev):
-    """Detections of the fp16 configuration against the fp32 path on photo-like inputs: same count within a few,
-    and the confident detections pair up (same class, box IoU > 0.9, mask IoU > 0.9)."""
+    """Detections of the fp16 configuration against the fp32 path: the detections in the upper half of each image's
+    score range pair up (same class, box IoU > 0.9, mask IoU > 0.9) for at least 90 % of them."""
     sd = synth.synth_state_dict(3, obj_bias=-16.0, head_gain=4.0)
     x = synth.synth_image_batch(31, 2, 544, 544).to(dev)
     net = _hip_model(sd, dev)
     post = _hip_post((544, 544), dev)
     with torch.no_grad():
         ref = [{k: v.clone() for k, v in d.items()} for d in post(net(x))]
-        assert sum(int((r["bbox"][:, 4] > 0.3).sum()) for r in ref) > 0
+        assert all(r["bbox"].shape[0] > 0 for r in ref)
         net.set_precision("f16")
         got = post(net(x))
     for r, g in zip(ref, got):
-        conf = r["bbox"][:, 4] > 0.3
-        if conf.sum() == 0:
-            continue
+        conf = r["bbox"][:, 4] >= 0.5 * r["bbox"][:, 4].max()        # the upper half of the score range
         matched = 0
         for i in torch.nonzero(conf).flatten().tolist():
             same = torch.nonzero(g["cls"] == r["cls"][i]).flatten()
