@@ -33,6 +33,7 @@ import torch  # noqa: E402
 ANCHORS_YOLOV4 = [[12, 16], [19, 36], [40, 28], [36, 75], [76, 55], [72, 146], [142, 110], [192, 243], [459, 401]]
 ANCHOR_MASK = [[6, 7, 8], [3, 4, 5], [0, 1, 2]]
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_F16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 WEIGHT_SEED, OBJ_BIAS, HEAD_GAIN = 3, -16.0, 4.0
 
@@ -43,21 +44,22 @@ def post_config(h, w):
                 nms_pre=400, nms_post=100, orien_thresh=0.3)
 
 
-def cpu_baseline(sd, x_cpu, target_seconds=12.0):
+def cpu_baseline(sd, x_cpu, target_seconds=12.0, f16=False):
     """Oracle forward + postprocess on the host cores; bounded sample of the same workload."""
     from oracle import orienmask_ref as R
+    fwd = R.forward_f16 if f16 else R.forward
     h, w = x_cpu.shape[2], x_cpu.shape[3]
     pc = post_config(h, w)
     post = R.PostProcessOracle(pc["grid_size"], pc["image_size"], pc["anchors"], pc["anchor_mask"], 80,
                                conf_thresh=pc["conf_thresh"])
     cores = torch.get_num_threads()
     sample = x_cpu[:2]
-    post(R.forward(sd, sample[:1]))                                # warm-up
+    post(fwd(sd, sample[:1]))                                      # warm-up
     t0 = time.perf_counter()
     n_img = 0
     reps = 0
     while True:
-        post(R.forward(sd, sample))
+        post(fwd(sd, sample))
         n_img += sample.shape[0]
         reps += 1
         if time.perf_counter() - t0 >= target_seconds or reps >= 20:
@@ -114,6 +116,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the preprocess / COCO-format side measurements")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
+    ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
+                    help="f32: the parity path and the headline metric (default).  f16: BASELINE configs[4], fp16 "
+                         "activations and weights with fp32 accumulation -- a separate, clearly labelled line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -135,7 +140,8 @@ def main():
 
     H = W = args.size
     B = args.batch
-    net = OrienMaskYOLOFPNPlus(3, 80).eval()
+    net = OrienMaskYOLOFPNPlus(3, 80).eval().set_precision(args.dtype)
+    f16 = args.dtype == "f16"
     sd = None
     if rank == 0:
         sd = synth.synth_state_dict(WEIGHT_SEED, obj_bias=OBJ_BIAS, head_gain=HEAD_GAIN)
@@ -192,7 +198,8 @@ def main():
             k = kernel_of[name]
             wino = k.startswith("wino")
             # Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36 -> executed = algorithmic / 2.25
-            acc(k, ms / n_fw, wk["flops"], wk["flops"] / 2.25 if wino else wk["flops"], wk["bytes"])
+            # fp16 configuration: every activation and weight element is 2 bytes (the fp32 heads are < 1 % of the bytes)
+            acc(k, ms / n_fw, wk["flops"], wk["flops"] / 2.25 if wino else wk["flops"], wk["bytes"] / (2 if f16 else 1))
             if k.startswith("wino_gemm"):
                 acc("wino_input_kernel", pre / n_fw, 0.0, 0.0, 5.0 * 4 * B * (H // arch.layer_div(specs[name])) ** 2 * specs[name].cin)
         dom = max(kern, key=lambda k: kern[k]["ms"])
@@ -212,21 +219,27 @@ def main():
                                "rocprofv3 --pmc passes of this bench at bs=32 (FETCH_SIZE doubled per MI355X_MICROARCH.md)")
         except Exception:
             pass
-        roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
+        peak_tf = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+        roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak_tf, unit="TFLOP/s",
+                        frac=round(achieved / peak_tf, 4), traffic=None if f16 else traffic,
+                        traffic_source=None if f16 else traffic_src,
                         algorithmic_bytes_per_launch=round(d["bytes"] / d["launches"]),
                         kernel=dom,
                         launches_per_step=d["launches"], avg_launch_ms=round(d["ms"] / d["launches"], 4),
                         kernel_ms_per_step=round(d["ms"], 3),
-                        executed_tflops=round(executed, 2), executed_frac=round(executed / PEAK_F32_MFMA_TFLOPS, 4),
-                        note="achieved counts ALGORITHMIC (direct-convolution) flops; the Winograd F(2x2,3x3) kernels "
-                             "execute 2.25x fewer multiplies, so frac may exceed 1 -- executed_* is what the matrix "
-                             "pipe actually ran (exact fp32 MFMA)",
+                        executed_tflops=round(executed, 2), executed_frac=round(executed / peak_tf, 4),
+                        note=("fp16 operands, fp32 accumulate on v_mfma_f32_32x32x16_f16 (dense peak 2.5 PFLOP/s); direct "
+                              "convolution, executed = algorithmic") if f16 else
+                             ("achieved counts ALGORITHMIC (direct-convolution) flops; the Winograd F(2x2,3x3) kernels "
+                              "execute 2.25x fewer multiplies, so frac may exceed 1 -- executed_* is what the matrix "
+                              "pipe actually ran (exact fp32 MFMA)"),
                         forward_kernels_ms_per_step=round(fwd_ms, 3), postprocess_ms_per_step=round(post_ms, 3),
                         forward_tflops=round(total_flops / (fwd_ms * 1e-3) / 1e12, 2),
                         forward_hbm_algorithmic_gbs=round(total_bytes / (fwd_ms * 1e-3) / 1e9, 1),
                         forward_hbm_frac=round(total_bytes / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                        binding="fp32 FLOPs on the f32-input matrix cores; the HBM bound is several x further away")
+                        binding=("fp16: matrix pipe and HBM are within 2x of each other (SURVEY.md 8d); forward_hbm_frac is the "
+                                 "north_star's HBM-roofline figure") if f16 else
+                                "fp32 FLOPs on the f32-input matrix cores; the HBM bound is several x further away")
         if args.layers:
             for name, ms, pre in layer_ms:
                 wk = arch.layer_work(specs[name], B, H, W)
@@ -239,10 +252,13 @@ def main():
                     k, t["launches"], t["ms"], t["flops"] / (t["ms"] * 1e-3) / 1e12,
                     t["exec_flops"] / (t["ms"] * 1e-3) / 1e12, t["bytes"] / (t["ms"] * 1e-3) / 1e9), file=sys.stderr)
         total_images = world * B * args.steps
-        line = dict(metric="images/sec end-to-end (544^2, bs=32) forward+postprocess", value=round(total_images / elapsed, 2),
+        metric = "images/sec end-to-end (544^2, bs=32) forward+postprocess"
+        if f16:
+            metric += " [fp16 activations, fp32 accumulate: BASELINE configs[4], NOT the headline fp32 metric]"
+        line = dict(metric=metric, value=round(total_images / elapsed, 2),
                     unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
-                    vs_baseline=None, dtype="f32", data="synthetic",
+                    vs_baseline=None, dtype=args.dtype, data="synthetic",
                     config=dict(workload="OrienMaskYOLOFPNPlus forward + OrienMaskYOLOPostProcess, %d x [3,%d,%d] per GPU "
                                          "(BASELINE configs[2]); seeded random-init weights (seed %d, obj_bias %g, head_gain %g): "
                                          ">400 candidates pass conf_thresh per image, NMS, 100 masks per image"
@@ -253,7 +269,7 @@ def main():
         if not args.no_extras:
             line["extras"] = measure_neighbours(dev, dets, B)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd, x_cpu)
+            line["cpu_baseline"] = cpu_baseline(sd, x_cpu, f16=f16)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

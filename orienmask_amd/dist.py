@@ -25,16 +25,16 @@ def shard_range(n_items, rank, world):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def broadcast_blob(blob, numel, device, src=0):
-    """Broadcast a flat float32 blob from `src`; ranks other than src pass blob=None."""
+def broadcast_blob(blob, numel, device, src=0, dtype=torch.float32):
+    """Broadcast a flat blob (float32, or float16 for the fp16 weights) from `src`; other ranks pass blob=None."""
     import torch.distributed as dist
     rank, world = world_info()
     if rank == src:
-        if blob is None or blob.numel() != numel or blob.dtype != torch.float32:
-            raise ValueError("source rank must provide the %d-float blob" % numel)
+        if blob is None or blob.numel() != numel or blob.dtype != dtype:
+            raise ValueError("source rank must provide the %d-element %s blob" % (numel, dtype))
         blob = blob.to(device).contiguous()
     else:
-        blob = torch.empty(numel, dtype=torch.float32, device=device)
+        blob = torch.empty(numel, dtype=dtype, device=device)
     if world > 1:
         dist.broadcast(blob, src=src)
     return blob
@@ -50,6 +50,10 @@ def broadcast_packed_weights(net, device, src=0):
     blob = _pack.pack_state_dict(net.state_dict(), net._layers, numel) if rank == src else None
     blob = broadcast_blob(blob, numel, device, src)
     net.bind_packed(blob)
+    if getattr(net, "precision", "f32") == "f16":       # the fp16 configuration needs the fp16 weight rows as well
+        n16 = _lib.load().om_model_weight_halfs(h)
+        b16 = _pack.pack_state_dict_f16(net.state_dict(), net._layers, n16) if rank == src else None
+        net.bind_packed_f16(broadcast_blob(b16, n16, device, src, dtype=torch.float16))
     return blob
 
 
