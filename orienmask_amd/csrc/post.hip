@@ -433,24 +433,30 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
 __device__ __forceinline__ float bil_row(float v0, float v1, float w0, float w1) { return fmaf(v0, w0, v1 * w1); }
 
 __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
+    // blockIdx.y = (image, anchor field): the x4 bilinear up-sampling of an anchor's two orientation planes is shared by
+    // every detection of that anchor (9 fields but up to 100 detections per image), so it is evaluated ONCE per block of
+    // pixels and the detections of the field are looped over with only the predicate inside the loop.
     // One thread = a block of 16 x (up to) 4 output pixels that share their two source rows: output rows
     // 4j-2 .. 4j+1 interpolate between source rows j-1 and j (phases 0.125, 0.375, 0.625, 0.875), so the 24 loads
     // and the horizontal taps are done once per block instead of once per row.
-    const int det = blockIdx.y;
-    const int b = det / p.cfg.nms_post, k = det - b * p.cfg.nms_post;
-    if (k >= p.out_count[b]) return;
+    const int nfields = p.cfg.num_scales * p.cfg.anchors_per_scale;
+    const int b = blockIdx.y / nfields, field = blockIdx.y - b * nfields;
+    const int count = p.out_count[b];
+    const float* dpar = p.det_par + (size_t)b * p.cfg.nms_post * 8;
+    // does this image have a detection on this field at all?  (uniform: scalar loads)
+    int first = -1;
+    for (int k = 0; k < count; ++k)
+        if (__float_as_int(dpar[k * 8 + 6]) == field * 2) { first = k; break; }
+    if (first < 0) return;
     const int H = p.cfg.image_h, W = p.cfg.image_w;
     const int groups = W / MASK_PX;
     const int oh = H / 4, ow = W / 4;
     const int item = blockIdx.x * 256 + threadIdx.x;
     if (item >= (oh + 1) * groups) return;
     const int jy = item / groups, g = item - jy * groups;      // source rows jy-1 and jy
-    const float* dp = p.det_par + (size_t)det * 8;
-    const float cx = dp[0], cy = dp[1], tx = dp[2], ty = dp[3], gax = dp[4], gay = dp[5];
-    const int chan = __float_as_int(dp[6]), s = __float_as_int(dp[7]);
+    const int s = field / p.cfg.anchors_per_scale;
     const float nW = (float)p.cfg.grid_w[s], nH = (float)p.cfg.grid_h[s];
-    const int nch = p.cfg.num_scales * p.cfg.anchors_per_scale * 2;
-    const float* px = p.oriens + ((size_t)b * nch + chan) * oh * ow;
+    const float* px = p.oriens + ((size_t)b * nfields * 2 + field * 2) * oh * ow;
     const float* py = px + (size_t)oh * ow;
 
     // source rows (clamped at the borders exactly like torch: src >= 0, i1 = min(i0 + 1, n - 1))
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
         }
     }
     // the (up to) four output rows of this block
-#pragma unroll
+#pragma unroll 1
     for (int q = 0; q < 4; ++q) {
         const int y = 4 * jy - 2 + q;
         if (y < 0 || y >= H) continue;
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
         if (top_edge) wy1 = 0.0f;
         const float wy0 = 1.0f - wy1;
         const float base_y = ((float)y / (float)H) * nH;
-        unsigned packed[4] = {0, 0, 0, 0};
+        float vx[MASK_PX], vy[MASK_PX];
 #pragma unroll
         for (int e = 0; e < MASK_PX; ++e) {
             // top edge (jy == 0): both source rows are row 0 and the second weight is 0, like torch's clamped tap
@@ -509,18 +515,27 @@ __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
             const float bx0 = hx[1][e];
             const float ty0 = top_edge ? hy[1][e] : hy[0][e];
             const float by0 = hy[1][e];
-            const float vx = fmaf(tx0, wy0, bx0 * wy1);
-            const float vy = fmaf(ty0, wy0, by0 * wy1);
-            const int x = g * MASK_PX + e;
-            const float base_x = ((float)x / (float)W) * nW;
-            const float Px = (vx * gax) / 2.0f + base_x;                  // postprocess.py:142-143
-            const float Py = (vy * gay) / 2.0f + base_y;
-            const bool inside = (fabsf(Px - cx) < tx) && (fabsf(Py - cy) < ty);
-            packed[e >> 2] |= (inside ? 1u : 0u) << ((e & 3) * 8);
+            vx[e] = fmaf(tx0, wy0, bx0 * wy1);
+            vy[e] = fmaf(ty0, wy0, by0 * wy1);
         }
-        uint4 o;
-        o.x = packed[0]; o.y = packed[1]; o.z = packed[2]; o.w = packed[3];
-        *reinterpret_cast<uint4*>(p.out_mask + ((size_t)det * H + y) * W + (size_t)g * MASK_PX) = o;
+        for (int k = first; k < count; ++k) {
+            const float* dp = dpar + k * 8;
+            if (__float_as_int(dp[6]) != field * 2) continue;              // uniform
+            const float cx = dp[0], cy = dp[1], tx = dp[2], ty = dp[3], gax = dp[4], gay = dp[5];
+            unsigned packed[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < MASK_PX; ++e) {
+                const int x = g * MASK_PX + e;
+                const float base_x = ((float)x / (float)W) * nW;
+                const float Px = (vx[e] * gax) / 2.0f + base_x;                  // postprocess.py:142-143
+                const float Pyy = (vy[e] * gay) / 2.0f + base_y;
+                const bool inside = (fabsf(Px - cx) < tx) && (fabsf(Pyy - cy) < ty);
+                packed[e >> 2] |= (inside ? 1u : 0u) << ((e & 3) * 8);
+            }
+            uint4 o;
+            o.x = packed[0]; o.y = packed[1]; o.z = packed[2]; o.w = packed[3];
+            *reinterpret_cast<uint4*>(p.out_mask + (((size_t)b * p.cfg.nms_post + k) * H + y) * W + (size_t)g * MASK_PX) = o;
+        }
     }
 }
 
@@ -652,7 +667,8 @@ int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbo
     hipLaunchKernelGGL(om::post_select_kernel, dim3(B), dim3(om::SEL_THREADS), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     const int items = (cfg->image_h / 4 + 1) * (cfg->image_w / om::MASK_PX);
-    hipLaunchKernelGGL(om::post_mask_kernel, dim3((items + 255) / 256, B * cfg->nms_post), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(om::post_mask_kernel, dim3((items + 255) / 256, B * cfg->num_scales * cfg->anchors_per_scale), dim3(256), 0,
+                       stream, p);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }
