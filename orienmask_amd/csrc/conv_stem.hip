@@ -6,8 +6,9 @@
 //
 // K = 27 is too short for the matrix cores and the layer is HBM-bound (reads 12 B, writes
 // 128 B per pixel), so it runs on the vector ALUs:
-//   * workgroup = 32 x 8 output pixels; the 3 x 10 x 34 input patch (zero padded) is staged
-//     in LDS once, coalesced along x from the NCHW planes;
+//   * workgroup = a 32-pixel-wide column of STEM_STRIPS strips of 8 rows; per strip the 3 x 10 x 34 input patch
+//     (zero padded) is staged in LDS, coalesced along x from the NCHW planes; the next strip's patch is fetched
+//     into registers while the current one computes, and the 108 weights per thread are loaded once per column;
 //   * thread = (pixel column, 4 output channels); its 27 x 4 weights live in registers;
 //   * the 8 channel-quads of a pixel are 8 neighbouring lanes, so one wave store writes
 //     8 pixels x 128 B = 1 KiB contiguous NHWC.
@@ -21,6 +22,10 @@ constexpr int STEM_TX = 32, STEM_TY = 8, STEM_CO = 32;
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+constexpr int STEM_STRIPS = 8;      // 8-row strips one workgroup walks down (weights and scale/shift loaded once)
+constexpr int STEM_PATCH = 3 * (STEM_TY + 2) * (STEM_TX + 2);
+constexpr int STEM_LD = (STEM_PATCH + 255) / 256;     // patch elements each thread stages
+
 // OutT = float: the f32 path; OutT = _Float16: the fp16-activation path (same arithmetic, rounded once at the store)
 template <typename OutT>
 __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict__ in, const float* __restrict__ w,
@@ -28,18 +33,34 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
                                                         const float* __restrict__ shift, OutT* __restrict__ out,
                                                         int H, int W) {
     __shared__ float patch[3][STEM_TY + 2][STEM_TX + 2];
+    float* const patch_flat = &patch[0][0][0];
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * STEM_TX, y0 = blockIdx.y * STEM_TY, b = blockIdx.z;
+    const int x0 = blockIdx.x * STEM_TX, b = blockIdx.z;
     const float* img = in + (size_t)b * 3 * H * W;
-    for (int e = tid; e < 3 * (STEM_TY + 2) * (STEM_TX + 2); e += 256) {
-        const int c = e / ((STEM_TY + 2) * (STEM_TX + 2));
-        const int r = e - c * (STEM_TY + 2) * (STEM_TX + 2);
-        const int py = r / (STEM_TX + 2), px = r - py * (STEM_TX + 2);
-        const int gy = y0 + py - 1, gx = x0 + px - 1;
-        float v = 0.f;
-        if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = img[((size_t)c * H + gy) * W + gx];
-        patch[c][py][px] = v;
-    }
+    // the next strip's patch elements travel through registers while the current strip computes
+    float stage[STEM_LD];
+    auto fetch = [&](int y0) {
+#pragma unroll
+        for (int i = 0; i < STEM_LD; ++i) {
+            const int e = tid + i * 256;
+            const int c = e / ((STEM_TY + 2) * (STEM_TX + 2));
+            const int r = e - c * (STEM_TY + 2) * (STEM_TX + 2);
+            const int py = r / (STEM_TX + 2), px = r - py * (STEM_TX + 2);
+            const int gy = y0 + py - 1, gx = x0 + px - 1;
+            float v = 0.f;
+            if (e < STEM_PATCH && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = img[((size_t)c * H + gy) * W + gx];
+            stage[i] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < STEM_LD; ++i) {
+            const int e = tid + i * 256;
+            if (e < STEM_PATCH) patch_flat[e] = stage[i];
+        }
+    };
+    const int strip0 = blockIdx.y * STEM_STRIPS;
+    fetch(strip0 * STEM_TY);
     const int quad = tid & 7, px = tid >> 3;
     // weights [cout][tap=(kh*3+kw)][ci=3] -> this thread's 4 output channels
     f32x4 wr[27];
@@ -52,39 +73,46 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
     }
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + quad * 4);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + quad * 4);
-    __syncthreads();
+    for (int si = 0; si < STEM_STRIPS; ++si) {
+        const int y0 = (strip0 + si) * STEM_TY;
+        if (y0 >= H) break;
+        commit();
+        __syncthreads();
+        if (si + 1 < STEM_STRIPS && y0 + STEM_TY < H) fetch(y0 + STEM_TY);
 #pragma unroll 2
-    for (int ty = 0; ty < STEM_TY; ++ty) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ty = 0; ty < STEM_TY; ++ty) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+            for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
+                for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-                for (int ci = 0; ci < 3; ++ci) {
-                    const float v = patch[ci][ty + kh][px + kw];
-                    const f32x4 ww = wr[(kh * 3 + kw) * 3 + ci];
-                    acc[0] = fmaf(v, ww[0], acc[0]);
-                    acc[1] = fmaf(v, ww[1], acc[1]);
-                    acc[2] = fmaf(v, ww[2], acc[2]);
-                    acc[3] = fmaf(v, ww[3], acc[3]);
+                    for (int ci = 0; ci < 3; ++ci) {
+                        const float v = patch[ci][ty + kh][px + kw];
+                        const f32x4 ww = wr[(kh * 3 + kw) * 3 + ci];
+                        acc[0] = fmaf(v, ww[0], acc[0]);
+                        acc[1] = fmaf(v, ww[1], acc[1]);
+                        acc[2] = fmaf(v, ww[2], acc[2]);
+                        acc[3] = fmaf(v, ww[3], acc[3]);
+                    }
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v = fmaf(acc[k], sc[k], sh[k]);
+                o[k] = v > 0.f ? v : v * 0.1f;
+            }
+            const int gy = y0 + ty, gx = x0 + px;
+            if (gy < H && gx < W) {
+                OutT* dst = out + (((size_t)b * H + gy) * W + gx) * STEM_CO + quad * 4;
+                if constexpr (sizeof(OutT) == 4) {
+                    *reinterpret_cast<f32x4*>(dst) = o;
+                } else {
+                    const f16x4 h = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+                    *reinterpret_cast<f16x4*>(dst) = h;
                 }
-        f32x4 o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float v = fmaf(acc[k], sc[k], sh[k]);
-            o[k] = v > 0.f ? v : v * 0.1f;
-        }
-        const int gy = y0 + ty, gx = x0 + px;
-        if (gy < H && gx < W) {
-            OutT* dst = out + (((size_t)b * H + gy) * W + gx) * STEM_CO + quad * 4;
-            if constexpr (sizeof(OutT) == 4) {
-                *reinterpret_cast<f32x4*>(dst) = o;
-            } else {
-                const f16x4 h = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
-                *reinterpret_cast<f16x4*>(dst) = h;
             }
         }
+        __syncthreads();      // everyone is done with the patch before the next strip overwrites it
     }
 }
 
@@ -107,7 +135,7 @@ int launch_conv_stem(const float* in_nchw, int B, int H, int W, const float* w, 
     OM_REQUIRE(in_nchw && w && scale && shift && out_nhwc, OM_EINVAL, "stem: null pointer");
     OM_REQUIRE(cout == STEM_CO, OM_EINVAL, "stem: cout=%d, only 32 supported", cout);
     OM_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0, OM_EINVAL, "stem: bad shape B=%d H=%d W=%d", B, H, W);
-    dim3 grid((W + STEM_TX - 1) / STEM_TX, (H + STEM_TY - 1) / STEM_TY, B);
+    dim3 grid((W + STEM_TX - 1) / STEM_TX, (H + STEM_TY * STEM_STRIPS - 1) / (STEM_TY * STEM_STRIPS), B);
     hipLaunchKernelGGL(conv_stem_kernel<float>, grid, dim3(256), 0, stream, in_nchw, w, scale, shift, out_nhwc, H, W);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
@@ -118,7 +146,7 @@ int launch_conv_stem_f16(const float* in_nchw, int B, int H, int W, const float*
     OM_REQUIRE(in_nchw && w && scale && shift && out_nhwc_f16, OM_EINVAL, "stem: null pointer");
     OM_REQUIRE(cout == STEM_CO, OM_EINVAL, "stem: cout=%d, only 32 supported", cout);
     OM_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0, OM_EINVAL, "stem: bad shape B=%d H=%d W=%d", B, H, W);
-    dim3 grid((W + STEM_TX - 1) / STEM_TX, (H + STEM_TY - 1) / STEM_TY, B);
+    dim3 grid((W + STEM_TX - 1) / STEM_TX, (H + STEM_TY * STEM_STRIPS - 1) / (STEM_TY * STEM_STRIPS), B);
     hipLaunchKernelGGL(conv_stem_kernel<_Float16>, grid, dim3(256), 0, stream, in_nchw, w, scale, shift,
                        static_cast<_Float16*>(out_nhwc_f16), H, W);
     OM_CHECK_HIP(hipGetLastError());
