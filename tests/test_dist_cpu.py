@@ -31,6 +31,11 @@ def _worker(rank, world, port, q):
     got = omd.broadcast_blob(blob, numel, torch.device("cpu"), src=0)
     want = pack.pack_state_dict(synth.synth_state_dict(9), net._layers, numel)
     ok_blob = bool(torch.equal(got, want))
+    # the fp16 weight rows of the fp16-activation configuration travel the same way
+    n16 = omlib.load().om_model_weight_halfs(h)
+    b16 = pack.pack_state_dict_f16(net.state_dict(), net._layers, n16) if rank == 0 else None
+    got16 = omd.broadcast_blob(b16, n16, torch.device("cpu"), src=0, dtype=torch.float16)
+    ok_blob = ok_blob and bool(torch.equal(got16, pack.pack_state_dict_f16(synth.synth_state_dict(9), net._layers, n16)))
     start, stop = omd.shard_range(67, rank, world)
     merged = omd.gather_detections([{"image": i} for i in range(start, stop)])
     q.put((rank, ok_blob, start, stop, [m["image"] for m in merged]))

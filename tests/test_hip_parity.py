@@ -655,6 +655,21 @@ def test_forward_f16_matches_oracle(dev, batch, size):
     print("fp16 forward vs oracle.forward_f16: worst rel err %.3e" % worst)
 
 
+def test_forward_f16_non_plus_model_matches_oracle(dev):
+    """The OrienMaskYOLO graph (variant 1) through the fp16 path."""
+    from orienmask_amd.model import OrienMaskYOLO
+    sd = synth.synth_state_dict(6, obj_bias=-16.0, head_gain=4.0, model="OrienMaskYOLO")
+    x = synth.synth_image_batch(23, 1, 544, 544)
+    net = OrienMaskYOLO(3, 80).eval()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).set_precision("f16")
+    with torch.no_grad():
+        out = net(x.to(dev))
+    want = R.forward_f16(sd, x, model="OrienMaskYOLO")
+    for (gb, go), (wb, wo) in zip(out, want):
+        assert _rel_err(gb.cpu(), wb) < F16_FWD_TOL and _rel_err(go.cpu(), wo) < F16_FWD_TOL
+
+
 def test_forward_f16_is_batch_invariant_and_switchable(dev):
     """Same image alone or inside a batch -> bit-identical heads; switching the precision back gives the f32 results."""
     sd = synth.synth_state_dict(5, obj_bias=-16.0, head_gain=4.0)
