@@ -112,8 +112,9 @@ int om_model_load_weights_f16(om_model* m, const void* packed_f16_dev, size_t by
 size_t om_forward_f16_workspace_bytes(const om_model* m, int B, int H, int W);
 int om_forward_f16(om_model* m, const float* x, int B, int H, int W, float* bbox32, float* bbox16, float* bbox8,
                    float* oriens, void* workspace, size_t ws_bytes, om_stream stream);
-/* tile of conv_igemm_f16_kernel<bm,bn> that runs layer `index` (0 x 0: stem) */
-int om_layer_tile_f16(const om_model* m, int index, int B, int H, int W, int* bm, int* bn);
+/* kernel that runs layer `index` in the fp16 configuration: algo 0 = conv_stem_kernel<f16>, 1 = conv_igemm_f16_kernel<bm,bn>,
+ * 4 = conv3x3_f16_kernel<bm,bn> (stride-1 3x3: the three taps of a kernel row share one LDS copy of the input rows) */
+int om_layer_tile_f16(const om_model* m, int index, int B, int H, int W, int* bm, int* bn, int* algo);
 
 /* ---- measurement: per-layer durations with HIP events on the stream om_forward launches on
  * (the reference measures with torch.cuda.Event pairs, utils/timer.py:70-82).  While enabled, every

@@ -1,0 +1,276 @@
+// 3x3 stride-1 convolution, fp16 activations / fp32 accumulate, with the three horizontal taps of a kernel row sharing
+// ONE copy of the input rows in LDS (the stride-1 3x3 layers are 88 % of the network's FLOPs,
+// /root/reference/model/backbone/darknet.py:9-13, model/orienmask_yolo_fpnplus.py:33-71; arithmetic as
+// conv_igemm_f16.hip: fp16 operands, fp32 sums, one rounding at the store).
+//
+// Why (MI355X): in the generic implicit-GEMM kernel every tap re-fetches the A operand, and measured on the 136^2
+// 128->256 layer the k-loop was bound by the LDS-DMA path (instruction issue and ~9 TB/s of L2->LDS traffic), not by the
+// matrix pipe: with the operand fetches answered with zeros it ran 1.7x faster.  For an M tile of BM consecutive raster
+// pixels the A rows of taps (kh, 0..2) are the same BM+2 input pixels shifted by one, so:
+//   * per (channel chunk, kernel row) ONE "patch" of BM+2 input pixels x 32 channels is DMA'd (BM/64 + 1 pieces instead
+//     of 3 * BM/64) and the three taps read their fragments at row offsets 0, 1, 2;
+//   * zero padding can no longer come from the DMA (a patch row is a valid neighbour for one tap and padding for
+//     another): every lane carries a 9-bit "tap is padding" mask for each of its pixels and ANDs its A fragment with it
+//     (4 v_and per fragment, hidden under the MFMAs);
+//   * the weights stream through a 3-deep ring of per-tap slices (BN rows x 64 B), two steps ahead, as before; the patch
+//     is double buffered and requested during the first two taps of the previous patch; counted vmcnt per tap.
+// LDS: 2 x (BM + 64) + 3 x BN rows of 64 B = 64 KiB for the 256x128 tile (2 workgroups/CU), exactly the fp32 C tile of
+// one wave-row for the epilogue (conv_f16_common.h).
+#include <cstdlib>
+
+#include "conv_f16_common.h"
+
+namespace om {
+
+template <int BM, int BN>
+constexpr int c3_blocks_per_cu() { return BM * BN >= 256 * 128 ? 2 : (BM * BN >= 128 * 128 ? 3 : 4); }
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, (c3_blocks_per_cu<BM, BN>())) void conv3x3_f16_kernel(const IgemmHParams p) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NWN = BN / WN;
+    constexpr int A_CH = BM / 64 + 1;             // patch pieces (64 rows x 64 B each); BM + 2 rows are needed
+    constexpr int P0 = (A_CH + 1) / 2;            // patch pieces requested during tap 0 (the rest during tap 1)
+    constexpr int B_CH = BN / 64;
+    constexpr int PATCH = (BM + 64) * 4;          // f32x4 units per patch buffer
+    constexpr int BSL = BN * 4;                   // f32x4 units per weight slice
+    static_assert((BM / WM) * (BN / WN) == 4, "four waves per workgroup");
+    static_assert(BM % 64 == 0 && BN % 64 == 0, "whole 64-row pieces");
+    static_assert(WM * BN / 4 <= 2 * PATCH + 3 * BSL, "one wave-row of the fp32 C tile must fit in LDS");
+    __shared__ f32x4 smem[2 * PATCH + 3 * BSL + 1];       // ONE LDS object; the last 16 B hold the ticket
+    int* const s_ticket = reinterpret_cast<int*>(smem + 2 * PATCH + 3 * BSL);
+    f32x4* const s_patch = smem;
+    f32x4* const s_w = smem + 2 * PATCH;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int lrow = tid >> 2, lcol = tid & 3;     // loader: row within a 64-row piece, 16-byte position in the row
+    const int scol = lcol ^ ((lrow >> 2) & 3);     // logical chunk this lane fetches (the LDS image stays lane-linear)
+    const int fi = lane & 31, fk = lane >> 5;
+    const int fswB = (fi >> 2) & 3;
+    const int npatch = 3 * p.kc;                   // (channel chunk, kernel row) pairs
+    const int in_bytes = ((p.total_in_pixels - 1) * p.in_pix_stride + p.cin) * 2;     // < 2^31, checked by the host
+    const int row_halfs = 9 * p.cin;
+
+    for (;;) {
+        if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+        __syncthreads();
+        int tile = *s_ticket;
+        if (tile >= p.total_tiles) break;
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        const int tile_n = tile % p.n_tiles;
+        const int tile_m = tile / p.n_tiles;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+        // loader role: patch row r = lrow + 64 j is input pixel m0 - 1 + (kh - 1) W + r (raster index over the batch);
+        // a negative or past-the-end offset is out of the descriptor's range -> zeros
+        int rowbase[A_CH], rowoffB[B_CH];
+#pragma unroll
+        for (int j = 0; j < A_CH; ++j) rowbase[j] = ((m0 - 1 + lrow + 64 * j) * p.in_pix_stride + scol * 8) * 2;
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) rowoffB[j] = ((n0 + lrow + 64 * j) * row_halfs + scol * 8) * 2;
+        // consumer role: "tap t is padding" bits of this lane's pixels (one per MFMA row block)
+        unsigned inv[TM];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            int m = m0 + wm * WM + a * 32 + fi;
+            if (m >= p.M) m = p.M - 1;              // rows beyond M are never stored
+            const int rr = m % p.HoWo;
+            const int y = rr / p.W, x = rr - y * p.W;
+            const unsigned badrow = (y == 0 ? 1u : 0u) | (y == p.H - 1 ? 4u : 0u);
+            const unsigned badcol = (x == 0 ? 1u : 0u) | (x == p.W - 1 ? 4u : 0u);
+            inv[a] = ((badrow & 1u) ? 0x007u : 0u) | ((badrow & 4u) ? 0x1C0u : 0u) | badcol * 0x49u;
+        }
+
+        // ---- DMA issue helpers (plain locals go to the builtin: see conv_igemm_f16.hip)
+        auto issue_patch_piece = [&](int j, int pi, bool live) {
+            const int cc = pi / 3, kh = pi - 3 * cc;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.in), 0, live ? in_bytes : 0, 0x00020000);
+            const int soff = ((kh - 1) * p.W * p.in_pix_stride + cc * 32) * 2;            // scalar
+            const int vo = rowbase[j] + soff;
+            f32x4* dst = s_patch + (pi & 1) * PATCH + wave_u * 64 + j * 256;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
+        };
+        auto issue_w_piece = [&](int j, int s, bool live) {
+            const int pi = s / 3, kw = s - 3 * pi;
+            const int cc = pi / 3, kh = pi - 3 * cc;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, live ? p.w_bytes : 0, 0x00020000);
+            const int koff = ((kh * 3 + kw) * p.cin + cc * 32) * 2;                       // scalar
+            const int vo = rowoffB[j] + koff;
+            f32x4* dst = s_w + (s % 3) * BSL + wave_u * 64 + j * 256;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
+        };
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+        f32x4 ca[TM], cb[TN], na[TM], nb[TN];
+        // fragments of (patch buffer pb, tap column kw, weight slot ws), k-slice q
+        auto read_frags = [&](f32x4(&fa)[TM], f32x4(&fb)[TN], int pb, int kw, int ws, int q) {
+            const int rowA = wm * WM + fi + kw;
+            const int chA = (2 * q + fk) ^ ((rowA >> 2) & 3);
+            const f32x4* pa = s_patch + pb * PATCH + rowA * 4 + chA;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = pa[a * 32 * 4];          // + 32 rows keeps (row >> 2) & 3
+            const f32x4* pw = s_w + ws * BSL + (wn * WN + fi) * 4 + ((2 * q + fk) ^ fswB);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = pw[b * 32 * 4];
+        };
+        auto take = [&](int tap) {       // next -> current, A masked with this tap's padding bits
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const unsigned keep = ((inv[a] >> tap) & 1u) ? 0u : 0xFFFFFFFFu;
+                const unsigned* src = reinterpret_cast<const unsigned*>(&na[a]);
+                unsigned* dst = reinterpret_cast<unsigned*>(&ca[a]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dst[k] = src[k] & keep;
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) cb[b] = nb[b];
+        };
+        auto mfmas = [&]() {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    // weights first: D[i = channel][j = pixel]
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cb[b]),
+                                                                       __builtin_bit_cast(f16x8, ca[a]), acc[a][b], 0, 0, 0);
+        };
+
+        // prologue: patch 0 and weight slices 0, 1 in flight; everything but slice 1 waited for
+#pragma unroll
+        for (int j = 0; j < A_CH; ++j) issue_patch_piece(j, 0, true);
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) issue_w_piece(j, 0, true);
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) issue_w_piece(j, 1, true);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(B_CH) : "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags(na, nb, 0, 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        take(0);
+
+        int s = 0;
+        for (int pi = 0; pi < npatch; ++pi) {
+            const int pb = pi & 1;
+            const int kh = pi % 3;
+            const bool more_patch = pi + 1 < npatch;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw, ++s) {
+                const int tap = kh * 3 + kw;
+                const int ws = s % 3;
+                const bool live2 = s + 2 < 3 * npatch;
+                // ---- k-slice 0
+                mfmas();
+                read_frags(na, nb, pb, kw, ws, 1);
+#pragma unroll
+                for (int j = 0; j < B_CH; ++j) issue_w_piece(j, s + 2, live2);
+                if (kw == 0) {
+#pragma unroll
+                    for (int j = 0; j < P0; ++j) issue_patch_piece(j, pi + 1, more_patch);
+                } else if (kw == 1) {
+#pragma unroll
+                    for (int j = P0; j < A_CH; ++j) issue_patch_piece(j, pi + 1, more_patch);
+                }
+                // everything requested before this tap has landed (weight slice s+1, and before tap 2 the whole next
+                // patch); my reads of this tap's buffers are done
+                if (kw == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(B_CH + P0) : "memory");
+                else if (kw == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(B_CH + A_CH - P0) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(B_CH) : "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                take(tap);
+                // ---- k-slice 1; the next tap's first fragments come from the next weight slot (and, after tap 2, from
+                // the other patch buffer, tap column 0)
+                mfmas();
+                if (kw < 2) read_frags(na, nb, pb, kw + 1, (s + 1) % 3, 0);
+                else read_frags(na, nb, pb ^ 1, 0, (s + 1) % 3, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                take(kw < 2 ? tap + 1 : ((kh + 1) % 3) * 3);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        f16_epilogue<BM, BN, WM, WN>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk);
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_c3(IgemmHParams p, int cout_pad, hipStream_t stream) {
+    const int m_tiles = (p.M + BM - 1) / BM;
+    p.n_tiles = cout_pad / BN;
+    const long long total = (long long)m_tiles * p.n_tiles;
+    OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "conv3x3 f16: %lld tiles out of range", total);
+    p.total_tiles = (int)total;
+    const long long slots = 256ll * c3_blocks_per_cu<BM, BN>();
+    const long long grid = total < slots ? total : slots;
+    hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
+// true if the layer can run here: stride-1 3x3 whose input view fits a 2^31-byte buffer descriptor and whose rows are
+// short enough for a patch (any W works: the patch is a run of raster pixels, not an image rectangle)
+bool conv3x3_f16_supported(const ConvArgsH& a) {
+    static const int enabled = [] { const char* e = getenv("OM_CONV3X3_SHARED"); return e ? atoi(e) : 1; }();
+    if (!enabled || a.ks != 3 || a.stride != 1 || a.cin % 32 || a.cout_pad % 64) return false;
+    const long long bytes = ((long long)a.B * a.H * a.W - 1) * a.in_pix_stride * 2 + a.cin * 2;
+    return bytes < 0x70000000ll && a.out_mode == 0;      // headroom: patch rows run up to 320 + W pixels past the end
+}
+
+void conv3x3_tile_for_f16(int M, int cout_pad, int* bm, int* bn) {
+    if (cout_pad % 128) { *bm = 128; *bn = 64; return; }
+    // 256x128 when it fills the chip for at least a few rounds, else the finer 128x128
+    const long long t256 = (long long)((M + 255) / 256) * (cout_pad / 128);
+    const long long t128 = (long long)((M + 127) / 128) * (cout_pad / 128);
+    const double c256 = (double)((t256 + 255) / 256) * 256 * 128 / 1.0;
+    const double c128 = (double)((t128 + 255) / 256) * 128 * 128 / 0.85;
+    *bn = 128;
+    *bm = c256 <= c128 ? 256 : 128;
+    static const int force = [] { const char* e = getenv("OM_CONV3X3_BM"); return e ? atoi(e) : 0; }();
+    if (force == 128 || force == 256) *bm = force;
+}
+
+int launch_conv3x3_f16(const ConvArgsH& a, hipStream_t stream) {
+    OM_REQUIRE(a.in && a.w && a.scale && a.shift && a.out && a.ticket, OM_EINVAL, "conv3x3 f16: null pointer");
+    OM_REQUIRE(conv3x3_f16_supported(a), OM_EINVAL, "conv3x3 f16: layer not supported by the shared-patch kernel");
+    OM_REQUIRE(a.in_pix_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(a.w) & 15) == 0,
+               OM_EINVAL, "conv3x3 f16: input view / weights must be 16-byte aligned");
+    OM_REQUIRE(!(a.res && a.out_f32), OM_EINVAL, "conv3x3 f16: residual only with fp16 output");
+    IgemmHParams p;
+    p.in = static_cast<const _Float16*>(a.in); p.w = static_cast<const _Float16*>(a.w);
+    p.scale = a.scale; p.shift = a.shift; p.res = static_cast<const _Float16*>(a.res); p.out = a.out;
+    p.ticket = a.ticket;
+    p.H = a.H; p.W = a.W; p.cin = a.cin; p.in_pix_stride = a.in_pix_stride;
+    p.Ho = a.H; p.Wo = a.W; p.HoWo = a.H * a.W; p.cout = a.cout;
+    p.ks = 3; p.stride = 1; p.pad = 1;
+    p.M = a.B * a.H * a.W; p.taps = 9; p.kc = a.cin / 32; p.ksteps = 9 * p.kc;
+    p.leaky = a.leaky; p.res_pix_stride = a.res_pix_stride; p.out_pix_stride = a.out_pix_stride;
+    p.out_mode = 0; p.up = 1; p.out_f32 = a.out_f32;
+    p.n_tiles = 0; p.total_tiles = 0;
+    p.total_in_pixels = a.B * a.H * a.W;
+    p.w_bytes = (int)(conv_f16_weight_halfs(a.cout_pad, 3, a.cin) * 2);
+    const int esz = a.out_f32 ? 4 : 2;
+    p.vec_io = ((a.out_pix_stride * esz) % 16 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+                (!a.res || (a.res_pix_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)))
+                   ? 1 : 0;
+    int bm, bn;
+    conv3x3_tile_for_f16(p.M, a.cout_pad, &bm, &bn);
+    if (bn == 64) return launch_c3<128, 64, 64, 32>(p, a.cout_pad, stream);
+    if (bm == 256) return launch_c3<256, 128, 128, 64>(p, a.cout_pad, stream);
+    return launch_c3<128, 128, 64, 64>(p, a.cout_pad, stream);
+}
+
+}  // namespace om

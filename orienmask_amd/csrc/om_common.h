@@ -74,7 +74,10 @@ struct ConvArgsH {
     int up;
     int out_f32;            // 1: the output tensor is fp32 (the four head convolutions)
 };
-int launch_conv_igemm_f16(const ConvArgsH& a, hipStream_t stream);
+int launch_conv_igemm_f16(const ConvArgsH& a, hipStream_t stream);     // dispatches stride-1 3x3 layers to conv3x3_f16.hip
+int launch_conv3x3_f16(const ConvArgsH& a, hipStream_t stream);
+bool conv3x3_f16_supported(const ConvArgsH& a);
+void conv3x3_tile_for_f16(int M, int cout_pad, int* bm, int* bn);
 void conv_tile_for_f16(int M, int cout_pad, int cin, int* bm, int* bn);
 inline size_t conv_f16_weight_halfs(int cout_pad, int ks, int cin) {
     return (size_t)cout_pad * ks * ks * cin;

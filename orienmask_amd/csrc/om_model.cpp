@@ -416,13 +416,23 @@ int om_model_load_weights_f16(om_model* m, const void* packed_f16_dev, size_t by
     return OM_OK;
 }
 
-int om_layer_tile_f16(const om_model* m, int index, int B, int H, int W, int* bm, int* bn) {
-    OM_REQUIRE(m && bm && bn, OM_EINVAL, "om_layer_tile_f16: null argument");
+int om_layer_tile_f16(const om_model* m, int index, int B, int H, int W, int* bm, int* bn, int* algo) {
+    OM_REQUIRE(m && bm && bn && algo, OM_EINVAL, "om_layer_tile_f16: null argument");
     OM_REQUIRE(index >= 0 && index < (int)m->layers.size(), OM_EINVAL, "om_layer_tile_f16: index %d", index);
     const om::LayerDef& L = m->layers[index];
-    if (L.stem) { *bm = 0; *bn = 0; return OM_OK; }
-    const int Ho = H / L.in_div / L.info.stride, Wo = W / L.in_div / L.info.stride;
+    if (L.stem) { *bm = 0; *bn = 0; *algo = 0; return OM_OK; }
+    const int Hin = H / L.in_div, Win = W / L.in_div;
+    const int Ho = Hin / L.info.stride, Wo = Win / L.info.stride;
+    om::ConvArgsH a{};
+    a.B = B; a.H = Hin; a.W = Win; a.cin = L.info.cin; a.in_pix_stride = m->pix_stride(L.in.buf);
+    a.cout = L.info.cout; a.cout_pad = L.info.cout_pad; a.ks = L.info.ksize; a.stride = L.info.stride; a.out_mode = L.out_mode;
+    if (om::conv3x3_f16_supported(a)) {
+        om::conv3x3_tile_for_f16(B * Ho * Wo, L.info.cout_pad, bm, bn);
+        *algo = 4;
+        return OM_OK;
+    }
     om::conv_tile_for_f16(B * Ho * Wo, L.info.cout_pad, L.info.cin, bm, bn);
+    *algo = 1;
     return OM_OK;
 }
 

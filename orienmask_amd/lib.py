@@ -57,7 +57,8 @@ SIGNATURES = {
     "om_model_load_weights_f16": (_i, [_vp, _vp, _sz]),
     "om_forward_f16_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "om_forward_f16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "om_layer_tile_f16": (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "om_layer_tile_f16": (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                               ctypes.POINTER(ctypes.c_int)]),
     "om_conv2d_f16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "om_conv2d_stem_f16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "om_conv2d_winograd_scratch_bytes": (_sz, [_i, _i, _i, _i]),

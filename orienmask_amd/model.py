@@ -210,11 +210,11 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         out = []
         if self.precision == "f16":
             for i, l in enumerate(self._layers):
-                bm, bn = ctypes.c_int(0), ctypes.c_int(0)
-                _lib.check(_lib.load().om_layer_tile_f16(h, i, B, H, W, ctypes.byref(bm), ctypes.byref(bn)),
-                           "om_layer_tile_f16")
-                out.append((l["name"], "conv_igemm_f16_kernel<%d,%d>" % (bm.value, bn.value) if bm.value
-                            else "conv_stem_kernel<f16>"))
+                bm, bn, algo = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+                _lib.check(_lib.load().om_layer_tile_f16(h, i, B, H, W, ctypes.byref(bm), ctypes.byref(bn),
+                                                         ctypes.byref(algo)), "om_layer_tile_f16")
+                fmt = {0: "conv_stem_kernel<f16>", 1: "conv_igemm_f16_kernel<%d,%d>", 4: "conv3x3_f16_kernel<%d,%d>"}[algo.value]
+                out.append((l["name"], fmt % (bm.value, bn.value) if algo.value else fmt))
             return out
         for i, l in enumerate(self._layers):
             bm, bn, algo = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)

@@ -563,6 +563,11 @@ F16_CONV_CASES = [
     (2, 9, 7, 256, 255, 1, 1, 0, False, 1),      # box head: fp32 out, cout not a multiple of 8
     (5, 4, 4, 1024, 512, 1, 1, 1, False, 0),
     (4, 32, 32, 128, 256, 3, 1, 1, True, 0),     # enough rows for the 256 x 128 tile
+    (2, 5, 3, 64, 128, 3, 1, 1, False, 0),       # rows shorter than the kernel: every pixel touches padding
+    (3, 1, 7, 64, 128, 3, 1, 1, True, 0),        # one-row images: the raster neighbours above/below are other images
+    (2, 7, 1, 64, 64, 3, 1, 0, False, 0),        # one-column images
+    (9, 17, 17, 512, 1024, 3, 1, 1, True, 0),    # conv6-like: several images per tile
+    (2, 24, 40, 256, 128, 3, 1, 1, False, 1),    # fp32 output from the shared-patch kernel
 ]
 
 
