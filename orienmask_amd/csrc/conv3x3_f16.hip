@@ -169,9 +169,9 @@ __global__ __launch_bounds__(256, (c3_blocks_per_cu<BM, BN>())) void conv3x3_f16
                 const int tap = kh * 3 + kw;
                 const int ws = s % 3;
                 const bool live2 = s + 2 < 3 * npatch;
-                // ---- k-slice 0
-                mfmas();
+                // ---- k-slice 0 (the LDS reads of the next slice are issued first: they return under the MFMAs)
                 read_frags(na, nb, pb, kw, ws, 1);
+                mfmas();
 #pragma unroll
                 for (int j = 0; j < B_CH; ++j) issue_w_piece(j, s + 2, live2);
                 if (kw == 0) {
@@ -191,9 +191,9 @@ __global__ __launch_bounds__(256, (c3_blocks_per_cu<BM, BN>())) void conv3x3_f16
                 take(tap);
                 // ---- k-slice 1; the next tap's first fragments come from the next weight slot (and, after tap 2, from
                 // the other patch buffer, tap column 0)
-                mfmas();
                 if (kw < 2) read_frags(na, nb, pb, kw + 1, (s + 1) % 3, 0);
                 else read_frags(na, nb, pb ^ 1, 0, (s + 1) % 3, 0);
+                mfmas();
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 take(kw < 2 ? tap + 1 : ((kh + 1) % 3) * 3);

@@ -188,9 +188,9 @@ __global__ __launch_bounds__(256, (f16_blocks_per_cu<BM, BN>())) void conv_igemm
             const int buf1 = buf == NBUF - 1 ? 0 : buf + 1;
             const int buf2 = buf1 == NBUF - 1 ? 0 : buf1 + 1;    // step s+2: last read in step s-1, before its barrier
             const bool live2 = s + 2 < p.ksteps;
-            // ---- k-slice 0
-            mfmas();
+            // ---- k-slice 0 (the LDS reads of the next slice are issued first: they return under the MFMAs)
             read_frags(na, nb, buf, 1);
+            mfmas();
 #pragma unroll
             for (int i = 0; i < NP0; ++i) issue_piece(i, buf2, live2);
             // step s+1 has landed (everything older than the NP0 pieces just issued); my reads of `buf` are done
@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256, (f16_blocks_per_cu<BM, BN>())) void conv_igemm
 #pragma unroll
             for (int b = 0; b < TN; ++b) cb[b] = nb[b];
             // ---- k-slice 1
-            mfmas();
             read_frags(na, nb, buf1, 0);
+            mfmas();
 #pragma unroll
             for (int i = NP0; i < NP; ++i) issue_piece(i, buf2, live2);
             __builtin_amdgcn_sched_barrier(0);
