@@ -159,18 +159,36 @@ def main():
         dets = step()
     torch.cuda.synchronize()
 
+    # ---- untimed pass with events around EVERY layer: the per-kernel table, and which kernel dominates
+    specs = {s.name: s for s in arch.fpnplus_convs()}
+    kernel_of = dict(net.layer_kernels(B, H, W))
+    n_prof = 3
     net.profile_enable(True)
-    post_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
+    post_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_prof)]
+    for i in range(n_prof):
         with torch.no_grad():
             pred = net(x)
             post_ev[i][0].record()
             dets = post(pred)
             post_ev[i][1].record()
+    torch.cuda.synchronize()
+    layer_ms, n_fw = net.profile_read()
+    post_ms = sum(a.elapsed_time(b) for a, b in post_ev) / n_prof
+    by_kernel = {}
+    for name, ms, pre in layer_ms:
+        by_kernel[kernel_of[name]] = by_kernel.get(kernel_of[name], 0.0) + ms
+    dom = max(by_kernel, key=by_kernel.get)
+    dom_layers = [name for name, _, _ in layer_ms if kernel_of[name] == dom]
+
+    # ---- timed region: K steps, HIP events only around the dominant kernel's launches (an event pair costs a few
+    # microseconds of GPU time; around all ~90 layers that was 3 % of the step)
+    net.profile_enable_layers(dom_layers)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        dets = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -179,14 +197,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-
-    layer_ms, n_fw = net.profile_read()
+    timed_ms, timed_fw = net.profile_read()
     net.profile_enable(False)
-    post_ms = sum(a.elapsed_time(b) for a, b in post_ev) / args.steps
+    dom_timed_ms = sum(ms for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw     # per step, all launches
 
     if rank == 0:
-        specs = {s.name: s for s in arch.fpnplus_convs()}
-        kernel_of = dict(net.layer_kernels(B, H, W))
         kern = {}
 
         def acc(name, ms, flops, exec_flops, byts):
@@ -202,11 +217,11 @@ def main():
             acc(k, ms / n_fw, wk["flops"], wk["flops"] / 2.25 if wino else wk["flops"], wk["bytes"] / (2 if f16 else 1))
             if k.startswith("wino_gemm"):
                 acc("wino_input_kernel", pre / n_fw, 0.0, 0.0, 5.0 * 4 * B * (H // arch.layer_div(specs[name])) ** 2 * specs[name].cin)
-        dom = max(kern, key=lambda k: kern[k]["ms"])
         d = kern[dom]
         fwd_ms = sum(t["ms"] for t in kern.values())
-        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        executed = d["exec_flops"] / (d["ms"] * 1e-3) / 1e12
+        # the dominant kernel's rate comes from the events recorded INSIDE the timed region
+        achieved = d["flops"] / (dom_timed_ms * 1e-3) / 1e12
+        executed = d["exec_flops"] / (dom_timed_ms * 1e-3) / 1e12
         total_flops = sum(t["flops"] for t in kern.values())
         total_bytes = sum(t["bytes"] for t in kern.values())
         traffic, traffic_src = None, None
@@ -225,8 +240,10 @@ def main():
                         traffic_source=None if f16 else traffic_src,
                         algorithmic_bytes_per_launch=round(d["bytes"] / d["launches"]),
                         kernel=dom,
-                        launches_per_step=d["launches"], avg_launch_ms=round(d["ms"] / d["launches"], 4),
-                        kernel_ms_per_step=round(d["ms"], 3),
+                        launches_per_step=d["launches"], avg_launch_ms=round(dom_timed_ms / d["launches"], 4),
+                        kernel_ms_per_step=round(dom_timed_ms, 3),
+                        measured="HIP events on the launch stream around every launch of this kernel inside the timed region; "
+                                 "the other per-kernel figures come from an untimed pass with events around all layers",
                         executed_tflops=round(executed, 2), executed_frac=round(executed / peak_tf, 4),
                         note=("fp16 operands, fp32 accumulate on v_mfma_f32_32x32x16_f16 (dense peak 2.5 PFLOP/s); direct "
                               "convolution, executed = algorithmic") if f16 else

@@ -128,6 +128,10 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
 /* algo: 0 = conv_stem_kernel, 1 = conv_igemm_f32_kernel<bm,bn>, 2 = wino_input_kernel + wino_gemm_kernel<bm,bn>,
  *       3 = wino_fused_kernel<bn> (input transform fused into the GEMM's loader) */
 int om_profile_enable(om_model* m, int enable);
+/* record events only around the layers with layer_mask[i] != 0 (an event pair costs a few microseconds of GPU time, so a
+ * timed region that only needs one kernel's durations should not pay for all ~90 layers); om_profile_read then returns 0
+ * for the other layers */
+int om_profile_enable_layers(om_model* m, const unsigned char* layer_mask, int n_layers);
 int om_profile_read(om_model* m, float* layer_ms, float* layer_pre_ms, int n_layers, int* n_forwards);
 
 /* ---- one convolution (unit-test entry) ----------------------------------------------------- */

@@ -66,6 +66,7 @@ struct om_model {
     const _Float16* weights16 = nullptr;
     // optional per-layer timing with HIP events on the launch stream (om_profile_*)
     bool profiling = false;
+    std::vector<unsigned char> prof_mask;    // empty: every layer; else 1 = record events for this layer
     std::vector<hipEvent_t> ev_pool;     // 3 events per (recorded forward, layer): start, mid, stop
     size_t ev_used = 0;
     int prof_forwards = 0;
@@ -318,7 +319,7 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
     for (const om::LayerDef& L : m->layers) {
         const om_layer_info& li = L.info;
         hipEvent_t ev_stop = nullptr, ev_mid = nullptr;
-        if (m->profiling) {
+        if (m->profiling && (m->prof_mask.empty() || m->prof_mask[&L - m->layers.data()])) {
             if (m->ev_used + 3 > m->ev_pool.size()) {
                 for (int k = 0; k < 3; ++k) {
                     hipEvent_t e;
@@ -458,6 +459,18 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
 int om_profile_enable(om_model* m, int enable) {
     OM_REQUIRE(m, OM_EINVAL, "om_profile_enable: null model");
     m->profiling = enable != 0;
+    m->prof_mask.clear();
+    m->ev_used = 0;
+    m->prof_forwards = 0;
+    return OM_OK;
+}
+
+int om_profile_enable_layers(om_model* m, const unsigned char* layer_mask, int n_layers) {
+    OM_REQUIRE(m && layer_mask, OM_EINVAL, "om_profile_enable_layers: null argument");
+    OM_REQUIRE(n_layers == (int)m->layers.size(), OM_EINVAL, "om_profile_enable_layers: n_layers=%d, graph has %zu", n_layers,
+               m->layers.size());
+    m->profiling = true;
+    m->prof_mask.assign(layer_mask, layer_mask + n_layers);
     m->ev_used = 0;
     m->prof_forwards = 0;
     return OM_OK;
@@ -467,16 +480,21 @@ int om_profile_read(om_model* m, float* layer_ms, float* layer_pre_ms, int n_lay
     OM_REQUIRE(m && layer_ms && layer_pre_ms && n_forwards, OM_EINVAL, "om_profile_read: null argument");
     OM_REQUIRE(n_layers == (int)m->layers.size(), OM_EINVAL, "om_profile_read: n_layers=%d, graph has %zu", n_layers,
                m->layers.size());
-    OM_REQUIRE(m->ev_used == (size_t)m->prof_forwards * m->layers.size() * 3, OM_ESTATE,
+    size_t n_rec = 0;
+    for (int i = 0; i < n_layers; ++i) n_rec += (m->prof_mask.empty() || m->prof_mask[i]) ? 1 : 0;
+    OM_REQUIRE(m->ev_used == (size_t)m->prof_forwards * n_rec * 3, OM_ESTATE,
                "om_profile_read: a profiled forward failed part-way");
     for (int i = 0; i < n_layers; ++i) layer_ms[i] = layer_pre_ms[i] = 0.f;
     size_t e = 0;
     for (int f = 0; f < m->prof_forwards; ++f)
-        for (int i = 0; i < n_layers; ++i, e += 3) {
-            OM_CHECK_HIP(hipEventSynchronize(m->ev_pool[e + 2]));
+        for (int i = 0; i < n_layers; ++i) {
+            if (!(m->prof_mask.empty() || m->prof_mask[i])) continue;
+            const size_t e0 = e;
+            e += 3;
+            OM_CHECK_HIP(hipEventSynchronize(m->ev_pool[e0 + 2]));
             float pre = 0.f, main = 0.f;
-            OM_CHECK_HIP(hipEventElapsedTime(&pre, m->ev_pool[e], m->ev_pool[e + 1]));
-            OM_CHECK_HIP(hipEventElapsedTime(&main, m->ev_pool[e + 1], m->ev_pool[e + 2]));
+            OM_CHECK_HIP(hipEventElapsedTime(&pre, m->ev_pool[e0], m->ev_pool[e0 + 1]));
+            OM_CHECK_HIP(hipEventElapsedTime(&main, m->ev_pool[e0 + 1], m->ev_pool[e0 + 2]));
             layer_pre_ms[i] += pre;
             layer_ms[i] += main;
         }

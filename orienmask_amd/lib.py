@@ -64,6 +64,7 @@ SIGNATURES = {
     "om_conv2d_winograd_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "om_conv2d_winograd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "om_profile_enable": (_i, [_vp, _i]),
+    "om_profile_enable_layers": (_i, [_vp, ctypes.c_char_p, _i]),
     "om_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _i,
                              ctypes.POINTER(ctypes.c_int)]),
     "om_conv2d": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),

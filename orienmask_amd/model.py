@@ -203,6 +203,12 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         """Record one HIP event pair per layer on the launch stream during forward()."""
         _lib.check(_lib.load().om_profile_enable(self._ensure_handle(), 1 if enable else 0), "om_profile_enable")
 
+    def profile_enable_layers(self, names):
+        """Like profile_enable(True), but events are recorded only around the named layers (cheaper inside a timed region)."""
+        h = self._ensure_handle()
+        mask = bytes(1 if l["name"] in set(names) else 0 for l in self._layers)
+        _lib.check(_lib.load().om_profile_enable_layers(h, mask, len(mask)), "om_profile_enable_layers")
+
     def layer_kernels(self, B, H, W):
         """Kernel instantiation that runs each layer at this size: 'conv_stem_kernel' or
         'conv_igemm_f32_kernel<BM,BN>' (graph order)."""
