@@ -660,6 +660,22 @@ def test_forward_f16_matches_oracle(dev, batch, size):
     print("fp16 forward vs oracle.forward_f16: worst rel err %.3e" % worst)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16"])
+def test_forward_on_side_streams_is_bit_identical(dev, prec):
+    """set_streams(2): two sub-batches on two HIP streams == one launch, bit for bit; odd batches fall back to one launch."""
+    sd = synth.synth_state_dict(7, obj_bias=-16.0, head_gain=4.0)
+    x = synth.synth_image_batch(24, 4, 544, 544).to(dev)
+    net = _hip_model(sd, dev).set_precision(prec)
+    with torch.no_grad():
+        want = [(a.clone(), b.clone()) for a, b in net(x)]
+        net.set_streams(2)
+        for xb, wb in ((x, want), (x[:3], [(a[:3], b[:3]) for a, b in want])):
+            got = net(xb)
+            torch.cuda.synchronize()
+            for (ga, gb), (wa, wb_) in zip(got, wb):
+                assert torch.equal(ga, wa) and torch.equal(gb, wb_)
+
+
 def test_forward_f16_non_plus_model_matches_oracle(dev):
     """The OrienMaskYOLO graph (variant 1) through the fp16 path."""
     from orienmask_amd.model import OrienMaskYOLO
