@@ -131,9 +131,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("OM_BENCH_FORCE_DIST") == "1"     # the env switch exercises the RCCL calls on one GPU
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from orienmask_amd import arch, synth
@@ -191,17 +193,17 @@ def main():
         step()                                                     # allocate the per-stream workspaces outside the timing
     if args.streams > 1:
         net.profile_enable_layers(dom_layers)                      # drop the warm-up's events
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         dets = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -298,7 +300,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, x_cpu, f16=f16)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

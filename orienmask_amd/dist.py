@@ -35,7 +35,7 @@ def broadcast_blob(blob, numel, device, src=0, dtype=torch.float32):
         blob = blob.to(device).contiguous()
     else:
         blob = torch.empty(numel, dtype=dtype, device=device)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.broadcast(blob, src=src)
     return blob
 
