@@ -116,6 +116,14 @@ int om_forward_f16(om_model* m, const float* x, int B, int H, int W, float* bbox
  * 4 = conv3x3_f16_kernel<bm,bn> (stride-1 3x3: the three taps of a kernel row share one LDS copy of the input rows) */
 int om_layer_tile_f16(const om_model* m, int index, int B, int H, int W, int* bm, int* bn, int* algo);
 
+/* ---- intermediate activations (tests / debugging; BASELINE configs[1] checks the DarkNet-53 features) -------------------
+ * Where layer `index`'s output lives inside the workspace of the last om_forward (f16 = 0) / om_forward_f16 (f16 = 1) call
+ * at this problem size: an NHWC view [B, H/div, W/div, channels] starting byte_offset bytes into the workspace, pixel
+ * stride pix_stride ELEMENTS (a concat buffer's slice has pix_stride > channels).  The four head layers write
+ * caller-owned tensors and are rejected. */
+int om_layer_output_view(const om_model* m, int index, int B, int H, int W, int f16, size_t* byte_offset, int* channels,
+                         int* pix_stride, int* div);
+
 /* ---- measurement: per-layer durations with HIP events on the stream om_forward launches on
  * (the reference measures with torch.cuda.Event pairs, utils/timer.py:70-82).  While enabled, every
  * om_forward records events around every kernel of every layer; om_profile_read synchronises on them and

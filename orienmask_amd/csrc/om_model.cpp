@@ -437,6 +437,23 @@ int om_layer_tile_f16(const om_model* m, int index, int B, int H, int W, int* bm
     return OM_OK;
 }
 
+int om_layer_output_view(const om_model* m, int index, int B, int H, int W, int f16, size_t* byte_offset, int* channels,
+                         int* pix_stride, int* div) {
+    OM_REQUIRE(m && byte_offset && channels && pix_stride && div, OM_EINVAL, "om_layer_output_view: null argument");
+    OM_REQUIRE(index >= 0 && index < (int)m->layers.size(), OM_EINVAL, "om_layer_output_view: index %d", index);
+    OM_REQUIRE(B > 0 && H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, OM_EINVAL, "om_layer_output_view: bad shape");
+    const om::LayerDef& L = m->layers[index];
+    OM_REQUIRE(L.out.buf >= 0, OM_EINVAL, "om_layer_output_view: layer %s writes a caller-owned head tensor", L.info.name);
+    const size_t esz = f16 ? 2 : 4;
+    size_t off = 0;
+    for (int i = 0; i < L.out.buf; ++i) off += om::align_up(m->buf_floats(i, B, H, W) * esz, 256);
+    *byte_offset = off + (size_t)L.out.ch_off * esz;
+    *channels = L.info.cout;
+    *pix_stride = m->bufs[L.out.buf].C;
+    *div = m->bufs[L.out.buf].div;      // an up-sampling layer's output is stored replicated at the buffer's resolution
+    return OM_OK;
+}
+
 int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, int* bn, int* algo) {
     OM_REQUIRE(m && bm && bn && algo, OM_EINVAL, "om_layer_tile: null argument");
     OM_REQUIRE(index >= 0 && index < (int)m->layers.size(), OM_EINVAL, "om_layer_tile: index %d", index);

@@ -63,6 +63,8 @@ SIGNATURES = {
     "om_conv2d_stem_f16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "om_conv2d_winograd_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "om_conv2d_winograd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "om_layer_output_view": (_i, [_vp, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int),
+                                  ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "om_profile_enable": (_i, [_vp, _i]),
     "om_profile_enable_layers": (_i, [_vp, ctypes.c_char_p, _i]),
     "om_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _i,

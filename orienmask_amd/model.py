@@ -236,6 +236,23 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         """Record one HIP event pair per layer on the launch stream during forward()."""
         _lib.check(_lib.load().om_profile_enable(self._ensure_handle(), 1 if enable else 0), "om_profile_enable")
 
+    def layer_output(self, name, x_shape):
+        """NCHW-shaped strided view [B, C, H/div, W/div] of layer `name`'s activation inside the workspace of the last
+        forward() on an input of shape x_shape (one launch, n_streams == 1).  For tests and debugging."""
+        h = self._ensure_handle()
+        idx = [l["name"] for l in self._layers].index(name)
+        B, _, H, W = x_shape
+        f16 = self.precision == "f16"
+        ws = next(iter(self._workspace.values()))
+        off, ch, ps, div = ctypes.c_size_t(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(_lib.load().om_layer_output_view(h, idx, B, H, W, 1 if f16 else 0, ctypes.byref(off), ctypes.byref(ch),
+                                                    ctypes.byref(ps), ctypes.byref(div)), "om_layer_output_view")
+        dt = torch.float16 if f16 else torch.float32
+        esz = 2 if f16 else 4
+        hh, ww = H // div.value, W // div.value
+        flat = ws[off.value:off.value + ((B * hh * ww - 1) * ps.value + ch.value) * esz].view(dt)
+        return torch.as_strided(flat, (B, ch.value, hh, ww), (hh * ww * ps.value, 1, ww * ps.value, ps.value))
+
     def profile_enable_layers(self, names):
         """Like profile_enable(True), but events are recorded only around the named layers (cheaper inside a timed region)."""
         h = self._ensure_handle()

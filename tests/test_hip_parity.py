@@ -660,6 +660,24 @@ def test_forward_f16_matches_oracle(dev, batch, size):
     print("fp16 forward vs oracle.forward_f16: worst rel err %.3e" % worst)
 
 
+def test_backbone_features_bs8_match_oracle(dev):
+    """BASELINE configs[1]: DarkNet-53 only, random weights, bs=8 at 544x544 -- x4 / x8 / x16 / x32 as the HIP kernels
+    left them in the workspace vs the CPU oracle's backbone, <= 1e-4 of each tensor's scale."""
+    sd = synth.synth_state_dict(8, obj_bias=-16.0, head_gain=4.0)
+    x = synth.synth_image_batch(25, 8, 544, 544)
+    net = _hip_model(sd, dev)
+    with torch.no_grad():
+        net(x.to(dev))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        x32, x16, x8, x4 = R.backbone(sd, x)
+    for name, want in (("backbone.conv3.2.conv.1", x4), ("backbone.conv4.8.conv.1", x8), ("backbone.conv5.8.conv.1", x16),
+                       ("backbone.conv6.4.conv.1", x32)):
+        got = net.layer_output(name, x.shape).cpu()
+        assert got.shape == want.shape
+        assert _rel_err(got, want) < REL_TOL, name
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16"])
 def test_forward_on_side_streams_is_bit_identical(dev, prec):
     """set_streams(2): two sub-batches on two HIP streams == one launch, bit for bit; odd batches fall back to one launch."""
