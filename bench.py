@@ -238,18 +238,17 @@ def main():
         total_bytes = sum(t["bytes"] for t in kern.values())
         traffic, traffic_src = None, None
         try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.sh)
-            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic_f16.json" if f16 else "r01_pmc_traffic.json")))
             key = [k for k in pmc if k.replace(" ", "").startswith(dom.rstrip(">").replace(" ", ""))]
             if key and B == 32 and H == 544:
                 traffic = round(pmc[key[0]]["hbm_bytes_per_launch_corrected"])
-                traffic_src = ("profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate "
+                traffic_src = ("profiles/r01_pmc_traffic%s.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate " % ("_f16" if f16 else "") +
                                "rocprofv3 --pmc passes of this bench at bs=32 (FETCH_SIZE doubled per MI355X_MICROARCH.md)")
         except Exception:
             pass
         peak_tf = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
         roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak_tf, unit="TFLOP/s",
-                        frac=round(achieved / peak_tf, 4), traffic=None if f16 else traffic,
-                        traffic_source=None if f16 else traffic_src,
+                        frac=round(achieved / peak_tf, 4), traffic=traffic, traffic_source=traffic_src,
                         algorithmic_bytes_per_launch=round(d["bytes"] / d["launches"]),
                         kernel=dom,
                         launches_per_step=d["launches"], avg_launch_ms=round(dom_timed_ms / d["launches"], 4),
