@@ -226,9 +226,13 @@ def main():
             wino = k.startswith("wino")
             # Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36 -> executed = algorithmic / 2.25
             # fp16 configuration: every activation and weight element is 2 bytes (the fp32 heads are < 1 % of the bytes)
-            acc(k, ms / n_fw, wk["flops"], wk["flops"] / 2.25 if wino else wk["flops"], wk["bytes"] / (2 if f16 else 1))
-            if k.startswith("wino_gemm"):
-                acc("wino_input_kernel", pre / n_fw, 0.0, 0.0, 5.0 * 4 * B * (H // arch.layer_div(specs[name])) ** 2 * specs[name].cin)
+            # F(2x4,3x3): 24 multiplies per 8 outputs instead of 72 -> executed = algorithmic / 3
+            red = 3.0 if k.startswith("wino24") else (2.25 if wino else 1.0)
+            acc(k, ms / n_fw, wk["flops"], wk["flops"] / red, wk["bytes"] / (2 if f16 else 1))
+            if k.startswith("wino_gemm") or k.startswith("wino24_gemm"):
+                vx = 3.0 if k.startswith("wino24") else 4.0       # transformed input: 3x / 4x the activation, plus reading it
+                acc("wino24_input_kernel" if k.startswith("wino24") else "wino_input_kernel", pre / n_fw, 0.0, 0.0,
+                    (1.0 + vx) * 4 * B * (H // arch.layer_div(specs[name])) ** 2 * specs[name].cin)
         d = kern[dom]
         fwd_ms = sum(t["ms"] for t in kern.values())
         # the dominant kernel's rate comes from the events recorded INSIDE the timed region

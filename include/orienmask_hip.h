@@ -53,9 +53,10 @@ typedef struct om_layer_info {
     int32_t cin, cout, cout_pad, ksize, stride;
     int32_t has_bn;             /* 1: conv(bias=False)+BN+leaky;  0: conv(bias=True) only */
     int32_t leaky;
+    int32_t wino_planes;        /* 0: no Winograd weights; 16: F(2x2,3x3); 24: F(2x4,3x3) (2 rows x 4 columns per tile) */
     int64_t w_off, scale_off, shift_off;
-    int64_t wino_off;           /* >= 0: Winograd F(2x2,3x3) weights U = G g G^T, [16][cout_pad][cin], for the
-                                   stride-1 3x3 layers; -1: none */
+    int64_t wino_off;           /* >= 0: Winograd weights U = G_y g G_x^T, [wino_planes][cout_pad][cin], plane index
+                                   = 4 i + j (16) or 6 i + j (24), for the stride-1 3x3 layers; -1: none */
     int64_t w16_off;            /* fp16 path: offset IN HALFS into the fp16 weight blob (om_model_load_weights_f16):
                                    [cout_pad][ksize*ksize][cin] fp16 (rows >= cout zero); -1: the stem (always fp32) */
 } om_layer_info;
@@ -134,7 +135,8 @@ int om_layer_output_view(const om_model* m, int index, int B, int H, int W, int 
  * this problem size; 0 x 0 for the stem kernel.  Lets a profile be grouped by kernel. */
 int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, int* bn, int* algo);
 /* algo: 0 = conv_stem_kernel, 1 = conv_igemm_f32_kernel<bm,bn>, 2 = wino_input_kernel + wino_gemm_kernel<bm,bn>,
- *       3 = wino_fused_kernel<bn> (input transform fused into the GEMM's loader) */
+ *       3 = wino_fused_kernel<bn> (input transform fused into the GEMM's loader),
+ *       5 = wino24_input_kernel + wino24_gemm_kernel (Winograd F(2x4,3x3), 64x64 tile) */
 int om_profile_enable(om_model* m, int enable);
 /* record events only around the layers with layer_mask[i] != 0 (an event pair costs a few microseconds of GPU time, so a
  * timed region that only needs one kernel's durations should not pay for all ~90 layers); om_profile_read then returns 0
@@ -162,6 +164,12 @@ int om_conv2d_f16(const void* in, int B, int H, int W, int cin, int in_pix_strid
                   void* out, int out_pix_stride, int out_f32, om_stream stream);
 int om_conv2d_stem_f16(const float* in, int B, int H, int W, const float* w, const float* scale, const float* shift,
                        int cout, void* out, om_stream stream);
+/* The same layer through Winograd F(2x4,3x3): u = G_y g G_x^T as [24][cout_pad][cin], cout_pad = cout rounded up to 64. */
+size_t om_conv2d_winograd24_scratch_bytes(int B, int H, int W, int cin);
+int om_conv2d_winograd24(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* u,
+                         const float* scale, const float* shift, int cout, int leaky, const float* res,
+                         int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
+                         om_stream stream);
 /* first layer: in [B,3,H,W] NCHW -> out [B,H,W,cout] NHWC, 3x3 stride 1. */
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale,
                    const float* shift, int cout, float* out, om_stream stream);

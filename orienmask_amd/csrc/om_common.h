@@ -88,6 +88,9 @@ void conv_tile_for(int M, int cout_pad, int* bm, int* bn);
 // Winograd F(2x2,3x3) path (conv_wino.hip): a.w = U [16][cout_pad][cin]
 int launch_conv_winograd(const ConvArgs& a, float* scratch, hipStream_t stream);
 size_t wino_scratch_floats(int B, int H, int W, int C);
+// Winograd F(2x4,3x3) path (conv_wino24.hip): a.w = U [24][cout_pad][cin]
+int launch_conv_winograd24(const ConvArgs& a, float* scratch, hipStream_t stream);
+size_t wino24_scratch_floats(int B, int H, int W, int C);
 bool wino_enabled();
 int wino_bn(long long T, int cout_pad);   // N tile of the (unfused) Winograd GEMM at this size
 bool wino_fused_for(int cin);     // true: the input transform is fused into the GEMM's loader   // tile shape launch_conv_igemm picks

@@ -14,6 +14,7 @@
 //   * the three box heads are written NHWC with a 256-float pixel stride (what the decode kernel
 //     wants), the orientation head NCHW (what the mask kernel wants);
 //   * no allocation, no synchronisation: ~90 launches on the caller's stream.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -91,10 +92,18 @@ struct om_model {
         L.info.scale_off = (int64_t)weight_floats; weight_floats += L.info.cout_pad;
         L.info.shift_off = (int64_t)weight_floats; weight_floats += L.info.cout_pad;
         L.info.wino_off = -1;
+        L.info.wino_planes = 0;
         if (ks == 3 && stride == 1 && !stem && L.info.cout_pad % 64 == 0 && cin % 32 == 0) {
+            // F(2x4,3x3) (24 planes) for the layers that run the unfused transform + GEMM pair; the fused-loader layers
+            // (cin <= 64) stay on F(2x2,3x3) (16 planes).  OM_WINO_F24=0 at model creation selects F(2x2) everywhere.
+            static const int f24 = [] { const char* e = getenv("OM_WINO_F24"); return e ? atoi(e) : 1; }();
+            // Not at 1/32 scale either (17 x 17 at 544: 18 % of a 2 x 4 tiling is padding and the GEMM has too few tiles:
+            // measured 0.465 vs 0.436 ms per conv6 layer).
+            static const int f24_fused = [] { const char* e = getenv("OM_WINO_F24_ALL"); return e ? atoi(e) : 1; }();
+            L.info.wino_planes = (f24 && (f24_fused || !om::wino_fused_for(cin)) && in_div < 32) ? 24 : 16;
             weight_floats = om::align_up(weight_floats, 4);
             L.info.wino_off = (int64_t)weight_floats;
-            weight_floats += (size_t)16 * L.info.cout_pad * cin;
+            weight_floats += (size_t)L.info.wino_planes * L.info.cout_pad * cin;
         }
         L.info.w16_off = -1;
         if (!stem) {
@@ -203,7 +212,8 @@ struct om_model {
         size_t mx = 0;
         for (const om::LayerDef& L : layers)
             if (L.info.wino_off >= 0) {
-                const size_t f = om::wino_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin);
+                const size_t f = L.info.wino_planes == 24 ? om::wino24_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin)
+                                                          : om::wino_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin);
                 if (f > mx) mx = f;
             }
         return mx;
@@ -379,7 +389,8 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             if (li.wino_off >= 0 && om::wino_enabled()) {
                 a.w = m->weights + li.wino_off;
                 a.mid_event = ev_mid;
-                rc = om::launch_conv_winograd(a, wino_scratch, stream);
+                rc = li.wino_planes == 24 ? om::launch_conv_winograd24(a, wino_scratch, stream)
+                                          : om::launch_conv_winograd(a, wino_scratch, stream);
             } else {
                 if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));     // single-kernel layer: mid == start
                 rc = om::launch_conv_igemm(a, stream);
@@ -459,6 +470,10 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
     OM_REQUIRE(index >= 0 && index < (int)m->layers.size(), OM_EINVAL, "om_layer_tile: index %d", index);
     const om::LayerDef& L = m->layers[index];
     if (L.stem) { *bm = 0; *bn = 0; *algo = 0; return OM_OK; }
+    if (L.info.wino_off >= 0 && om::wino_enabled() && L.info.wino_planes == 24) {
+        *algo = 5; *bm = 64; *bn = 64;
+        return OM_OK;
+    }
     if (L.info.wino_off >= 0 && om::wino_enabled()) {
         const int Hl = H / L.in_div, Wl = W / L.in_div;
         *algo = om::wino_fused_for(L.info.cin) ? 3 : 2;
@@ -585,6 +600,31 @@ int om_conv2d_f16(const void* in, int B, int H, int W, int cin, int in_pix_strid
 int om_conv2d_stem_f16(const float* in, int B, int H, int W, const float* w, const float* scale, const float* shift,
                        int cout, void* out, om_stream stream) {
     return om::launch_conv_stem_f16(in, B, H, W, w, scale, shift, cout, out, static_cast<hipStream_t>(stream));
+}
+
+size_t om_conv2d_winograd24_scratch_bytes(int B, int H, int W, int cin) {
+    if (B <= 0 || H <= 0 || W <= 0 || cin <= 0) return 0;
+    return om::align_up(om::wino24_scratch_floats(B, H, W, cin) * sizeof(float), 256);
+}
+
+int om_conv2d_winograd24(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* u,
+                         const float* scale, const float* shift, int cout, int leaky, const float* res,
+                         int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
+                         om_stream stream) {
+    OM_REQUIRE(B > 0 && H > 0 && W > 0, OM_EINVAL, "om_conv2d_winograd24: bad shape");
+    OM_REQUIRE(scratch && scratch_bytes >= om_conv2d_winograd24_scratch_bytes(B, H, W, cin), OM_ENOMEM,
+               "om_conv2d_winograd24: scratch too small");
+    om::ConvArgs a;
+    a.in = in; a.w = u; a.scale = scale; a.shift = shift; a.res = res; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.cin = cin; a.in_pix_stride = in_pix_stride;
+    a.Ho = H; a.Wo = W; a.cout = cout; a.cout_pad = om::round_up(cout, 64);
+    a.ks = 3; a.stride = 1; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
+    a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1;
+    static int* g_ticket = nullptr;
+    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), 256));
+    if (int rc = om::launch_zero_words(g_ticket, 1, static_cast<hipStream_t>(stream))) return rc;
+    a.ticket = g_ticket;
+    return om::launch_conv_winograd24(a, static_cast<float*>(scratch), static_cast<hipStream_t>(stream));
 }
 
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale, const float* shift,

@@ -17,7 +17,7 @@ class LayerInfo(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 64),
                 ("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("cout_pad", ctypes.c_int32),
                 ("ksize", ctypes.c_int32), ("stride", ctypes.c_int32),
-                ("has_bn", ctypes.c_int32), ("leaky", ctypes.c_int32),
+                ("has_bn", ctypes.c_int32), ("leaky", ctypes.c_int32), ("wino_planes", ctypes.c_int32),
                 ("w_off", ctypes.c_int64), ("scale_off", ctypes.c_int64), ("shift_off", ctypes.c_int64),
                 ("wino_off", ctypes.c_int64), ("w16_off", ctypes.c_int64)]
 
@@ -65,6 +65,8 @@ SIGNATURES = {
     "om_conv2d_winograd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "om_layer_output_view": (_i, [_vp, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int),
                                   ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "om_conv2d_winograd24_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "om_conv2d_winograd24": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "om_profile_enable": (_i, [_vp, _i]),
     "om_profile_enable_layers": (_i, [_vp, ctypes.c_char_p, _i]),
     "om_profile_read": (_i, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _i,

@@ -276,8 +276,8 @@ class OrienMaskYOLOFPNPlus(nn.Module):
             bm, bn, algo = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
             _lib.check(_lib.load().om_layer_tile(h, i, B, H, W, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(algo)),
                        "om_layer_tile")
-            fmt = ("conv_stem_kernel", "conv_igemm_f32_kernel<%d,%d>", "wino_gemm_kernel<%d,%d>",
-                   "wino_fused_kernel<%d,%d>")[algo.value]
+            fmt = {0: "conv_stem_kernel", 1: "conv_igemm_f32_kernel<%d,%d>", 2: "wino_gemm_kernel<%d,%d>",
+                   3: "wino_fused_kernel<%d,%d>", 5: "wino24_gemm_kernel<%d,%d>"}[algo.value]
             out.append((l["name"], fmt % ((bm.value, bn.value) if algo.value else ())))
         return out
 

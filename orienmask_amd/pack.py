@@ -29,7 +29,7 @@ def graph_layers(handle):
         out.append(dict(name=info.name.decode(), cin=info.cin, cout=info.cout, cout_pad=info.cout_pad,
                         ksize=info.ksize, stride=info.stride, has_bn=bool(info.has_bn), leaky=bool(info.leaky),
                         w_off=info.w_off, scale_off=info.scale_off, shift_off=info.shift_off,
-                        wino_off=info.wino_off, w16_off=info.w16_off))
+                        wino_off=info.wino_off, wino_planes=info.wino_planes, w16_off=info.w16_off))
     return out
 
 
@@ -55,11 +55,19 @@ def unwrap_checkpoint(obj):
 _WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
 
 
-def winograd_weights(w, cout_pad):
-    """[cout,cin,3,3] -> U [16][cout_pad][cin] float32 (rows >= cout zero), computed in float64."""
+# F(4,3) kernel transform with points {0, +-1, +-2}: the column transform of F(2x4,3x3)
+_WINO_G6 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                         [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
+
+
+def winograd_weights(w, cout_pad, planes=16):
+    """[cout,cin,3,3] -> U [planes][cout_pad][cin] float32 (rows >= cout zero), computed in float64.
+    planes = 16: F(2x2,3x3), U[4 i + j] = G[i] g G[j]^T;  planes = 24: F(2x4,3x3), U[6 i + j] = G[i] g G6[j]^T
+    (i: transform index down the rows, j: along the columns)."""
     cout, cin = w.shape[0], w.shape[1]
-    u = torch.einsum("ir,ncrs,js->ijnc", _WINO_G, w.detach().double().cpu(), _WINO_G).reshape(16, cout, cin)
-    out = torch.zeros(16, cout_pad, cin, dtype=torch.float32)
+    gx = _WINO_G if planes == 16 else _WINO_G6
+    u = torch.einsum("ir,ncrs,js->ijnc", _WINO_G, w.detach().double().cpu(), gx).reshape(planes, cout, cin)
+    out = torch.zeros(planes, cout_pad, cin, dtype=torch.float32)
     out[:, :cout] = u.float()
     return out
 
@@ -88,7 +96,8 @@ def pack_state_dict(state_dict, layers, total_floats):
         blob[l["scale_off"]:l["scale_off"] + cout] = scale.float()
         blob[l["shift_off"]:l["shift_off"] + cout] = shift.float()
         if l.get("wino_off", -1) >= 0:
-            blob[l["wino_off"]:l["wino_off"] + 16 * cpad * cin] = winograd_weights(w, cpad).reshape(-1)
+            planes = l.get("wino_planes", 16) or 16
+            blob[l["wino_off"]:l["wino_off"] + planes * cpad * cin] = winograd_weights(w, cpad, planes).reshape(-1)
     return blob
 
 

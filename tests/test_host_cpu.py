@@ -78,13 +78,22 @@ def test_pack_folds_batchnorm(built):
     assert torch.equal(blob[l["shift_off"]:l["shift_off"] + 255], sd["bbox_head16.1.bias"])
     assert blob[l["w_off"] + 255 * 512:l["w_off"] + 256 * 512].abs().sum() == 0
     assert l["wino_off"] == -1
-    # Winograd weights of a stride-1 3x3 layer: U = G g G^T; xi = 0 is g[0][0], xi = 15 is g[2][2],
-    # xi = 5 is the sum of all nine taps / 4
+    # Winograd weights of a stride-1 3x3 layer: U = G_y g G_x^T.  16 planes (F(2x2,3x3)): xi = 0 is g[0][0], xi = 15 is
+    # g[2][2], xi = 5 is the sum of all nine taps / 4.  24 planes (F(2x4,3x3)): xi = 0 is g[0][0] / 4, xi = 23 is g[2][2],
+    # xi = 6 + 1 is -(sum of all nine taps) / 12.
     l = by_name["backbone.conv3.1.conv.1"]
     assert l["wino_off"] >= 0 and by_name["backbone.conv3.0"]["wino_off"] == -1 and by_name["backbone.conv1"]["wino_off"] == -1
-    u = blob[l["wino_off"]:l["wino_off"] + 16 * 128 * 64].view(16, 128, 64)
-    assert torch.equal(u[0], w[:, :, 0, 0]) and torch.equal(u[15], w[:, :, 2, 2])
-    assert torch.allclose(u[5], w.double().sum((2, 3)).float() / 4, rtol=1e-6, atol=1e-8)
+    assert by_name["backbone.conv3.0"]["wino_planes"] == 0 and l["wino_planes"] in (16, 24)
+    planes = l["wino_planes"]
+    u = blob[l["wino_off"]:l["wino_off"] + planes * 128 * 64].view(planes, 128, 64)
+    if planes == 16:
+        assert torch.equal(u[0], w[:, :, 0, 0]) and torch.equal(u[15], w[:, :, 2, 2])
+        assert torch.allclose(u[5], w.double().sum((2, 3)).float() / 4, rtol=1e-6, atol=1e-8)
+    else:
+        assert torch.equal(u[0], w[:, :, 0, 0] / 4) and torch.equal(u[23], w[:, :, 2, 2])
+        assert torch.allclose(u[7], -(w.double().sum((2, 3)) / 12).float(), rtol=1e-6, atol=1e-8)
+    # the 1/32-scale layers keep F(2x2): too few 2 x 4 tiles at 17 x 17
+    assert by_name["backbone.conv6.1.conv.1"]["wino_planes"] == 16
 
 
 def test_registry_builders_mirror_reference(built):
