@@ -243,7 +243,9 @@ def main():
         traffic, traffic_src = None, None
         try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.sh)
             pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic_f16.json" if f16 else "r01_pmc_traffic.json")))
-            key = [k for k in pmc if k.replace(" ", "").startswith(dom.rstrip(">").replace(" ", ""))]
+            norm = lambda k: k.replace(" ", "")
+            key = [k for k in pmc if norm(k).startswith(norm(dom).rstrip(">"))] or \
+                  [k for k in pmc if k.split("<")[0] == dom.split("<")[0]]        # a non-template kernel has no <BM,BN> in its symbol
             if key and B == 32 and H == 544:
                 traffic = round(pmc[key[0]]["hbm_bytes_per_launch_corrected"])
                 traffic_src = ("profiles/r01_pmc_traffic%s.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate " % ("_f16" if f16 else "") +
