@@ -36,6 +36,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 WEIGHT_SEED, OBJ_BIAS, HEAD_GAIN = 3, -16.0, 4.0
+OBJ_BIAS_SPARSE = -18.5     # a few tens of detections per image (-18: 67, -19: 11, -20: 3, <= -24: none)
 
 
 def post_config(h, w):
@@ -116,6 +117,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the preprocess / COCO-format side measurements")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
+    ap.add_argument("--heads", choices=("dense", "sparse"), default="dense",
+                    help="head statistics of the seeded weights (SURVEY.md 8d Config 3 asks for both): dense = every image yields "
+                         ">400 candidates and 100 detections (the default, worst case for the postprocess); sparse = a few tens")
+    ap.add_argument("--obj-bias", type=float, default=None, help="override the objectness bias of the synthetic weights")
     ap.add_argument("--streams", type=int, default=1,
                     help="forward as N sub-batches on N HIP streams in the timed region (model.set_streams); the default 1 is "
                          "what the roofline figures assume (per-kernel events time overlapping kernels otherwise)")
@@ -145,11 +150,12 @@ def main():
 
     H = W = args.size
     B = args.batch
+    obj_bias = args.obj_bias if args.obj_bias is not None else (OBJ_BIAS if args.heads == "dense" else OBJ_BIAS_SPARSE)
     net = OrienMaskYOLOFPNPlus(3, 80).eval().set_precision(args.dtype)
     f16 = args.dtype == "f16"
     sd = None
     if rank == 0:
-        sd = synth.synth_state_dict(WEIGHT_SEED, obj_bias=OBJ_BIAS, head_gain=HEAD_GAIN)
+        sd = synth.synth_state_dict(WEIGHT_SEED, obj_bias=obj_bias, head_gain=HEAD_GAIN)
         net.load_state_dict(sd, strict=True)
     broadcast_packed_weights(net, dev, src=0)                      # one RCCL broadcast, untimed
     post = OrienMaskYOLOPostProcess(device=dev, **post_config(H, W))
@@ -295,8 +301,9 @@ def main():
                     vs_baseline=None, dtype=args.dtype, data="synthetic",
                     config=dict(workload="OrienMaskYOLOFPNPlus forward + OrienMaskYOLOPostProcess, %d x [3,%d,%d] per GPU "
                                          "(BASELINE configs[2]); seeded random-init weights (seed %d, obj_bias %g, head_gain %g): "
-                                         ">400 candidates pass conf_thresh per image, NMS, 100 masks per image"
-                                         % (B, H, W, WEIGHT_SEED, OBJ_BIAS, HEAD_GAIN),
+                                         "%s heads (dense: >400 candidates pass conf_thresh per image, NMS, 100 masks per image; "
+                                         "sparse: a few tens of detections per image)"
+                                         % (B, H, W, WEIGHT_SEED, obj_bias, HEAD_GAIN, args.heads),
                                 per_gpu_batch=B, image_size=[H, W], forward_streams=args.streams, detections_per_image=round(sum(int(d_["bbox"].shape[0]) for d_ in dets) / B, 1),
                                 parallelism="batch shard x%d, one RCCL weight broadcast, no collective in the step" % world),
                     roofline=roofline)
