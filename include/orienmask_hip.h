@@ -57,6 +57,8 @@ typedef struct om_layer_info {
     int64_t w_off, scale_off, shift_off;
     int64_t wino_off;           /* >= 0: Winograd weights U = G_y g G_x^T, [wino_planes][cout_pad][cin], plane index
                                    = 4 i + j (16) or 6 i + j (24), for the stride-1 3x3 layers; -1: none */
+    int64_t wino_alt_off;       /* wino_planes == 24 only: the layer's F(2x2,3x3) weights [16][cout_pad][cin] as well, used when
+                                   the batch is too small for the 2 x 4 tiling to fill the chip; -1 otherwise */
     int64_t w16_off;            /* fp16 path: offset IN HALFS into the fp16 weight blob (om_model_load_weights_f16):
                                    [cout_pad][ksize*ksize][cin] fp16 (rows >= cout zero); -1: the stem (always fp32) */
 } om_layer_info;

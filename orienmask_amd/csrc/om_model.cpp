@@ -92,6 +92,7 @@ struct om_model {
         L.info.scale_off = (int64_t)weight_floats; weight_floats += L.info.cout_pad;
         L.info.shift_off = (int64_t)weight_floats; weight_floats += L.info.cout_pad;
         L.info.wino_off = -1;
+        L.info.wino_alt_off = -1;
         L.info.wino_planes = 0;
         if (ks == 3 && stride == 1 && !stem && L.info.cout_pad % 64 == 0 && cin % 32 == 0) {
             // F(2x4,3x3) (24 planes) for the layers that run the unfused transform + GEMM pair; the fused-loader layers
@@ -104,6 +105,12 @@ struct om_model {
             weight_floats = om::align_up(weight_floats, 4);
             L.info.wino_off = (int64_t)weight_floats;
             weight_floats += (size_t)L.info.wino_planes * L.info.cout_pad * cin;
+            if (L.info.wino_planes == 24) {
+                // small problems (a few images) have too few 2 x 4 tiles to fill the chip: those forwards use F(2x2,3x3)
+                weight_floats = om::align_up(weight_floats, 4);
+                L.info.wino_alt_off = (int64_t)weight_floats;
+                weight_floats += (size_t)16 * L.info.cout_pad * cin;
+            }
         }
         L.info.w16_off = -1;
         if (!stem) {
@@ -207,13 +214,22 @@ struct om_model {
         add("orien_head.5", 256, A * 6, 1, 1, false, o, 4, View{om::BUF_ORIENS, 0}, nullptr, 2, 1);
     }
 
+    // F(2x4,3x3) needs enough tiles to fill the chip: measured at 544^2, bs=4 is 4 % faster with F(2x2) and bs=8 is 4 % faster
+    // with F(2x4); the switch is on the number of 1/32-scale cells in the batch (289 per 544^2 image).  OM_WINO_F24_MIN_CELLS
+    // overrides the threshold.
+    static bool use_f24(int B, int H, int W) {
+        static const long long min_cells = [] { const char* e = getenv("OM_WINO_F24_MIN_CELLS"); return e ? atoll(e) : 1700ll; }();
+        return (long long)B * (H / 32) * (W / 32) >= min_cells;
+    }
+
     // largest transformed-input scratch any Winograd layer needs at this problem size
     size_t wino_floats(int B, int H, int W) const {
         size_t mx = 0;
         for (const om::LayerDef& L : layers)
             if (L.info.wino_off >= 0) {
-                const size_t f = L.info.wino_planes == 24 ? om::wino24_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin)
-                                                          : om::wino_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin);
+                const size_t f = (L.info.wino_planes == 24 && use_f24(B, H, W))
+                                     ? om::wino24_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin)
+                                     : om::wino_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin);
                 if (f > mx) mx = f;
             }
         return mx;
@@ -387,10 +403,14 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             a.out_mode = L.out_mode; a.up = L.up;
             a.ticket = tickets + (&L - m->layers.data());
             if (li.wino_off >= 0 && om::wino_enabled()) {
-                a.w = m->weights + li.wino_off;
                 a.mid_event = ev_mid;
-                rc = li.wino_planes == 24 ? om::launch_conv_winograd24(a, wino_scratch, stream)
-                                          : om::launch_conv_winograd(a, wino_scratch, stream);
+                if (li.wino_planes == 24 && om_model::use_f24(B, H, W)) {
+                    a.w = m->weights + li.wino_off;
+                    rc = om::launch_conv_winograd24(a, wino_scratch, stream);
+                } else {
+                    a.w = m->weights + (li.wino_planes == 24 ? li.wino_alt_off : li.wino_off);
+                    rc = om::launch_conv_winograd(a, wino_scratch, stream);
+                }
             } else {
                 if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));     // single-kernel layer: mid == start
                 rc = om::launch_conv_igemm(a, stream);
@@ -470,7 +490,7 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
     OM_REQUIRE(index >= 0 && index < (int)m->layers.size(), OM_EINVAL, "om_layer_tile: index %d", index);
     const om::LayerDef& L = m->layers[index];
     if (L.stem) { *bm = 0; *bn = 0; *algo = 0; return OM_OK; }
-    if (L.info.wino_off >= 0 && om::wino_enabled() && L.info.wino_planes == 24) {
+    if (L.info.wino_off >= 0 && om::wino_enabled() && L.info.wino_planes == 24 && om_model::use_f24(B, H, W)) {
         *algo = 5; *bm = 64; *bn = 64;
         return OM_OK;
     }

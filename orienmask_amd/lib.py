@@ -19,7 +19,7 @@ class LayerInfo(ctypes.Structure):
                 ("ksize", ctypes.c_int32), ("stride", ctypes.c_int32),
                 ("has_bn", ctypes.c_int32), ("leaky", ctypes.c_int32), ("wino_planes", ctypes.c_int32),
                 ("w_off", ctypes.c_int64), ("scale_off", ctypes.c_int64), ("shift_off", ctypes.c_int64),
-                ("wino_off", ctypes.c_int64), ("w16_off", ctypes.c_int64)]
+                ("wino_off", ctypes.c_int64), ("wino_alt_off", ctypes.c_int64), ("w16_off", ctypes.c_int64)]
 
 
 class PostCfg(ctypes.Structure):

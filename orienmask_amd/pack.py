@@ -29,7 +29,8 @@ def graph_layers(handle):
         out.append(dict(name=info.name.decode(), cin=info.cin, cout=info.cout, cout_pad=info.cout_pad,
                         ksize=info.ksize, stride=info.stride, has_bn=bool(info.has_bn), leaky=bool(info.leaky),
                         w_off=info.w_off, scale_off=info.scale_off, shift_off=info.shift_off,
-                        wino_off=info.wino_off, wino_planes=info.wino_planes, w16_off=info.w16_off))
+                        wino_off=info.wino_off, wino_planes=info.wino_planes, wino_alt_off=info.wino_alt_off,
+                        w16_off=info.w16_off))
     return out
 
 
@@ -98,6 +99,8 @@ def pack_state_dict(state_dict, layers, total_floats):
         if l.get("wino_off", -1) >= 0:
             planes = l.get("wino_planes", 16) or 16
             blob[l["wino_off"]:l["wino_off"] + planes * cpad * cin] = winograd_weights(w, cpad, planes).reshape(-1)
+            if l.get("wino_alt_off", -1) >= 0:       # the F(2x2) planes next to the F(2x4) ones (small-batch forwards)
+                blob[l["wino_alt_off"]:l["wino_alt_off"] + 16 * cpad * cin] = winograd_weights(w, cpad, 16).reshape(-1)
     return blob
 
 

@@ -703,6 +703,23 @@ def test_forward_f16_matches_oracle(dev, batch, size):
     print("fp16 forward vs oracle.forward_f16: worst rel err %.3e" % worst)
 
 
+def test_forward_bs6_uses_f24_and_matches_oracle(dev):
+    """From 1700 1/32-scale cells on (bs >= 6 at 544x544) the stride-1 3x3 layers run Winograd F(2x4,3x3); below, F(2x2,3x3).
+    Head tensors of a 6-image batch against the oracle, and the switch itself as om_layer_tile reports it."""
+    sd = synth.synth_state_dict(9, obj_bias=-16.0, head_gain=4.0)
+    x = synth.synth_image_batch(26, 6, 544, 544)
+    net = _hip_model(sd, dev)
+    with torch.no_grad():
+        out = net(x.to(dev))
+    torch.cuda.synchronize()
+    k6 = dict(net.layer_kernels(6, 544, 544)); k2 = dict(net.layer_kernels(2, 544, 544))
+    assert k6["orien_head.2"].startswith("wino24_gemm") and k2["orien_head.2"].startswith("wino_gemm")
+    assert k6["backbone.conv6.2.conv.1"].startswith("wino_gemm")          # 1/32 scale: always F(2x2)
+    ref = R.forward(sd, x)
+    for (gb, go), (rb, ro) in zip(out, ref):
+        assert _rel_err(gb.cpu(), rb) < REL_TOL and _rel_err(go.cpu(), ro) < REL_TOL
+
+
 def test_backbone_features_bs8_match_oracle(dev):
     """BASELINE configs[1]: DarkNet-53 only, random weights, bs=8 at 544x544 -- x4 / x8 / x16 / x32 as the HIP kernels
     left them in the workspace vs the CPU oracle's backbone, <= 1e-4 of each tensor's scale."""

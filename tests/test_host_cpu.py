@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(built):
 
 
 def test_struct_layouts_match_header(built):
-    assert ctypes.sizeof(omlib.LayerInfo) == 64 + 7 * 4 + 4 + 5 * 8      # 4 bytes of padding before the int64s
+    assert ctypes.sizeof(omlib.LayerInfo) == 64 + 8 * 4 + 6 * 8
     assert ctypes.sizeof(omlib.PostCfg) == 4 * (1 + 3 + 3 + 2 + 1 + 9 + 9 + 9 + 1 + 2 + 2 + 1 + 1)
 
 
