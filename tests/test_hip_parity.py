@@ -564,15 +564,15 @@ def test_coco_formatter_end_to_end(dev):
             i += 1
 
 
-@pytest.mark.parametrize("batch", [1, 4])
-def test_graphed_pipeline_matches_eager(dev, batch):
+@pytest.mark.parametrize("batch,prec", [(1, "f32"), (4, "f32"), (2, "f16")])
+def test_graphed_pipeline_matches_eager(dev, batch, prec):
     """hipGraph replay of forward + postprocess == the eager call sequence, bit for bit.  Replays run back to back
     on fresh inputs with no eager call on the same workspaces in between (an eager call re-clears the tile-queue
     tickets and the radix histograms, which once hid a replay that did not), and the eager side is a second
     model / postprocess instance."""
     from orienmask_amd.graph import GraphedPipeline
     sd = synth.synth_state_dict(3, obj_bias=-16.0, head_gain=4.0)
-    net, net_ref = _hip_model(sd, dev), _hip_model(sd, dev)
+    net, net_ref = _hip_model(sd, dev).set_precision(prec), _hip_model(sd, dev).set_precision(prec)
     post, post_ref = _hip_post((544, 544), dev), _hip_post((544, 544), dev)
     xs = [synth.synth_image_batch(801 + i, batch, 544, 544).to(dev) for i in range(3)]
     pipe = GraphedPipeline(net, post, xs[0])
