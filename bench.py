@@ -10,15 +10,22 @@ synthetic 544x544 images already resident in HBM (BASELINE.json configs[2]).  Ea
 batch (weak scaling, no collective in the timed region); rank 0's packed weights are broadcast once
 over RCCL before timing.  Rank 0 prints ONE JSON line.
 
-roofline:     the dominant kernel (the Winograd GEMM on the f32 matrix cores).  achieved = ALGORITHMIC
-              (direct-convolution) FLOPs of the layers it runs / their summed duration, measured live with
-              HIP events on the launch stream over the timed steps (om_profile_*); peak = 157.3 TFLOP/s
-              (f32-input MFMA, MI355X_MICROARCH.md).  The forward is FLOP-bound in fp32 (SURVEY.md 8d);
-              Winograd executes 2.25x fewer multiplies, which is how frac can exceed 1 (executed_* fields).
-cpu_baseline: the CPU oracle (torch-CPU restatement of the reference, oracle/) on the host cores, on a
-              bounded sample, N=1 only.  Checker code, timed beside the product, never part of it.
+roofline:     the dominant kernel (the Winograd convolution on the f32 matrix cores).  achieved = the FLOPs the matrix
+              pipe EXECUTED for the layers it runs (Winograd F(2x4,3x3): 1/3 of the direct-convolution count, F(2x2,3x3):
+              1/2.25) / their summed duration INCLUDING the layer's input-transform pre-pass where there is one, measured
+              live with HIP events on the launch stream over the timed steps (om_profile_*); peak = 157.3 TFLOP/s
+              (f32-input MFMA, MI355X_MICROARCH.md); frac = achieved / peak, always <= 1.  The direct-convolution
+              ("algorithmic") rate of the same layers is reported next to it as achieved_algorithmic.  The forward is
+              FLOP-bound in fp32; the HBM figures (forward_hbm_*, conv_stack_hbm_pmc) are beside it.
+              traffic = HBM bytes per launch from the committed rocprofv3 PMC passes of this same bench -- printed only
+              when that file was measured with the library binary that is running now (sha256), else null.
+cpu_baseline: the CPU oracle (torch-CPU restatement of the reference, oracle/) on the host cores: thread-count sweep,
+              forward and postprocess timed separately at bs=1 and on the bench batch, N=1 only.  Checker code, timed
+              beside the product, never part of it.
 """
 import argparse
+import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -45,30 +52,79 @@ def post_config(h, w):
                 nms_pre=400, nms_post=100, orien_thresh=0.3)
 
 
-def cpu_baseline(sd, x_cpu, target_seconds=12.0, f16=False):
-    """Oracle forward + postprocess on the host cores; bounded sample of the same workload."""
+def cpu_baseline(sd, x_cpu, f16=False, budget_s=30.0):
+    """Oracle forward and postprocess on the host cores: thread sweep {8, 32, all} on one image, then with
+    the best count: bs=1 forward / postprocess, and the bench batch itself (or as many images of it as the budget allows)."""
     from oracle import orienmask_ref as R
     fwd = R.forward_f16 if f16 else R.forward
     h, w = x_cpu.shape[2], x_cpu.shape[3]
     pc = post_config(h, w)
     post = R.PostProcessOracle(pc["grid_size"], pc["image_size"], pc["anchors"], pc["anchor_mask"], 80,
                                conf_thresh=pc["conf_thresh"])
-    cores = torch.get_num_threads()
-    sample = x_cpu[:2]
-    post(fwd(sd, sample[:1]))                                      # warm-up
-    t0 = time.perf_counter()
-    n_img = 0
-    reps = 0
-    while True:
-        post(fwd(sd, sample))
-        n_img += sample.shape[0]
-        reps += 1
-        if time.perf_counter() - t0 >= target_seconds or reps >= 20:
-            break
-    dt = time.perf_counter() - t0
-    return dict(value=round(n_img / dt, 4), unit="images/s", cores=cores, kind="port",
-                sample="%d reps of forward+postprocess on 2 images (544x544) of the bench batch, torch-CPU oracle, "
-                       "%d threads" % (reps, cores))
+    ncpu = os.cpu_count() or 1
+    t_start = time.perf_counter()
+    one = x_cpu[:1]
+    sweep = {}
+    for nt in sorted({min(8, ncpu), min(32, ncpu), ncpu}):
+        torch.set_num_threads(nt)
+        fwd(sd, one)                                                   # warm-up at this thread count
+        t0 = time.perf_counter()
+        pred = fwd(sd, one)
+        sweep[nt] = time.perf_counter() - t0
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    t0 = time.perf_counter(); pred = fwd(sd, one); f1 = time.perf_counter() - t0
+    t0 = time.perf_counter(); post(pred); p1 = time.perf_counter() - t0
+    left = budget_s - (time.perf_counter() - t_start)
+    nb = int(max(2, min(x_cpu.shape[0], left / max(f1 * 0.8 + p1, 1e-3))))      # batched forward is a little cheaper per image
+    batch = x_cpu[:nb]
+    t0 = time.perf_counter(); pred = fwd(sd, batch); fb = time.perf_counter() - t0
+    t0 = time.perf_counter(); post(pred); pb = time.perf_counter() - t0
+    return dict(value=round(nb / (fb + pb), 4), unit="images/s", cores=best, kind="port",
+                sample="torch-CPU oracle (oracle/orienmask_ref.py), forward + postprocess of %d of the bench batch's %d images "
+                       "(544x544) in one call, %d threads (best of the sweep)" % (nb, x_cpu.shape[0], best),
+                host_cpus=ncpu,
+                thread_sweep_forward_bs1_ms={str(k): round(v * 1e3, 1) for k, v in sweep.items()},
+                bs1=dict(forward_ms=round(f1 * 1e3, 1), postprocess_ms=round(p1 * 1e3, 1),
+                         images_per_s=round(1.0 / (f1 + p1), 4)),
+                batch=dict(images=nb, forward_ms=round(fb * 1e3, 1), postprocess_ms=round(pb * 1e3, 1),
+                           images_per_s=round(nb / (fb + pb), 4)))
+
+
+def lib_sha256():
+    from orienmask_amd import lib as omlib
+    return hashlib.sha256(open(omlib.LIB_PATH, "rb").read()).hexdigest()
+
+
+def post_occupancy(B, post_cfg_):
+    """Occupancy of the three postprocess kernels against the gfx950 limits (8 waves per SIMD = 32 per CU, 160 KiB of LDS):
+    what the registers and LDS allow per CU, and what the launch geometry actually puts on the chip."""
+    from orienmask_amd import lib as omlib
+    L = omlib.load()
+    names = ["post_decode_kernel", "post_select_kernel", "post_mask_kernel"]
+    h, w = post_cfg_["image_size"]
+    npairs = sum(3 * gh * gw for gh, gw in post_cfg_["grid_size"]) * 80
+    grids = [((npairs + 2047) // 2048) * B, B, ((h // 4 + 1) * (w // 16) + 255) // 256 * B * 9]
+    out = {}
+    for i, name in enumerate(names):
+        t, v, l, nb = (ctypes.c_int(0) for _ in range(4))
+        omlib.check(L.om_post_kernel_occupancy(i, ctypes.byref(t), ctypes.byref(v), ctypes.byref(l), ctypes.byref(nb)),
+                    "om_post_kernel_occupancy")
+        waves_per_wg = t.value // 64
+        alloc = (v.value + 7) // 8 * 8
+        by_regs = min(8, 512 // max(alloc, 1))
+        by_lds = (160 * 1024) // l.value if l.value else 99
+        wg_per_cu = nb.value
+        waves_per_simd = min(8.0, wg_per_cu * waves_per_wg / 4.0)
+        resident_wgs = min(grids[i], wg_per_cu * 256)
+        out[name] = dict(threads_per_workgroup=t.value, vgprs=v.value, lds_bytes_per_workgroup=l.value,
+                         workgroups_per_cu=wg_per_cu, waves_per_simd=waves_per_simd, limit_waves_per_simd=8,
+                         occupancy_frac=round(waves_per_simd / 8.0, 3),
+                         limited_by=("registers" if by_regs * 4 // waves_per_wg <= min(by_lds, 32 // waves_per_wg) else
+                                     "lds" if by_lds < 32 // waves_per_wg else "waves"),
+                         grid_workgroups=grids[i],
+                         chip_wave_slots_used_frac=round(resident_wgs * waves_per_wg / (256 * 32.0), 4))
+    return out
 
 
 def measure_neighbours(dev, dets, B):
@@ -110,7 +166,7 @@ def measure_neighbours(dev, dets, B):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (metric is quoted at 32)")
     ap.add_argument("--size", type=int, default=544)
@@ -187,7 +243,7 @@ def main():
     post_ms = sum(a.elapsed_time(b) for a, b in post_ev) / n_prof
     by_kernel = {}
     for name, ms, pre in layer_ms:
-        by_kernel[kernel_of[name]] = by_kernel.get(kernel_of[name], 0.0) + ms
+        by_kernel[kernel_of[name]] = by_kernel.get(kernel_of[name], 0.0) + ms + pre
     dom = max(by_kernel, key=by_kernel.get)
     dom_layers = [name for name, _, _ in layer_ms if kernel_of[name] == dom]
 
@@ -217,66 +273,109 @@ def main():
     net.profile_enable(False)
     net.set_streams(1)
     timed_fw //= max(args.streams, 1)                              # one om_forward per sub-batch
-    dom_timed_ms = sum(ms for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw     # per step, all launches
+    dom_main_ms = sum(ms for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw      # per step, all launches
+    dom_timed_ms = dom_main_ms + sum(pre for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw
 
     if rank == 0:
         kern = {}
 
-        def acc(name, ms, flops, exec_flops, byts):
-            t = kern.setdefault(name, dict(ms=0.0, flops=0.0, exec_flops=0.0, bytes=0.0, launches=0))
-            t["ms"] += ms; t["flops"] += flops; t["exec_flops"] += exec_flops; t["bytes"] += byts; t["launches"] += 1
+        def acc(name, ms, flops, exec_flops, byts, pre_ms=0.0):
+            t = kern.setdefault(name, dict(ms=0.0, pre_ms=0.0, flops=0.0, exec_flops=0.0, bytes=0.0, launches=0))
+            t["ms"] += ms; t["pre_ms"] += pre_ms; t["flops"] += flops; t["exec_flops"] += exec_flops; t["bytes"] += byts
+            t["launches"] += 1
 
+        def reduction(k):
+            # multiplies the matrix pipe executes per direct-convolution multiply: F(2x4,3x3) 24 per 8 outputs instead of 72,
+            # F(2x2,3x3) 16 per 4 outputs instead of 36
+            return 3.0 if k.startswith("wino24") else (2.25 if k.startswith("wino") else 1.0)
+
+        pre_kernel = {}
         for name, ms, pre in layer_ms:
             wk = arch.layer_work(specs[name], B, H, W)
             k = kernel_of[name]
-            wino = k.startswith("wino")
-            # Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36 -> executed = algorithmic / 2.25
             # fp16 configuration: every activation and weight element is 2 bytes (the fp32 heads are < 1 % of the bytes)
-            # F(2x4,3x3): 24 multiplies per 8 outputs instead of 72 -> executed = algorithmic / 3
-            red = 3.0 if k.startswith("wino24") else (2.25 if wino else 1.0)
-            acc(k, ms / n_fw, wk["flops"], wk["flops"] / red, wk["bytes"] / (2 if f16 else 1))
-            if k.startswith("wino_gemm") or k.startswith("wino24_gemm"):
+            acc(k, ms / n_fw, wk["flops"], wk["flops"] / reduction(k), wk["bytes"] / (2 if f16 else 1), pre / n_fw)
+            if pre > 0 and (k.startswith("wino_gemm") or k.startswith("wino24_gemm")):
                 vx = 3.0 if k.startswith("wino24") else 4.0       # transformed input: 3x / 4x the activation, plus reading it
-                acc("wino24_input_kernel" if k.startswith("wino24") else "wino_input_kernel", pre / n_fw, 0.0, 0.0,
-                    (1.0 + vx) * 4 * B * (H // arch.layer_div(specs[name])) ** 2 * specs[name].cin)
+                pk = "wino24_input_kernel" if k.startswith("wino24") else "wino_input_kernel"
+                pre_kernel[k] = pk
+                acc(pk, pre / n_fw, 0.0, 0.0, (1.0 + vx) * 4 * B * (H // arch.layer_div(specs[name])) ** 2 * specs[name].cin)
         d = kern[dom]
-        fwd_ms = sum(t["ms"] for t in kern.values())
-        # the dominant kernel's rate comes from the events recorded INSIDE the timed region
-        achieved = d["flops"] / (dom_timed_ms * 1e-3) / 1e12
+        fwd_ms = sum(t["ms"] for t in kern.values())              # pre-pass kernels are their own entries
+        # the dominant kernel's rate comes from the events recorded INSIDE the timed region; a layer's input-transform
+        # pre-pass belongs to the same convolution and is charged to it
+        achieved_alg = d["flops"] / (dom_timed_ms * 1e-3) / 1e12
         executed = d["exec_flops"] / (dom_timed_ms * 1e-3) / 1e12
+        executed_main_only = d["exec_flops"] / (dom_main_ms * 1e-3) / 1e12
         total_flops = sum(t["flops"] for t in kern.values())
-        total_bytes = sum(t["bytes"] for t in kern.values())
-        traffic, traffic_src = None, None
-        try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.sh)
-            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic_f16.json" if f16 else "r01_pmc_traffic.json")))
+        total_exec = sum(t["exec_flops"] for t in kern.values())
+        total_bytes = sum(t["bytes"] for t in kern.values() if t["flops"] > 0)
+        # ---- HBM traffic from the committed PMC passes, only if they were measured with THIS library binary
+        traffic, traffic_src, conv_stack = None, None, None
+        pmc_file = os.path.join(REPO, "profiles", "r02_pmc_traffic_f16.json" if f16 else "r02_pmc_traffic.json")
+        try:
+            pmc = json.load(open(pmc_file))
+            meta = pmc.pop("_meta", {})
             norm = lambda k: k.replace(" ", "")
-            key = [k for k in pmc if norm(k).startswith(norm(dom).rstrip(">"))] or \
-                  [k for k in pmc if k.split("<")[0] == dom.split("<")[0]]        # a non-template kernel has no <BM,BN> in its symbol
-            if key and B == 32 and H == 544:
-                traffic = round(pmc[key[0]]["hbm_bytes_per_launch_corrected"])
-                traffic_src = ("profiles/r01_pmc_traffic%s.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, separate " % ("_f16" if f16 else "") +
-                               "rocprofv3 --pmc passes of this bench at bs=32 (FETCH_SIZE doubled per MI355X_MICROARCH.md)")
-        except Exception:
-            pass
+            def find(kname):
+                key = [k for k in pmc if norm(k).startswith(norm(kname).rstrip(">"))] or \
+                      [k for k in pmc if k.split("<")[0] == kname.split("<")[0]]   # a non-template kernel has no <BM,BN> in its symbol
+                return pmc[key[0]] if key else None
+            if meta.get("lib_sha256") != lib_sha256():
+                traffic_src = ("%s was measured with another build of liborienmask_hip.so (sha256 %s...): not reported; rerun "
+                               "tools/pmc_traffic.sh" % (os.path.relpath(pmc_file, REPO), str(meta.get("lib_sha256"))[:12]))
+            elif meta.get("batch") != B or meta.get("size") != H:
+                traffic_src = "%s was measured at another problem size" % os.path.relpath(pmc_file, REPO)
+            else:
+                e = find(dom)
+                if e:
+                    traffic = round(e["hbm_bytes_per_launch_corrected"])
+                    if dom in pre_kernel and find(pre_kernel[dom]):
+                        traffic += round(find(pre_kernel[dom])["hbm_bytes_per_launch_corrected"])
+                    traffic_src = ("%s: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch%s, separate rocprofv3 --pmc passes of this "
+                                   "bench with this library binary (FETCH_SIZE doubled per MI355X_MICROARCH.md)"
+                                   % (os.path.relpath(pmc_file, REPO), " incl. the input-transform pre-pass" if dom in pre_kernel else ""))
+                tot_b, tot_ms, missing = 0.0, 0.0, []
+                for kname, t in kern.items():
+                    e = find(kname)
+                    if e is None:
+                        missing.append(kname)
+                        continue
+                    tot_b += e["hbm_bytes_per_launch_corrected"] * t["launches"]
+                    tot_ms += t["ms"]
+                conv_stack = dict(gbs=round(tot_b / (tot_ms * 1e-3) / 1e9, 1), frac_of_8tbs=round(tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                  bytes_per_step=round(tot_b), kernels_ms_per_step=round(tot_ms, 3), kernels_without_counters=missing,
+                                  note="rocprofv3 PMC HBM bytes of every convolution kernel of the forward / their summed durations in this run")
+        except FileNotFoundError:
+            traffic_src = "no %s" % os.path.relpath(pmc_file, REPO)
+        except Exception as e:      # a malformed file must not take the bench line down
+            traffic_src = "could not read %s: %s" % (os.path.relpath(pmc_file, REPO), e)
         peak_tf = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
-        roofline = dict(bound="mfma", achieved=round(achieved, 2), peak=peak_tf, unit="TFLOP/s",
-                        frac=round(achieved / peak_tf, 4), traffic=traffic, traffic_source=traffic_src,
-                        algorithmic_bytes_per_launch=round(d["bytes"] / d["launches"]),
-                        kernel=dom,
-                        launches_per_step=d["launches"], avg_launch_ms=round(dom_timed_ms / d["launches"], 4),
+        alg_bytes_per_launch = d["bytes"] / d["launches"]      # layer-fused model: input once, output once, residual once, weights
+        roofline = dict(bound="mfma", achieved=round(executed, 2), peak=peak_tf, unit="TFLOP/s",
+                        frac=round(executed / peak_tf, 4), traffic=traffic, traffic_source=traffic_src,
+                        algorithmic_bytes_per_launch=round(alg_bytes_per_launch),
+                        kernel=dom, pre_pass_kernel=pre_kernel.get(dom),
+                        launches_per_step=d["launches"], avg_launch_ms=round(dom_main_ms / d["launches"], 4),
+                        avg_launch_ms_with_pre_pass=round(dom_timed_ms / d["launches"], 4),
                         kernel_ms_per_step=round(dom_timed_ms, 3),
-                        measured="HIP events on the launch stream around every launch of this kernel inside the timed region; "
-                                 "the other per-kernel figures come from an untimed pass with events around all layers",
-                        executed_tflops=round(executed, 2), executed_frac=round(executed / peak_tf, 4),
+                        measured="HIP events on the launch stream around every launch of this kernel (and of its pre-pass) inside the "
+                                 "timed region; the other per-kernel figures come from an untimed pass with events around all layers",
+                        achieved_algorithmic=round(achieved_alg, 2),
+                        achieved_without_pre_pass=round(executed_main_only, 2),
                         note=("fp16 operands, fp32 accumulate on v_mfma_f32_32x32x16_f16 (dense peak 2.5 PFLOP/s); direct "
                               "convolution, executed = algorithmic") if f16 else
-                             ("achieved counts ALGORITHMIC (direct-convolution) flops; the Winograd F(2x2,3x3) kernels "
-                              "execute 2.25x fewer multiplies, so frac may exceed 1 -- executed_* is what the matrix "
-                              "pipe actually ran (exact fp32 MFMA)"),
+                             ("achieved = flops the f32 matrix pipe executed (exact fp32 MFMA; Winograd F(2x4,3x3) runs 1/3 of the "
+                              "direct-convolution multiplies) over the time of the GEMM kernel AND its input-transform pre-pass; "
+                              "achieved_algorithmic counts direct-convolution flops over the same time"),
                         forward_kernels_ms_per_step=round(fwd_ms, 3), postprocess_ms_per_step=round(post_ms, 3),
-                        forward_tflops=round(total_flops / (fwd_ms * 1e-3) / 1e12, 2),
+                        forward_tflops_algorithmic=round(total_flops / (fwd_ms * 1e-3) / 1e12, 2),
+                        forward_tflops_executed=round(total_exec / (fwd_ms * 1e-3) / 1e12, 2),
+                        forward_executed_frac=round(total_exec / (fwd_ms * 1e-3) / 1e12 / peak_tf, 4),
                         forward_hbm_algorithmic_gbs=round(total_bytes / (fwd_ms * 1e-3) / 1e9, 1),
                         forward_hbm_frac=round(total_bytes / (fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                        conv_stack_hbm_pmc=conv_stack,
+                        postprocess_occupancy=post_occupancy(B, post_config(H, W)),
                         binding=("fp16: matrix pipe and HBM are within 2x of each other (SURVEY.md 8d); forward_hbm_frac is the "
                                  "north_star's HBM-roofline figure") if f16 else
                                 "fp32 FLOPs on the f32-input matrix cores; the HBM bound is several x further away")
@@ -291,6 +390,7 @@ def main():
                 print("%-34s %3d launches %8.3f ms %7.2f TF algorithmic %7.2f TF executed %7.1f GB/s" % (
                     k, t["launches"], t["ms"], t["flops"] / (t["ms"] * 1e-3) / 1e12,
                     t["exec_flops"] / (t["ms"] * 1e-3) / 1e12, t["bytes"] / (t["ms"] * 1e-3) / 1e9), file=sys.stderr)
+            print("forward kernels %.3f ms, postprocess %.3f ms" % (fwd_ms, post_ms), file=sys.stderr)
         total_images = world * B * args.steps
         metric = "images/sec end-to-end (544^2, bs=32) forward+postprocess"
         if f16:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OM_VERSION 110          /* 0.1.1: fp16-activation path (om_*_f16), om_layer_info.w16_off */
+#define OM_VERSION 120          /* 0.1.2: om_post_cfg.nms_semantics / nms_normalized, om_nms_ex, om_ref_math */
 
 #define OM_OK 0
 #define OM_EINVAL (-1)          /* bad argument (null pointer, shape not supported) */
@@ -78,6 +78,15 @@ typedef struct om_post_cfg {
     float orien_thresh;                         /* 0.3 */
     int32_t bbox_pix_stride;                    /* floats between pixels of the NHWC bbox heads
                                                    (256 for om_forward's outputs) */
+    int32_t nms_semantics;                      /* which of the reference's two NMS backends (eval/function.py:98-101) the
+                                                   suppression follows:
+                                                   0 = nms_cpu (eval/src/nms_cpu.cpp:4-63): areas (x2-x1)*(y2-y1), suppress
+                                                       when IoU >= nms_thresh, survivors in ascending candidate order;
+                                                   1 = nms_cuda (eval/src/nms_kernel.cu:13-140): areas w*h, suppress when
+                                                       IoU > nms_thresh, survivors in score-descending order */
+    int32_t nms_normalized;                     /* batched_nms(normalized=...), eval/function.py:91-92: 1 = class offset
+                                                   cls * 2.0; 0 = cls * (max(x, y) + max(w, h) / 2 + 0.5) over the image's
+                                                   candidates */
 } om_post_cfg;
 
 int om_version(void);
@@ -198,6 +207,12 @@ int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbo
                    const float* oriens, int B, float* out_bbox, int64_t* out_cls, uint8_t* out_mask,
                    int32_t* out_count, int32_t* out_keep, void* workspace, size_t ws_bytes, om_stream stream);
 
+/* measurement: launch geometry and resource use of the three postprocess kernels (which: 0 = post_decode_kernel,
+ * 1 = post_select_kernel, 2 = post_mask_kernel) as the runtime reports them for this device: threads per workgroup, VGPRs
+ * per lane, static LDS bytes per workgroup and the number of workgroups one CU can hold (hipOccupancyMaxActiveBlocks...).
+ * bench.py turns them into waves/SIMD against the gfx950 limit of 8 (north_star: "occupancy for NMS/mask-assembly"). */
+int om_post_kernel_occupancy(int which, int* threads, int* vgprs, int* lds_bytes, int* max_blocks_per_cu);
+
 /* ---- COCO-format conversion ------------------------------------------------------------
  * om_recover_bbox: COCOMetrics._recover_shape_bbox, /root/reference/eval/coco_eval.py:146-189.
  *   bbox [K,stride] normalised (cx,cy,w,h,..) -> out_xywh [K,4] top-left x, y, w, h in original-image pixels.
@@ -213,11 +228,24 @@ int om_recover_masks_rle(const uint8_t* mask, int K, int H, int W, int crop_top,
                          int crop_right, int hflip, int vflip, int orig_h, int orig_w, uint32_t* counts, int max_runs,
                          int32_t* n_runs, uint8_t* resized_or_null, om_stream stream);
 
-/* ---- NMS (CPU-backend semantics of the reference: IoU >= thresh suppresses, corners from
- *      cx +- w/2, keep returned in ascending input order; n <= 1024) ------------------------ */
+/* ---- unit-test entry: the elementary functions the decode uses, restated bit-exactly from what torch-CPU runs at the
+ * reference's call sites eval/orienmask_yolo_postprocess.py:127-136 (csrc/ref_math.h).  func: 0 = glibc expf (torch's
+ * scalar loop), 1 = Sleef expf_u10 (torch's vectorised loop), 2 / 3 = sigmoid through either, 4 = sigmoid of a
+ * [rows][num_classes] array exactly as predict[..., 5:].sigmoid() evaluates it (classes below (C/32)*32 vectorised, the
+ * row tail scalar), 5 = correctly rounded expf. */
+int om_ref_math(const float* x, long long n, int func, int num_classes, float* y, om_stream stream);
+
+/* ---- NMS: the reference's native export nms(dets[n,5], threshold) -> keep (eval/src/nms_cpu.cpp:65-75,
+ *      eval/src/nms_cuda.cpp:8-17), n <= 65536 (0 from om_nms_workspace_bytes above that).
+ *      om_nms = om_nms_ex(semantics 0): the CPU backend (IoU >= thresh suppresses, areas from the corners cx +- w/2, keep
+ *      in ascending input order, nms_cpu.cpp:4-63).  semantics 1: the CUDA backend (IoU > thresh, areas w*h, keep in
+ *      score-descending order, nms_kernel.cu:13-140); score ties, which torch's CUDA sort leaves unspecified, are visited
+ *      in ascending input order. */
 size_t om_nms_workspace_bytes(int n);
 int om_nms(const float* dets, int n, float thresh, int64_t* keep, int32_t* n_keep, void* workspace,
            size_t ws_bytes, om_stream stream);
+int om_nms_ex(const float* dets, int n, float thresh, int semantics, int64_t* keep, int32_t* n_keep, void* workspace,
+              size_t ws_bytes, om_stream stream);
 
 #ifdef __cplusplus
 }

@@ -196,6 +196,35 @@ def nms_cpu(dets, threshold):
     return torch.from_numpy(np.nonzero(keep_flag)[0].astype(np.int64))
 
 
+_nms_cuda_lib = None
+
+
+def nms_cuda(dets, threshold):
+    """nms_cuda, /root/reference/eval/src/nms_kernel.cu:72-140, through the C restatement oracle/nms_cuda_ref.c (the CUDA
+    source itself cannot be built: THC headers are gone).  dets [n,5] (cx,cy,w,h,score); returns int64 keep indices in
+    SCORE-DESCENDING order (order_t[keep], :136-139).  The sort (:76, torch's CUDA sort: ties unspecified) is restated as a
+    stable descending sort, i.e. ties are visited in ascending index order."""
+    global _nms_cuda_lib
+    dets = dets.detach().to(torch.float32).contiguous()
+    n = dets.shape[0]
+    if n == 0:
+        return torch.zeros(0, dtype=torch.long)
+    if _nms_cuda_lib is None:
+        path = os.path.join(_HERE, "libnms_cuda_ref.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/libnms_cuda_ref.so not built; run `make -C oracle` or __graft_entry__.build()")
+        lib = ctypes.CDLL(path)
+        lib.nms_cuda_ref_f32.restype = ctypes.c_int
+        lib.nms_cuda_ref_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+        _nms_cuda_lib = lib
+    order = torch.sort(dets[:, 4].contiguous(), stable=True, dim=0, descending=True)[1]
+    sorted5 = dets[order].contiguous()
+    keep_sorted = np.zeros(n, dtype=np.int64)
+    m = _nms_cuda_lib.nms_cuda_ref_f32(sorted5.numpy().ctypes.data, n, ctypes.c_float(threshold), keep_sorted.ctypes.data)
+    assert m >= 0
+    return order[torch.from_numpy(keep_sorted[:m])]
+
+
 def nms_numpy(dets, threshold, order=None):
     """Same algorithm in numpy float32 (no C); used to cross-check nms_ref.c in tests."""
     d = np.asarray(dets, dtype=np.float32)
@@ -227,9 +256,10 @@ def nms_numpy(dets, threshold, order=None):
     return np.nonzero(~sup)[0].astype(np.int64)
 
 
-def batched_nms(dets, cats, threshold=0.5, normalized=True):
+def batched_nms(dets, cats, threshold=0.5, normalized=True, backend="cpu"):
     """batched_nms, /root/reference/eval/function.py:77-103: boxes of class c are shifted
-    by c * (1.5 + 0.5) in x and y so that different classes never overlap."""
+    by c * (1.5 + 0.5) in x and y so that different classes never overlap.  backend: which native
+    kernel function.py:98-101 dispatches to ("cpu": tensors on the host, "cuda": tensors on a GPU)."""
     if dets.shape[0] == 0:
         keep = torch.zeros(0, dtype=torch.long)
     else:
@@ -239,7 +269,7 @@ def batched_nms(dets, cats, threshold=0.5, normalized=True):
             max_coordinate = dets[:, :2].max() + dets[:, 2:4].max() / 2
         shifted = dets.clone()
         shifted[:, :2] += cats.float().view(-1, 1) * (max_coordinate + 0.5)
-        keep = nms_cpu(shifted, threshold)
+        keep = nms_cuda(shifted, threshold) if backend == "cuda" else nms_cpu(shifted, threshold)
     return dets[keep], cats[keep], keep
 
 
@@ -248,11 +278,27 @@ def batched_nms(dets, cats, threshold=0.5, normalized=True):
 # --------------------------------------------------------------------------------------
 
 
+class _single_thread:
+    """torch's CPU sigmoid over strided rows is not bit-reproducible across thread counts (a thread's linear element range may
+    start inside a row, which moves the boundary between the vectorised Sleef part and the scalar glibc tail of that row;
+    tools/gen_golden.py:single_thread has the details).  The oracle evaluates the decode under one thread, as the fixtures
+    were generated, so that its answer does not depend on the machine it runs on."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        torch.set_num_threads(1)
+
+    def __exit__(self, *a):
+        torch.set_num_threads(self.n)
+
+
 class PostProcessOracle:
     """OrienMaskYOLOPostProcess, /root/reference/eval/orienmask_yolo_postprocess.py:8-166."""
 
     def __init__(self, grid_size, image_size, anchors, anchor_mask, num_classes, conf_thresh=0.05,
-                 nms_thresh=0.5, nms_pre=400, nms_post=100, orien_thresh=0.3):
+                 nms_thresh=0.5, nms_pre=400, nms_post=100, orien_thresh=0.3, nms_backend="cpu", nms_normalized=True):
+        self.nms_backend = nms_backend
+        self.nms_normalized = nms_normalized
         self.grids = [(int(g[0]), int(g[1])) for g in grid_size]          # (nH, nW) per scale
         if isinstance(image_size, int):
             image_size = (image_size, image_size)
@@ -297,14 +343,17 @@ class PostProcessOracle:
         nh, nw = self.grids[i]
         na = len(self.anchor_mask[i])
         t = raw.reshape(na, -1, nh, nw).permute(0, 2, 3, 1).contiguous()      # postprocess.py:86
-        obj = t[..., 4].sigmoid().view(-1)
-        cls = t[..., 5:].sigmoid().view(-1, self.num_classes)
+        with _single_thread():
+            obj = t[..., 4].sigmoid().view(-1)
+            cls = t[..., 5:].sigmoid().view(-1, self.num_classes)
         conf = cls * obj.unsqueeze(-1)
         anc = self.norm_anchors[self.anchor_mask[i]]
         aw, ah = anc[:, 0:1], anc[:, 1:2]
         coord = t[..., 0:4]
-        coord[..., 0] = (coord[..., 0].sigmoid() + self.gx[i]) / nw
-        coord[..., 1] = (coord[..., 1].sigmoid() + self.gy[i]) / nh
+        with _single_thread():
+            sx, sy = coord[..., 0].sigmoid(), coord[..., 1].sigmoid()
+        coord[..., 0] = (sx + self.gx[i]) / nw
+        coord[..., 1] = (sy + self.gy[i]) / nh
         coord[..., 2] = coord[..., 2].exp() * aw.view(-1, 1, 1)
         coord[..., 3] = coord[..., 3].exp() * ah.view(-1, 1, 1)
         return coord.reshape(-1, 4), conf
@@ -340,7 +389,7 @@ class PostProcessOracle:
     def finish(self, coord, score, cls, anchor_idx, field):
         """multi_class_nms, postprocess.py:146-166."""
         dets = torch.cat([coord, score.unsqueeze(-1)], 1)
-        dets, cats, keep = batched_nms(dets, cls, self.nms_thresh)
+        dets, cats, keep = batched_nms(dets, cls, self.nms_thresh, self.nms_normalized, self.nms_backend)
         if keep.numel() > self.nms_post:
             _, top = dets[:, -1].topk(self.nms_post)
             dets = dets[top]; cats = cats[top]; keep = keep[top]

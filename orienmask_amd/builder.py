@@ -24,8 +24,10 @@ def build_func_partial(config, module, **kwargs):
 
 
 def build_postprocess(config, device):
+    """/root/reference/trainer/builder.py:73-77: `nms` is optional (no entry -> the default batched_nms)."""
     cfg = dict(config)
-    nms = build_func_partial(cfg.pop("nms"), _eval)
+    nms_config = cfg.pop("nms", None)
+    nms = build_func_partial(nms_config, _eval) if nms_config else None
     return build(cfg, _eval, nms_func=nms, device=device)
 
 

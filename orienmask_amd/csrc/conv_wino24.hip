@@ -94,6 +94,7 @@ struct Wino24Params {
     int leaky, res_pix_stride, out_pix_stride, vec_io;
 };
 
+template <int EXP>
 __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params p) {
     constexpr int BM = 64, BN = 64, WM = 32, WN = 32;
     constexpr int NWN = BN / WN;
@@ -115,10 +116,15 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
     const int ksteps = 24 * p.kc;
     const size_t v_plane = (size_t)p.T * p.C, u_plane = (size_t)p.cout_pad * p.C;
 
-    for (;;) {
-        if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
-        __syncthreads();
-        int tile = *s_ticket;
+    for (int iter = 0;; ++iter) {
+        int tile;
+        if constexpr (EXP == 5) {
+            tile = blockIdx.x + iter * gridDim.x;
+        } else {
+            if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+            __syncthreads();
+            tile = *s_ticket;
+        }
         if (tile >= p.total_tiles) break;
         tile = __builtin_amdgcn_readfirstlane(tile);
         const int tile_n = tile % p.n_tiles;
@@ -192,13 +198,14 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
                     const int slot = q * 4 + t;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[t], ca[t], acc, 0, 0, 0);
                     if (t == 1 && q < 3) read_frags(na, nb, buf, q + 1);
-                    if (slot < NP) issue_piece(slot, buf2, live2);
+                    if constexpr (EXP != 3) { if (slot < NP) issue_piece(slot, buf2, live2); }
                     if (slot == 12) read_frags(na, nb, buf1, 0);
                     if (slot == 11) {
                         // everything older than this step's NP pieces has landed = the operands of step s+1;
                         // all my reads of the current buffer are done (lgkmcnt) -> raw barrier, no compiler fence
-                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NP) : "memory");
-                        __builtin_amdgcn_s_barrier();
+                        if constexpr (EXP == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NP) : "memory");
+                        if constexpr (EXP != 4) __builtin_amdgcn_s_barrier();
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -234,6 +241,12 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
+        if constexpr (EXP == 2) {
+            if (p.T == -12345) {        // never true: keeps the accumulators alive without an epilogue
+                for (int e = 0; e < 8; ++e) p.out[tid + e * 256] = outa[e >> 2][e & 3][tid & 15];
+            }
+            continue;
+        }
         // ---- epilogue: eight output positions through LDS C tiles, three positions per pass (the ring holds 48 KiB)
         f32x4* sC = smem;
         const int n4 = tid % CH, r0 = tid / CH;
@@ -276,6 +289,10 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
                     if (y >= p.H || x >= p.W) continue;
                     const size_t pix = ((size_t)bi * p.H + y) * p.W + x;
                     f32x4 v = sC[e * BM * CH + mr * CH + (n4 ^ (mr & 7))];
+                    if constexpr (EXP == 1) {
+                        if (p.T == -12345) *reinterpret_cast<f32x4*>(p.out + pix) = v;
+                        continue;
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         float tv = fmaf(v[k], sc[k], sh[k]);
@@ -333,7 +350,15 @@ int launch_conv_winograd24(const ConvArgs& a, float* scratch, hipStream_t stream
     OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "winograd24: %lld tiles out of range", total);
     p.total_tiles = (int)total;
     const long long grid = total < 512 ? total : 512;        // 2 workgroups per CU (register-bound)
-    hipLaunchKernelGGL(wino24_gemm_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
+    static const int exp_ = [] { const char* e = getenv("OM_EXPERIMENT"); return e ? atoi(e) : 0; }();
+    switch (exp_) {
+        case 1: hipLaunchKernelGGL(wino24_gemm_kernel<1>, dim3((unsigned)grid), dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL(wino24_gemm_kernel<2>, dim3((unsigned)grid), dim3(256), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL(wino24_gemm_kernel<3>, dim3((unsigned)grid), dim3(256), 0, stream, p); break;
+        case 4: hipLaunchKernelGGL(wino24_gemm_kernel<4>, dim3((unsigned)grid), dim3(256), 0, stream, p); break;
+        case 5: hipLaunchKernelGGL(wino24_gemm_kernel<5>, dim3((unsigned)grid), dim3(256), 0, stream, p); break;
+        default: hipLaunchKernelGGL(wino24_gemm_kernel<0>, dim3((unsigned)grid), dim3(256), 0, stream, p); break;
+    }
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }

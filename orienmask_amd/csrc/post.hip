@@ -24,12 +24,15 @@
 // is compiled with -ffp-contract=off and the only fused multiply-adds are the explicit fmaf calls of
 // the bilinear taps (the placement torch's CPU kernel compiles to; see oracle/orienmask_ref.py).
 #include "om_common.h"
+#include "ref_math.h"
 
 namespace om {
 
 constexpr int DEC_TILE = 2048;          // pairs per decode workgroup
 constexpr int SEL_THREADS = 1024;
-constexpr int SEL_MAXN = 512;           // nms_pre limit of the fused path (LDS bit-matrix 32 KiB)
+constexpr int SEL_MAXN = 1024;          // nms_pre limit of the fused path
+constexpr int SEL_LDS_MASK_N = 512;     // up to this many candidates the suppression bit-matrix stays in LDS (32 KiB); above,
+                                        // it lives in the workspace (what the reference's CUDA backend always does)
 constexpr int L1_BINS = 2048;           // key >> 19
 constexpr int MASK_PX = 16;             // pixels per thread in the mask kernel
 
@@ -44,14 +47,13 @@ struct PostParams {
     int* tile_count;       // [B][ntiles]
     unsigned* hist1;       // [B][L1_BINS]
     float* det_par;        // [B][nms_post][8]
+    unsigned long long* nms_mask;   // [B][SEL_MAXN * SEL_MAXN / 64], used when nms_pre > SEL_LDS_MASK_N
     float* out_bbox;
     int64_t* out_cls;
     uint8_t* out_mask;
     int32_t* out_count;
     int32_t* out_keep;
 };
-
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // candidate index -> (scale, anchor slot, pixel)
 __device__ __forceinline__ void locate(const PostParams& p, int cand, int& s, int& a, int& pix) {
@@ -68,10 +70,23 @@ __device__ __forceinline__ void locate(const PostParams& p, int cand, int& s, in
 __global__ __launch_bounds__(256) void post_decode_kernel(const PostParams p) {
     __shared__ unsigned hist[L1_BINS];
     __shared__ int wcnt[4];
+    __shared__ unsigned long long s_tab[32];     // glibc's 2^(k/32) table (ref_math.h), indexed per lane
+    __shared__ float s_obj[DEC_TILE + 2];       // sigmoid(objectness) of the candidates this tile touches
     const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x;
     for (int i = tid; i < L1_BINS; i += 256) hist[i] = 0;
+    if (tid < 32) s_tab[tid] = kExp2fTab[tid];
     __syncthreads();
     const int C = p.cfg.num_classes, per = 5 + C;
+    // sigmoid(obj) once per candidate (postprocess.py:128: a strided view -> torch's scalar loop -> glibc expf)
+    const int cand_first = (tile * DEC_TILE) / C;
+    const int cand_last = min(p.ncand - 1, (tile * DEC_TILE + DEC_TILE - 1) / C);
+    for (int i = tid; i <= cand_last - cand_first; i += 256) {
+        int s, a, pix;
+        locate(p, cand_first + i, s, a, pix);
+        const int hw = p.cfg.grid_h[s] * p.cfg.grid_w[s];
+        s_obj[i] = sigmoid_scalar_ref(p.bbox[s][((size_t)b * hw + pix) * p.cfg.bbox_pix_stride + a * per + 4], s_tab);
+    }
+    __syncthreads();
     unsigned* keys = p.keys + (size_t)b * p.ntiles * DEC_TILE + (size_t)tile * DEC_TILE;
     int cnt = 0;
 #pragma unroll 2
@@ -84,7 +99,7 @@ __global__ __launch_bounds__(256) void post_decode_kernel(const PostParams p) {
             locate(p, cand, s, a, pix);
             const int hw = p.cfg.grid_h[s] * p.cfg.grid_w[s];
             const float* q = p.bbox[s] + ((size_t)b * hw + pix) * p.cfg.bbox_pix_stride + a * per;
-            const float conf = sigmoidf_(q[5 + cls]) * sigmoidf_(q[4]);
+            const float conf = sigmoid_class_ref(q[5 + cls], cls, C, s_tab) * s_obj[cand - cand_first];
             if (conf > p.cfg.conf_thresh) {
                 key = __float_as_uint(conf);
                 atomicAdd(&hist[key >> 19], 1u);
@@ -161,45 +176,77 @@ __device__ __forceinline__ void bitonic_sort_desc(unsigned long long* v, int n_p
     }
 }
 
-struct Box5 { float x1, y1, x2, y2, area; };
+// Suppression bit-matrix.  Boxes are already in visiting (score-descending) order.  mask: [n][words] u64 (LDS or
+// global); bit jj of word wd of row pi = "box pi suppresses box 64 wd + jj".  Two semantics (om_post_cfg.nms_semantics):
+//   0  the reference's CPU backend, eval/src/nms_cpu.cpp:38-60: areas from the corners, suppress when IoU >= thr
+//   1  the reference's CUDA backend, eval/src/nms_kernel.cu:13-23,62: areas w * h, suppress when IoU > thr
+// (sarea holds whichever area the semantics asks for; the corner arithmetic is the same in both.)
+__device__ __forceinline__ unsigned long long nms_mask_word(const float* sx1, const float* sy1, const float* sx2,
+                                                            const float* sy2, const float* sarea, int n, float thr,
+                                                            bool strict, int pi, int wd) {
+    unsigned long long bits = 0;
+    const int j0 = wd * 64;
+    if (j0 + 63 > pi) {
+        const float ix1 = sx1[pi], iy1 = sy1[pi], ix2 = sx2[pi], iy2 = sy2[pi], ia = sarea[pi];
+        const int jend = min(64, n - j0);
+        for (int jj = max(0, pi + 1 - j0); jj < jend; ++jj) {
+            const int pj = j0 + jj;
+            const float xx1 = fmaxf(ix1, sx1[pj]), yy1 = fmaxf(iy1, sy1[pj]);
+            const float xx2 = fminf(ix2, sx2[pj]), yy2 = fminf(iy2, sy2[pj]);
+            const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+            const float inter = w * h;
+            const float ovr = inter / (ia + sarea[pj] - inter);
+            if (strict ? (ovr > thr) : (ovr >= thr)) bits |= 1ull << jj;
+        }
+    }
+    return bits;
+}
 
-// Suppression bit-matrix + serial reduction.  Boxes are already in visiting (score-descending) order.
-// mask: [n][words] u64 (LDS or global).  keep_flag[pi] = 1 when box pi survives.
 __device__ __forceinline__ void nms_bitmask(const float* sx1, const float* sy1, const float* sx2, const float* sy2,
-                                            const float* sarea, int n, float thr, unsigned long long* mask,
-                                            int words, unsigned char* keep_flag) {
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    for (int item = tid; item < n * words; item += nthr) {
+                                            const float* sarea, int n, float thr, bool strict, unsigned long long* mask,
+                                            int words) {
+    for (int item = threadIdx.x; item < n * words; item += blockDim.x) {
         const int pi = item / words, wd = item - pi * words;
-        unsigned long long bits = 0;
-        const int j0 = wd * 64;
-        if (j0 + 63 > pi) {
-            const float ix1 = sx1[pi], iy1 = sy1[pi], ix2 = sx2[pi], iy2 = sy2[pi], ia = sarea[pi];
-            const int jend = min(64, n - j0);
-            for (int jj = max(0, pi + 1 - j0); jj < jend; ++jj) {
-                const int pj = j0 + jj;
-                const float xx1 = fmaxf(ix1, sx1[pj]), yy1 = fmaxf(iy1, sy1[pj]);
-                const float xx2 = fminf(ix2, sx2[pj]), yy2 = fminf(iy2, sy2[pj]);
-                const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
-                const float inter = w * h;
-                const float ovr = inter / (ia + sarea[pj] - inter);
-                if (ovr >= thr) bits |= 1ull << jj;
+        mask[item] = nms_mask_word(sx1, sy1, sx2, sy2, sarea, n, thr, strict, pi, wd);
+    }
+    __syncthreads();
+}
+
+// Serial part of greedy NMS (nms_cpu.cpp:38-60 / the host loop of nms_kernel.cu:123-134), 64 rows at a time:
+// wave 0 walks the diagonal word of the block with scalar operations (64 dependent steps in registers), then every
+// wave ORs the kept rows of the block into the removed-words to the right.  s_removed: [words] u64 in LDS;
+// keep_flag[pi] = 1 when box pi survives (LDS or global).  blockDim.x must be a multiple of 64.
+__device__ __forceinline__ void nms_reduce_blocked(const unsigned long long* mask, int n, int words,
+                                                   unsigned long long* s_removed, unsigned long long* s_kept_bits,
+                                                   unsigned char* keep_flag) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    for (int w = tid; w < words; w += blockDim.x) s_removed[w] = 0ull;
+    __syncthreads();
+    for (int blk = 0; blk < words; ++blk) {
+        const int row = blk * 64 + lane;
+        if (wave == 0) {
+            const unsigned long long diag = row < n ? mask[(size_t)row * words + blk] : 0ull;
+            unsigned long long rem = s_removed[blk];
+            unsigned long long kept = 0ull;
+            const int rows_here = min(64, n - blk * 64);
+            for (int i = 0; i < rows_here; ++i) {
+                const unsigned long long d = __shfl(diag, i);      // uniform
+                if (!((rem >> i) & 1ull)) { kept |= 1ull << i; rem |= d; }
             }
+            if (lane == 0) *s_kept_bits = kept;
+            if (row < n) keep_flag[row] = (unsigned char)((kept >> lane) & 1ull);
         }
-        mask[item] = bits;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        unsigned long long removed = 0;     // lane w holds word w
-        for (int pi = 0; pi < n; ++pi) {
-            const unsigned long long row = tid < words ? mask[pi * words + tid] : 0ull;
-            const unsigned long long rw = __shfl(removed, pi >> 6);
-            const bool kept = !((rw >> (pi & 63)) & 1ull);
-            if (kept) removed |= row;
-            if (tid == 0) keep_flag[pi] = kept ? 1 : 0;
+        __syncthreads();
+        const unsigned long long kept = *s_kept_bits;
+        const bool mine = row < n && ((kept >> lane) & 1ull);
+        for (int w = blk + 1 + wave; w < words; w += nwaves) {
+            unsigned long long v = mine ? mask[(size_t)row * words + w] : 0ull;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d);
+            if (lane == 0) s_removed[w] |= v;
         }
+        __syncthreads();
     }
-    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -212,14 +259,12 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
     __shared__ unsigned long long s_comp[SEL_MAXN];         // (key << 32) | ~position
     __shared__ unsigned s_key[SEL_MAXN];
     __shared__ int s_pair[SEL_MAXN];
-    // decoded boxes alias the histogram (free once the radix select is done)
-    float* const s_bx = reinterpret_cast<float*>(hist);
-    float* const s_by = s_bx + SEL_MAXN;
-    float* const s_bw = s_by + SEL_MAXN;
-    float* const s_bh = s_bw + SEL_MAXN;
-    static_assert(4 * SEL_MAXN <= L1_BINS, "box arrays must fit in the histogram");
+    __shared__ float s_bx[SEL_MAXN], s_by[SEL_MAXN], s_bw[SEL_MAXN], s_bh[SEL_MAXN];
     __shared__ float s_x1[SEL_MAXN], s_y1[SEL_MAXN], s_x2[SEL_MAXN], s_y2[SEL_MAXN], s_area[SEL_MAXN];
-    __shared__ unsigned long long s_mask[SEL_MAXN * (SEL_MAXN / 64)];
+    __shared__ unsigned long long s_mask[SEL_LDS_MASK_N * (SEL_LDS_MASK_N / 64)];
+    __shared__ unsigned long long s_removed[SEL_MAXN / 64];
+    __shared__ unsigned long long s_kept_bits;
+    __shared__ float s_red[SEL_THREADS / 64];
     __shared__ unsigned char s_keep[SEL_MAXN];
     __shared__ unsigned char s_keep_pos[SEL_MAXN];
     __shared__ short s_ord[SEL_MAXN];
@@ -351,36 +396,68 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
         s_ord[tid] = (short)pos;
         const int pair = s_pair[pos];
         const int C = p.cfg.num_classes;
-        const int cand = pair / C, cls = pair - cand * C;
+        const int cand = pair / C;
         int s, a, pix;
         locate(p, cand, s, a, pix);
         const int gh = p.cfg.grid_h[s], gw = p.cfg.grid_w[s];
         const int gy = pix / gw, gx = pix - gy * gw;
         const float* q = p.bbox[s] + ((size_t)b * gh * gw + pix) * p.cfg.bbox_pix_stride + a * (5 + C);
         const int aid = p.cfg.anchor_mask[s][a];
-        const float bx = (sigmoidf_(q[0]) + (float)gx) / (float)gw;
-        const float by = (sigmoidf_(q[1]) + (float)gy) / (float)gh;
-        const float bw = expf(q[2]) * (p.cfg.anchor_w[aid] / (float)p.cfg.image_w);
-        const float bh = expf(q[3]) * (p.cfg.anchor_h[aid] / (float)p.cfg.image_h);
+        // tx, ty: strided views -> torch's scalar sigmoid (glibc expf), bit-exact; tw, th: MKL vsExp in the reference, matched
+        // to one ulp by the correctly rounded value (ref_math.h)
+        const float bx = (sigmoid_scalar_ref(q[0]) + (float)gx) / (float)gw;
+        const float by = (sigmoid_scalar_ref(q[1]) + (float)gy) / (float)gh;
+        const float bw = expf_cr(q[2]) * (p.cfg.anchor_w[aid] / (float)p.cfg.image_w);
+        const float bh = expf_cr(q[3]) * (p.cfg.anchor_h[aid] / (float)p.cfg.image_h);
         s_bx[tid] = bx; s_by[tid] = by; s_bw[tid] = bw; s_bh[tid] = bh;
-        // class offset (function.py:93-96) then corners and area (nms_cpu.cpp:17-22)
-        const float off = (float)cls * 2.0f;
+    }
+    // class offset, function.py:91-96: cls * (max_coordinate + 0.5); max_coordinate = 1.5 when normalized, else
+    // dets[:, :2].max() + dets[:, 2:4].max() / 2 over the candidates of this image
+    float class_step = 2.0f;
+    if (!p.cfg.nms_normalized) {
+        float mxy = -__builtin_inff(), mwh = -__builtin_inff();
+        if (tid < n) { mxy = fmaxf(s_bx[tid], s_by[tid]); mwh = fmaxf(s_bw[tid], s_bh[tid]); }
+        for (int pass = 0; pass < 2; ++pass) {
+            float v = pass == 0 ? mxy : mwh;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+            __syncthreads();
+            if ((tid & 63) == 0) s_red[tid >> 6] = v;
+            __syncthreads();
+            v = s_red[0];
+            for (int w = 1; w < SEL_THREADS / 64; ++w) v = fmaxf(v, s_red[w]);
+            if (pass == 0) mxy = v; else mwh = v;
+        }
+        class_step = (mxy + mwh / 2.0f) + 0.5f;
+    }
+    const bool cuda_sem = p.cfg.nms_semantics == 1;
+    if (tid < n) {
+        const int pair = s_pair[s_ord[tid]];
+        const int cls = pair - (pair / p.cfg.num_classes) * p.cfg.num_classes;
+        const float bx = s_bx[tid], by = s_by[tid], bw = s_bw[tid], bh = s_bh[tid];
+        // corners (nms_cpu.cpp:17-20 == devIoU's a[0] -+ a[2] / 2, nms_kernel.cu:14-17) and the semantics' area
+        const float off = (float)cls * class_step;
         const float ox = bx + off, oy = by + off;
         const float x1 = ox - bw / 2.0f, y1 = oy - bh / 2.0f, x2 = ox + bw / 2.0f, y2 = oy + bh / 2.0f;
         s_x1[tid] = x1; s_y1[tid] = y1; s_x2[tid] = x2; s_y2[tid] = y2;
-        s_area[tid] = (x2 - x1) * (y2 - y1);
+        s_area[tid] = cuda_sem ? bw * bh : (x2 - x1) * (y2 - y1);       // nms_kernel.cu:20-21 / nms_cpu.cpp:22
     }
     __syncthreads();
 
     const int words = (n + 63) >> 6;
-    nms_bitmask(s_x1, s_y1, s_x2, s_y2, s_area, n, p.cfg.nms_thresh, s_mask, words, s_keep);
+    unsigned long long* const mask = n <= SEL_LDS_MASK_N ? s_mask : p.nms_mask + (size_t)b * SEL_MAXN * (SEL_MAXN / 64);
+    nms_bitmask(s_x1, s_y1, s_x2, s_y2, s_area, n, p.cfg.nms_thresh, cuda_sem, mask, words);
+    nms_reduce_blocked(mask, n, words, s_removed, &s_kept_bits, s_keep);
+    __syncthreads();
 
     // ---- output order (nms_cpu.cpp:62 ascending list position; postprocess.py:150-154 top-nms_post)
     int kept_total;
     const int my_keep = (tid < n) ? s_keep[tid] : 0;
     const int rank_sorted = block_scan_excl(my_keep, s_wave, kept_total);
     int K, slot = -1;
-    if (caseA || kept_total > nms_post) {
+    // the CUDA backend returns keep in visiting (score-descending) order (nms_kernel.cu:136-139), so dets[keep] is sorted
+    // and the top-nms_post of postprocess.py:150-154 is its head in every case
+    if (caseA || cuda_sem || kept_total > nms_post) {
         K = kept_total < nms_post ? kept_total : nms_post;
         if (my_keep && rank_sorted < K) slot = rank_sorted;
     } else {
@@ -540,51 +617,140 @@ __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// standalone NMS (the reference's native export): sort, bit-matrix in the caller's workspace, reduce
+// standalone NMS (the reference's native export nms(dets, threshold) -> keep): one 1024-thread workgroup sorts,
+// fills the bit-matrix in the caller's workspace, reduces it 64 rows at a time and compacts the survivors.
+// Everything that grows with n lives in the workspace, so n is bounded only by NMS_MAXN (the reference has no bound).
 // ------------------------------------------------------------------------------------------------
-constexpr int NMS_MAXN = 1024;
+constexpr int NMS_MAXN = 1 << 16;
 
-__global__ __launch_bounds__(1024) void nms_kernel(const float* dets, int n, float thr, int64_t* keep, int32_t* n_keep,
-                                                   unsigned long long* mask) {
-    __shared__ unsigned long long s_comp[NMS_MAXN];
-    __shared__ float s_x1[NMS_MAXN], s_y1[NMS_MAXN], s_x2[NMS_MAXN], s_y2[NMS_MAXN], s_area[NMS_MAXN];
-    __shared__ unsigned char s_keep[NMS_MAXN], s_keep_pos[NMS_MAXN];
-    __shared__ int s_wave[16];
+struct NmsWs { size_t comp, x1, y1, x2, y2, area, keep_flag, keep_pos, mask, total; };
+
+static NmsWs nms_ws_layout(int n) {
+    NmsWs w;
+    size_t n_pad = 64;
+    while (n_pad < (size_t)n) n_pad <<= 1;
+    const size_t words = ((size_t)n + 63) / 64;
+    size_t off = 0;
+    w.comp = off; off += align_up(n_pad * sizeof(unsigned long long), 256);
+    w.x1 = off; off += align_up((size_t)n * 4, 256);
+    w.y1 = off; off += align_up((size_t)n * 4, 256);
+    w.x2 = off; off += align_up((size_t)n * 4, 256);
+    w.y2 = off; off += align_up((size_t)n * 4, 256);
+    w.area = off; off += align_up((size_t)n * 4, 256);
+    w.keep_flag = off; off += align_up((size_t)n, 256);
+    w.keep_pos = off; off += align_up((size_t)n, 256);
+    w.mask = off; off += align_up((size_t)n * words * sizeof(unsigned long long), 256);
+    w.total = off;
+    return w;
+}
+
+struct NmsPtrs {
+    unsigned long long* comp; float *x1, *y1, *x2, *y2, *area; unsigned char *keep_flag, *keep_pos; unsigned long long* mask;
+};
+static __host__ __device__ NmsPtrs nms_ptrs(char* ws, const NmsWs& L) {
+    NmsPtrs q;
+    q.comp = reinterpret_cast<unsigned long long*>(ws + L.comp);
+    q.x1 = reinterpret_cast<float*>(ws + L.x1); q.y1 = reinterpret_cast<float*>(ws + L.y1);
+    q.x2 = reinterpret_cast<float*>(ws + L.x2); q.y2 = reinterpret_cast<float*>(ws + L.y2);
+    q.area = reinterpret_cast<float*>(ws + L.area);
+    q.keep_flag = reinterpret_cast<unsigned char*>(ws + L.keep_flag);
+    q.keep_pos = reinterpret_cast<unsigned char*>(ws + L.keep_pos);
+    q.mask = reinterpret_cast<unsigned long long*>(ws + L.mask);
+    return q;
+}
+
+// visiting order (score descending, ties by index ascending: torch's CPU sort is stable at these sizes, its CUDA sort leaves
+// ties unspecified) + corners and areas in that order
+__global__ __launch_bounds__(1024) void nms_sort_kernel(const float* dets, int n, int semantics, char* ws, const NmsWs L) {
+    const NmsPtrs q = nms_ptrs(ws, L);
     const int tid = threadIdx.x;
     int n_pad = 64;
     while (n_pad < n) n_pad <<= 1;
-    if (tid < n_pad) {
+    for (int i = tid; i < n_pad; i += 1024) {
         unsigned long long c = 0;
-        if (tid < n) {
-            // order-preserving map of the float score to u32 (handles negative scores too)
-            unsigned u = __float_as_uint(dets[tid * 5 + 4]);
+        if (i < n) {
+            unsigned u = __float_as_uint(dets[(size_t)i * 5 + 4]);      // order-preserving map of the float score
             u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-            c = ((unsigned long long)u << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)tid);
+            c = ((unsigned long long)u << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
         }
-        s_comp[tid] = c;
+        q.comp[i] = c;
     }
     __syncthreads();
-    bitonic_sort_desc(s_comp, n_pad);
-    int pos = 0;
-    if (tid < n) {
-        pos = (int)(0xFFFFFFFFu - (unsigned)(s_comp[tid] & 0xFFFFFFFFull));
-        const float* d = dets + pos * 5;
+    for (int k = 2; k <= n_pad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n_pad; i += 1024) {
+                const int partner = i ^ j;
+                if (partner > i) {
+                    const unsigned long long a = q.comp[i], c = q.comp[partner];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < c) : (a > c)) { q.comp[i] = c; q.comp[partner] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < n; i += 1024) {
+        const int pos = (int)(0xFFFFFFFFu - (unsigned)(q.comp[i] & 0xFFFFFFFFull));
+        const float* d = dets + (size_t)pos * 5;
         const float cx = d[0], cy = d[1], w = d[2], h = d[3];
         const float x1 = cx - w / 2.0f, y1 = cy - h / 2.0f, x2 = cx + w / 2.0f, y2 = cy + h / 2.0f;
-        s_x1[tid] = x1; s_y1[tid] = y1; s_x2[tid] = x2; s_y2[tid] = y2;
-        s_area[tid] = (x2 - x1) * (y2 - y1);
-        s_keep_pos[tid] = 0;
+        q.x1[i] = x1; q.y1[i] = y1; q.x2[i] = x2; q.y2[i] = y2;
+        q.area[i] = semantics == 1 ? w * h : (x2 - x1) * (y2 - y1);
+        q.keep_pos[i] = 0;
     }
-    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void nms_mask_kernel(int n, float thr, int semantics, char* ws, const NmsWs L) {
+    const NmsPtrs q = nms_ptrs(ws, L);
     const int words = (n + 63) >> 6;
-    nms_bitmask(s_x1, s_y1, s_x2, s_y2, s_area, n, thr, mask, words, s_keep);
-    if (tid < n && s_keep[tid]) s_keep_pos[pos] = 1;
+    const long long item = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (item >= (long long)n * words) return;
+    const int pi = (int)(item / words), wd = (int)(item - (long long)pi * words);
+    q.mask[item] = nms_mask_word(q.x1, q.y1, q.x2, q.y2, q.area, n, thr, semantics == 1, pi, wd);
+}
+
+__global__ __launch_bounds__(1024) void nms_reduce_kernel(int n, int semantics, int64_t* keep, int32_t* n_keep, char* ws,
+                                                          const NmsWs L) {
+    __shared__ unsigned long long s_removed[NMS_MAXN / 64];
+    __shared__ unsigned long long s_kept_bits;
+    __shared__ int s_wave[16];
+    const NmsPtrs q = nms_ptrs(ws, L);
+    const int tid = threadIdx.x;
+    const int words = (n + 63) >> 6;
+    nms_reduce_blocked(q.mask, n, words, s_removed, &s_kept_bits, q.keep_flag);
     __syncthreads();
-    int total;
-    const int flag = tid < n ? s_keep_pos[tid] : 0;
-    const int rank = block_scan_excl(flag, s_wave, total);
-    if (flag) keep[rank] = tid;
-    if (tid == 0) *n_keep = total;
+    // ---- output order: ascending original index (nms_cpu.cpp:62) or visiting order (nms_kernel.cu:136-139)
+    if (semantics == 0) {
+        for (int i = tid; i < n; i += 1024)
+            if (q.keep_flag[i]) q.keep_pos[(int)(0xFFFFFFFFu - (unsigned)(q.comp[i] & 0xFFFFFFFFull))] = 1;
+        __syncthreads();
+    }
+    int running = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int flag = i < n ? (semantics == 0 ? q.keep_pos[i] : q.keep_flag[i]) : 0;
+        int total;
+        const int rank = block_scan_excl(flag, s_wave, total);
+        if (flag) keep[running + rank] = semantics == 0 ? i : (int)(0xFFFFFFFFu - (unsigned)(q.comp[i] & 0xFFFFFFFFull));
+        running += total;
+    }
+    if (tid == 0) *n_keep = running;
+}
+
+// unit-test entry: the reference-exact elementary functions of ref_math.h on a flat array
+__global__ void ref_math_kernel(const float* x, long long n, int func, int C, float* y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    float r;
+    switch (func) {
+        case 0: r = expf_glibc(v); break;
+        case 1: r = expf_sleef(v); break;
+        case 2: r = sigmoid_scalar_ref(v); break;
+        case 3: r = sigmoid_vector_ref(v); break;
+        case 4: r = sigmoid_class_ref(v, (int)(i % C), C); break;      // x is [rows][C] class logits
+        default: r = expf_cr(v); break;
+    }
+    y[i] = r;
 }
 
 static int fill_params(const om_post_cfg* cfg, PostParams& p) {
@@ -597,6 +763,8 @@ static int fill_params(const om_post_cfg* cfg, PostParams& p) {
     OM_REQUIRE(cfg->num_classes >= 1 && cfg->anchors_per_scale * (5 + cfg->num_classes) <= cfg->bbox_pix_stride,
                OM_EINVAL, "postprocess: bbox_pix_stride=%d too small", cfg->bbox_pix_stride);
     OM_REQUIRE(cfg->conf_thresh >= 0.0f, OM_EINVAL, "postprocess: conf_thresh must be >= 0");
+    OM_REQUIRE(cfg->nms_semantics == 0 || cfg->nms_semantics == 1, OM_EINVAL,
+               "postprocess: nms_semantics=%d (0 = the reference's CPU backend, 1 = its CUDA backend)", cfg->nms_semantics);
     p.cfg = *cfg;
     p.cand_off[0] = 0;
     for (int s = 0; s < 3; ++s) {
@@ -614,7 +782,7 @@ static int fill_params(const om_post_cfg* cfg, PostParams& p) {
     return OM_OK;
 }
 
-struct PostWs { size_t keys, tile_count, hist1, det_par, total; };
+struct PostWs { size_t keys, tile_count, hist1, det_par, nms_mask, total; };
 
 static PostWs post_ws_layout(const PostParams& p, int B) {
     PostWs w;
@@ -623,6 +791,8 @@ static PostWs post_ws_layout(const PostParams& p, int B) {
     w.tile_count = off; off += align_up((size_t)B * p.ntiles * sizeof(int), 256);
     w.hist1 = off; off += align_up((size_t)B * L1_BINS * sizeof(unsigned), 256);
     w.det_par = off; off += align_up((size_t)B * p.cfg.nms_post * 8 * sizeof(float), 256);
+    w.nms_mask = off;
+    if (p.cfg.nms_pre > SEL_LDS_MASK_N) off += align_up((size_t)B * SEL_MAXN * (SEL_MAXN / 64) * sizeof(unsigned long long), 256);
     w.total = off;
     return w;
 }
@@ -651,7 +821,8 @@ int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbo
     OM_REQUIRE(ws_bytes >= w.total, OM_ENOMEM, "om_postprocess: workspace %zu bytes < %zu needed", ws_bytes, w.total);
     OM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0 && (reinterpret_cast<uintptr_t>(out_mask) & 15) == 0,
                OM_EINVAL, "om_postprocess: workspace must be 256-byte and out_mask 16-byte aligned");
-    OM_REQUIRE((long long)B * cfg->nms_post < 65536, OM_EINVAL, "om_postprocess: B * nms_post must be < 65536");
+    OM_REQUIRE((long long)B * cfg->num_scales * cfg->anchors_per_scale < 65536, OM_EINVAL,
+               "om_postprocess: B * scales * anchors_per_scale must be < 65536 (the mask kernel's grid.y)");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     char* base = static_cast<char*>(workspace);
     p.bbox[0] = bbox32; p.bbox[1] = bbox16; p.bbox[2] = bbox8; p.oriens = oriens; p.B = B;
@@ -659,6 +830,7 @@ int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbo
     p.tile_count = reinterpret_cast<int*>(base + w.tile_count);
     p.hist1 = reinterpret_cast<unsigned*>(base + w.hist1);
     p.det_par = reinterpret_cast<float*>(base + w.det_par);
+    p.nms_mask = reinterpret_cast<unsigned long long*>(base + w.nms_mask);
     p.out_bbox = out_bbox; p.out_cls = out_cls; p.out_mask = out_mask; p.out_count = out_count; p.out_keep = out_keep;
 
     if (int rc = om::launch_zero_words(p.hist1, (size_t)B * om::L1_BINS, stream)) return rc;
@@ -673,27 +845,60 @@ int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbo
     return OM_OK;
 }
 
+int om_post_kernel_occupancy(int which, int* threads, int* vgprs, int* lds_bytes, int* max_blocks_per_cu) {
+    OM_REQUIRE(threads && vgprs && lds_bytes && max_blocks_per_cu, OM_EINVAL, "om_post_kernel_occupancy: null argument");
+    OM_REQUIRE(which >= 0 && which <= 2, OM_EINVAL, "om_post_kernel_occupancy: which=%d (0 decode, 1 select, 2 mask)", which);
+    const void* fn = which == 0 ? reinterpret_cast<const void*>(om::post_decode_kernel)
+                   : which == 1 ? reinterpret_cast<const void*>(om::post_select_kernel)
+                                : reinterpret_cast<const void*>(om::post_mask_kernel);
+    const int nthreads = which == 1 ? om::SEL_THREADS : 256;
+    hipFuncAttributes attr;
+    OM_CHECK_HIP(hipFuncGetAttributes(&attr, fn));
+    int nb = 0;
+    OM_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, nthreads, 0));
+    *threads = nthreads; *vgprs = attr.numRegs; *lds_bytes = (int)attr.sharedSizeBytes; *max_blocks_per_cu = nb;
+    return OM_OK;
+}
+
+int om_ref_math(const float* x, long long n, int func, int num_classes, float* y, om_stream stream_) {
+    OM_REQUIRE(x && y && n >= 0 && func >= 0 && func <= 5 && num_classes >= 1, OM_EINVAL, "om_ref_math: bad argument");
+    if (n == 0) return OM_OK;
+    hipLaunchKernelGGL(om::ref_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), x, n,
+                       func, num_classes, y);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
 size_t om_nms_workspace_bytes(int n) {
     if (n <= 0) return 256;
-    const size_t words = ((size_t)n + 63) / 64;
-    return om::align_up((size_t)n * words * sizeof(unsigned long long), 256);
+    if (n > om::NMS_MAXN) return 0;
+    return om::nms_ws_layout(n).total;
+}
+
+int om_nms_ex(const float* dets, int n, float thresh, int semantics, int64_t* keep, int32_t* n_keep, void* workspace,
+              size_t ws_bytes, om_stream stream_) {
+    OM_REQUIRE(n_keep && (n == 0 || (dets && keep && workspace)), OM_EINVAL, "om_nms: null argument");
+    OM_REQUIRE(n >= 0 && n <= om::NMS_MAXN, OM_EINVAL, "om_nms: n=%d, at most %d boxes supported", n, om::NMS_MAXN);
+    OM_REQUIRE(semantics == 0 || semantics == 1, OM_EINVAL, "om_nms: semantics=%d (0 = CPU backend, 1 = CUDA backend)", semantics);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n == 0) return om::launch_zero_words(n_keep, 1, stream);
+    const om::NmsWs L = om::nms_ws_layout(n);
+    OM_REQUIRE(ws_bytes >= L.total, OM_ENOMEM, "om_nms: workspace %zu bytes < %zu needed", ws_bytes, L.total);
+    OM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, OM_EINVAL, "om_nms: workspace must be 256-byte aligned");
+    char* ws = static_cast<char*>(workspace);
+    hipLaunchKernelGGL(om::nms_sort_kernel, dim3(1), dim3(1024), 0, stream, dets, n, semantics, ws, L);
+    OM_CHECK_HIP(hipGetLastError());
+    const long long items = (long long)n * ((n + 63) / 64);
+    hipLaunchKernelGGL(om::nms_mask_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, n, thresh, semantics, ws, L);
+    OM_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(om::nms_reduce_kernel, dim3(1), dim3(1024), 0, stream, n, semantics, keep, n_keep, ws, L);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
 }
 
 int om_nms(const float* dets, int n, float thresh, int64_t* keep, int32_t* n_keep, void* workspace, size_t ws_bytes,
-           om_stream stream_) {
-    OM_REQUIRE(n_keep && (n == 0 || (dets && keep && workspace)), OM_EINVAL, "om_nms: null argument");
-    OM_REQUIRE(n >= 0 && n <= om::NMS_MAXN, OM_EINVAL, "om_nms: n=%d, at most %d boxes supported", n, om::NMS_MAXN);
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (n == 0) {
-        return om::launch_zero_words(n_keep, 1, stream);
-        return OM_OK;
-    }
-    OM_REQUIRE(ws_bytes >= om_nms_workspace_bytes(n), OM_ENOMEM, "om_nms: workspace %zu bytes < %zu needed", ws_bytes,
-               om_nms_workspace_bytes(n));
-    hipLaunchKernelGGL(om::nms_kernel, dim3(1), dim3(1024), 0, stream, dets, n, thresh, keep, n_keep,
-                       static_cast<unsigned long long*>(workspace));
-    OM_CHECK_HIP(hipGetLastError());
-    return OM_OK;
+           om_stream stream) {
+    return om_nms_ex(dets, n, thresh, 0, keep, n_keep, workspace, ws_bytes, stream);
 }
 
 }  // extern "C"

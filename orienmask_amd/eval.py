@@ -5,10 +5,17 @@
   batched_nms, nms          same signatures and return triples as
                             /root/reference/eval/function.py:55-103
 
-Everything runs in liborienmask_hip.so (``om_postprocess`` / ``om_nms``); the whole batch is three
+Everything runs in liborienmask_hip.so (``om_postprocess`` / ``om_nms_ex``); the whole batch is three
 kernel launches and ONE device->host copy (the per-image detection counts), against the reference's
-per-image Python loop with four host round trips.  Suppression follows the reference's CPU backend
-(nms_cpu.cpp: IoU >= threshold, ascending-index keep order), the only backend that builds today.
+per-image Python loop with four host round trips.
+
+The reference dispatches on ``dets.is_cuda`` between two native backends with DIFFERENT semantics
+(/root/reference/eval/function.py:69-72,98-101):
+  "cpu"   nms_cpu.cpp:4-63     IoU >= threshold suppresses, areas (x2-x1)*(y2-y1), keep in ascending index order
+  "cuda"  nms_kernel.cu:13-140 IoU >  threshold suppresses, areas w*h, keep in score-descending order
+Both run here on the GPU.  The default is "cpu" -- the backend that still builds, the one the golden fixtures were
+produced with; ``set_nms_backend("cuda")`` (or ``backend="cuda"`` / ``nms_backend="cuda"``) selects what a GPU user
+of the reference gets.
 """
 import ctypes
 import functools
@@ -23,13 +30,29 @@ def _pair(v):
     return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
 
 
-def nms(dets, cats, threshold=0.5):
+NMS_BACKENDS = {"cpu": 0, "cuda": 1}
+_nms_backend = "cpu"
+
+
+def set_nms_backend(name):
+    """Module default for nms / batched_nms / OrienMaskYOLOPostProcess: "cpu" or "cuda" (see the module docstring)."""
+    global _nms_backend
+    if name not in NMS_BACKENDS:
+        raise ValueError("nms backend must be one of %s, got %r" % (sorted(NMS_BACKENDS), name))
+    _nms_backend = name
+
+
+def get_nms_backend():
+    return _nms_backend
+
+
+def nms(dets, cats, threshold=0.5, backend=None):
     """Plain NMS; returns (dets[keep], cats[keep], keep).  /root/reference/eval/function.py:55-74."""
-    keep = _nms_keep(dets, threshold)
+    keep = _nms_keep(dets, threshold, backend)
     return dets[keep], cats[keep], keep
 
 
-def batched_nms(dets, cats, threshold=0.5, normalized=True):
+def batched_nms(dets, cats, threshold=0.5, normalized=True, backend=None):
     """Class-aware NMS: boxes are shifted by class * (max_coordinate + 0.5) so that classes never
     interact.  /root/reference/eval/function.py:77-103."""
     if dets.size(0) == 0:
@@ -38,13 +61,16 @@ def batched_nms(dets, cats, threshold=0.5, normalized=True):
         max_coordinate = 1.5 if normalized else dets[:, :2].max() + dets[:, 2:4].max() / 2
         shifted = dets.clone()
         shifted[:, :2] += cats.float().view(-1, 1) * (max_coordinate + 0.5)
-        keep = _nms_keep(shifted, threshold)
+        keep = _nms_keep(shifted, threshold, backend)
     return dets[keep], cats[keep], keep
 
 
-def _nms_keep(dets, threshold):
-    """om_nms: the native export nms(dets[n,5], threshold) -> keep of
-    /root/reference/eval/src/nms_cpu.cpp:65-75 / nms_cuda.cpp:8-17."""
+def _nms_keep(dets, threshold, backend=None):
+    """om_nms_ex: the native export nms(dets[n,5], threshold) -> keep of
+    /root/reference/eval/src/nms_cpu.cpp:65-75 (backend "cpu") / nms_cuda.cpp:8-17 (backend "cuda")."""
+    backend = _nms_backend if backend is None else backend
+    if backend not in NMS_BACKENDS:
+        raise ValueError("nms backend must be one of %s, got %r" % (sorted(NMS_BACKENDS), backend))
     if dets.size(0) == 0:
         return dets.new_zeros(0, dtype=torch.long)
     _lib.require_cuda_tensor(dets, "dets")
@@ -54,18 +80,24 @@ def _nms_keep(dets, threshold):
     dev = d.device
     keep = torch.empty(n, dtype=torch.long, device=dev)
     n_keep = torch.zeros(1, dtype=torch.int32, device=dev)
-    ws = torch.empty(L.om_nms_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    nbytes = L.om_nms_workspace_bytes(n)
+    if nbytes == 0:
+        raise _lib.OrienMaskHipError("om_nms: %d boxes exceed the library's limit of 65536" % n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        rc = L.om_nms(ctypes.c_void_p(d.data_ptr()), n, float(threshold), ctypes.c_void_p(keep.data_ptr()),
-                      ctypes.c_void_p(n_keep.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
-                      _lib.current_stream_ptr(dev))
-    _lib.check(rc, "om_nms")
+        rc = L.om_nms_ex(ctypes.c_void_p(d.data_ptr()), n, float(threshold), NMS_BACKENDS[backend],
+                         ctypes.c_void_p(keep.data_ptr()), ctypes.c_void_p(n_keep.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                         ws.numel(), _lib.current_stream_ptr(dev))
+    _lib.check(rc, "om_nms_ex")
     return keep[:int(n_keep.item())]
 
 
 class OrienMaskYOLOPostProcess:
     def __init__(self, grid_size, image_size, anchors, anchor_mask, num_classes, conf_thresh=0.05, nms_func=None,
-                 nms_pre=400, nms_post=100, orien_thresh=0.3, device=None):
+                 nms_pre=400, nms_post=100, orien_thresh=0.3, device=None, nms_backend=None):
+        """Same arguments as the reference (eval/orienmask_yolo_postprocess.py:9-11) plus `nms_backend`
+        ("cpu" | "cuda" | None = the module default / the one bound into nms_func): which of the reference's two NMS
+        backends the fused kernel follows."""
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device()) \
             if torch.cuda.is_available() else torch.device("cpu")
         self.nHs = [int(g[0]) for g in grid_size]
@@ -81,7 +113,13 @@ class OrienMaskYOLOPostProcess:
         self.nms_post = int(nms_post)
         self.orien_thresh = float(orien_thresh)
         self.nms = nms_func if nms_func else batched_nms
-        self.nms_thresh = self._threshold_of(self.nms)
+        self.nms_thresh, self.nms_normalized, bound_backend = self._nms_settings(self.nms)
+        self.nms_backend = nms_backend or bound_backend or _nms_backend
+        if self.nms_backend not in NMS_BACKENDS:
+            raise ValueError("nms_backend must be one of %s, got %r" % (sorted(NMS_BACKENDS), self.nms_backend))
+        if not 1 <= self.nms_post <= self.nms_pre <= 1024:
+            raise ValueError("the fused HIP postprocess needs 1 <= nms_post <= nms_pre <= 1024 (got %d, %d)"
+                             % (self.nms_post, self.nms_pre))
         if self.scales != 3 or len(set(self.num_anchors)) != 1:
             raise ValueError("the HIP postprocess supports 3 scales with the same number of anchors each")
         if len(self.anchors) > _lib.OM_MAX_ANCHORS:
@@ -89,15 +127,17 @@ class OrienMaskYOLOPostProcess:
         self._ws = {}
 
     @staticmethod
-    def _threshold_of(func):
-        """The fused kernel implements batched_nms itself; it only needs the IoU threshold that
-        build_postprocess bound into the partial (/root/reference/trainer/builder.py:73-77)."""
+    def _nms_settings(func):
+        """The fused kernel implements batched_nms itself; it needs the keyword arguments that build_postprocess bound
+        into the partial (/root/reference/trainer/builder.py:73-77): (threshold, normalized, backend or None)."""
         if func is batched_nms:
-            return 0.5
-        if isinstance(func, functools.partial) and func.func is batched_nms:
-            if func.keywords.get("normalized", True) is not True:
-                raise NotImplementedError("the fused postprocess implements batched_nms(normalized=True) only")
-            return float(func.keywords.get("threshold", 0.5))
+            return 0.5, True, None
+        if isinstance(func, functools.partial) and func.func is batched_nms and not func.args:
+            kw = func.keywords
+            unknown = set(kw) - {"threshold", "normalized", "backend"}
+            if unknown:
+                raise TypeError("batched_nms got unexpected keyword arguments %s" % sorted(unknown))
+            return float(kw.get("threshold", 0.5)), bool(kw.get("normalized", True)), kw.get("backend")
         raise NotImplementedError(
             "nms_func must be orienmask_amd.eval.batched_nms or a functools.partial of it; a foreign NMS callable "
             "cannot run inside the fused HIP postprocess (there is no Python fallback)")
@@ -121,6 +161,8 @@ class OrienMaskYOLOPostProcess:
         c.nms_pre, c.nms_post = self.nms_pre, self.nms_post
         c.orien_thresh = self.orien_thresh
         c.bbox_pix_stride = bbox_pix_stride
+        c.nms_semantics = NMS_BACKENDS[self.nms_backend]
+        c.nms_normalized = 1 if self.nms_normalized else 0
         return c
 
     def __call__(self, predict):

@@ -10,6 +10,11 @@ no memset on the hot path -- counters are cleared by a kernel (`launch_zero_word
 
 The tensors in `detections` are views of graph-owned buffers: the next call overwrites them (clone to keep).
 
+The captured kernels hold RAW device pointers into the model's workspace, the postprocess workspace and the packed
+weight blobs.  The pipeline keeps its own references to those tensors, so an eager `model(x)` / `postprocess(pred)` at
+another shape (which drops them from the model's caches) cannot hand their memory to someone else; and a weight change
+after capture (`load_state_dict`, `.to()`, `set_precision`) makes the next call raise instead of replaying stale weights.
+
 Measured on MI355X (tools/graph_bench.py) replay and eager take the same time at every batch size
 (B=1 5.25 ms, B=4 7.55 ms, B=32 34.2 ms): the ~130 launches are issued far ahead of the GPU, so the step is
 GPU-bound even at B=1 and the graph only removes host work (useful when the host thread is busy with decoding).
@@ -37,6 +42,17 @@ class GraphedPipeline:
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self._launch()
+        # everything the captured launches point into (see the module docstring)
+        self._precision = model.precision
+        self._weights = (model._packed, model._packed16 if model.precision == "f16" else None)
+        self._keepalive = list(model._workspace.values()) + list(postprocess._ws.values()) + [w for w in self._weights if w is not None]
+
+    def _check_bindings(self):
+        m = self.model
+        now = (m._packed, m._packed16 if m.precision == "f16" else None)
+        if m.precision != self._precision or any(a is not b for a, b in zip(now, self._weights)):
+            raise RuntimeError("GraphedPipeline: the model's weights or precision changed after capture; build a new "
+                               "GraphedPipeline (the captured kernels read the packed blobs that were bound at capture time)")
 
     def _launch(self):
         pred = self.model(self.static_in)
@@ -45,6 +61,7 @@ class GraphedPipeline:
     def __call__(self, image):
         if image.shape != self.static_in.shape:
             raise ValueError("captured for shape %s, got %s" % (tuple(self.static_in.shape), tuple(image.shape)))
+        self._check_bindings()
         self.static_in.copy_(image, non_blocking=True)
         self.graph.replay()
         return self.post.collect(self._outs)

@@ -33,7 +33,8 @@ class PostCfg(ctypes.Structure):
                 ("conf_thresh", ctypes.c_float), ("nms_thresh", ctypes.c_float),
                 ("nms_pre", ctypes.c_int32), ("nms_post", ctypes.c_int32),
                 ("orien_thresh", ctypes.c_float),
-                ("bbox_pix_stride", ctypes.c_int32)]
+                ("bbox_pix_stride", ctypes.c_int32),
+                ("nms_semantics", ctypes.c_int32), ("nms_normalized", ctypes.c_int32)]
 
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -81,8 +82,11 @@ SIGNATURES = {
     "om_recover_bbox": (_i, [_vp, _i, _i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _i, _i, _i, _i,
                              _vp, _vp]),
     "om_recover_masks_rle": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "om_post_kernel_occupancy": (_i, [_i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "om_nms_workspace_bytes": (_sz, [_i]),
     "om_nms": (_i, [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "om_nms_ex": (_i, [_vp, _i, _f, _i, _vp, _vp, _vp, _sz, _vp]),
+    "om_ref_math": (_i, [_vp, ctypes.c_longlong, _i, _i, _vp, _vp]),
 }
 
 _lib = None

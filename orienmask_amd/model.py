@@ -85,13 +85,33 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         self._packed_device = None
         self._workspace = {}         # (device, B, H, W) -> uint8 tensor
         if pretrained is not None:
-            # reference: BaseBackbone._load_pretrained_weights, /root/reference/model/base.py:48-64
-            sd = _pack.unwrap_checkpoint(torch.load(pretrained, map_location="cpu"))
-            own = self.state_dict()
-            own.update({k: v for k, v in sd.items() if k in own and v.shape == own[k].shape})
-            self.load_state_dict(own)
+            self._load_pretrained_backbone(pretrained)
 
     # ------------------------------------------------------------------ weights
+    def _load_pretrained_backbone(self, path):
+        """BaseBackbone._load_pretrained_weights, /root/reference/model/base.py:48-64: the file is loaded INSIDE the backbone,
+        so its keys are backbone-relative ('conv1.conv_block.0.weight', as in pretrained_darknet53.pth); keys that are
+        missing from the backbone or have another shape are ignored and reported, as the reference does.  Returns the
+        ignored keys."""
+        import warnings
+        sd = _pack.unwrap_checkpoint(torch.load(path, map_location="cpu", weights_only=False))
+        own = self.state_dict()
+        picked, ignored = {}, []
+        for k, v in sd.items():
+            full = "backbone." + k
+            if full in own and tuple(v.shape) == tuple(own[full].shape):
+                picked[full] = v
+            else:
+                ignored.append(k)
+        if not picked:
+            warnings.warn("pretrained file %s: none of its %d keys matches the backbone (expected backbone-relative keys such "
+                          "as 'conv1.conv_block.0.weight'); the model keeps its initialisation" % (path, len(sd)))
+        elif ignored:
+            warnings.warn("pretrained file %s: ignored keys %s" % (path, ignored[:8] + (["..."] if len(ignored) > 8 else [])))
+        own.update(picked)
+        self.load_state_dict(own)
+        return ignored
+
     def _ensure_handle(self):
         if self._handle is None:
             L = _lib.load()

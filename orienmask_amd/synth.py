@@ -84,6 +84,96 @@ def synth_photo_batch(seed, batch, height, width):
     return torch.from_numpy(np.floor(rng.random((batch, height, width, 3)) * 256).astype(np.float32))
 
 
+def _ulp_steps(x, k):
+    """float32 x moved by k units in the last place (k may be negative)."""
+    v = np.float32(x)
+    i = v.view(np.int32)
+    i = i + np.int32(k) if v >= 0 else i - np.int32(k)
+    return i.view(np.float32)
+
+
+def _plant_ties(rng, bbox, regime, nh, nw, grid_sizes, num_anchors, num_classes):
+    """Near-tie structures of the 'ties_*' regimes (see synth_heads); all of them live on the finest scale."""
+    if (nh, nw) != tuple(grid_sizes[-1]):
+        return
+    batch = bbox.shape[0]
+    for b in range(batch):
+        if regime == "ties_cut":
+            # 39 clusters of 9 cells voting for one box each (the 'clustered' construction) ...
+            cells = [(y, x) for y in range(2, nh - 2, 4) for x in range(2, nw - 2, 4)]
+            order = rng.permutation(len(cells))
+            n_clusters = min(39, len(cells) // 2)
+            for ci in order[:n_clusters]:
+                y, x = cells[ci]
+                a = int(rng.integers(num_anchors)); c = int(rng.integers(num_classes))
+                ob = 4.0 + rng.random(); cl = 4.0 + rng.random()
+                for dy in (-1, 0, 1):
+                    for dx in (-1, 0, 1):
+                        bbox[b, a, 0, y + dy, x + dx] = -3.0 * dx
+                        bbox[b, a, 1, y + dy, x + dx] = -3.0 * dy
+                        bbox[b, a, 2:4, y + dy, x + dx] = 1.2
+                        bbox[b, a, 4, y + dy, x + dx] = ob - 0.2 * (abs(dy) + abs(dx)) - 0.1 * rng.random()
+                        bbox[b, a, 5 + c, y + dy, x + dx] = cl
+            # ... and the ladder: isolated small boxes on the remaining cluster sites, class logits 12 ulps apart
+            # (confidence steps of 1-3 ulps, strictly monotone within one sigmoid implementation), visited in a shuffled order so that index order != score order
+            sites = [cells[ci] for ci in order[n_clusters:]]
+            n_lad = min(120, 4 * len(sites))
+            ks = rng.permutation(n_lad)
+            for j in range(n_lad):
+                y, x = sites[j // 4]
+                dy, dx = ((0, 0), (0, 2), (2, 0), (2, 2))[j % 4]       # 4 ladder boxes per site, two cells apart
+                a = 0
+                # one sigmoid implementation per image (torch evaluates classes below (C/32)*32 with Sleef, the rest with
+                # glibc's expf, csrc/ref_math.h): a ladder that mixed them would contain exact ties, whose order inside
+                # torch.topk is unspecified
+                nvec = (num_classes // 32) * 32
+                c = int(rng.integers(nvec)) if (b % 2 == 0 or nvec == num_classes) else nvec + int(rng.integers(num_classes - nvec))
+                bbox[b, a, 0:2, y + dy, x + dx] = 0.0
+                bbox[b, a, 2:4, y + dy, x + dx] = -1.0                   # small boxes: never overlap their neighbours
+                bbox[b, a, 4, y + dy, x + dx] = 0.5
+                bbox[b, a, 5 + c, y + dy, x + dx] = _ulp_steps(0.25, 12 * int(ks[j]))
+        elif regime == "ties_thresh":
+            # sigma(ob) * sigma(cl) = conf_thresh at the middle of the ladder (solved in float64)
+            ob = np.float32(-2.9444389791664403)                          # logit(0.05)
+            so = 1.0 / (1.0 + np.exp(-np.float64(ob)))
+            target = 0.005 / so
+            cl0 = np.float32(np.log(target / (1.0 - target)))
+            cells = [(y, x) for y in range(1, nh - 1, 2) for x in range(1, nw - 1, 2)]
+            order = rng.permutation(len(cells))
+            n_lad = min(120, len(cells))
+            ks = rng.permutation(n_lad) - n_lad // 2
+            for j in range(n_lad):
+                y, x = cells[order[j]]
+                c = int(rng.integers(num_classes))
+                bbox[b, 1, 0:2, y, x] = 0.0
+                bbox[b, 1, 2:4, y, x] = -1.5
+                bbox[b, 1, 4, y, x] = ob
+                bbox[b, 1, 5 + c, y, x] = _ulp_steps(cl0, int(ks[j]))
+        elif regime == "ties_iou":
+            # anchor slot 2 of the finest scale; tw = th = 0 -> w, h = the anchor exactly.  Pair (x, x+1): IoU = 0.5 when the
+            # centre distance is w / 3; the left box's tx walks through that point in steps of 8 ulps (~0.6 IoU ulps)
+            from math import log
+            a = num_anchors - 1
+            w_cells = None
+            k = 0
+            for y in range(4, nh - 3, 8):
+                for x in range(2, nw - 9, 8):
+                    if k >= 64:
+                        break
+                    if w_cells is None:
+                        w_cells = 40.0 / 8.0                              # ANCHORS_YOLOV4[2] = 40 px wide, 8 px cells
+                    s2 = 1.0 / (1.0 + np.exp(-2.0))
+                    s1 = s2 + 1.0 - w_cells / 3.0                         # (1 + s2 - s1) = w / 3 in cell units
+                    t1 = np.float32(log(s1 / (1.0 - s1)))
+                    for xx, tx, ob in ((x, _ulp_steps(t1, 8 * (k - 32)), 3.0), (x + 1, np.float32(2.0), 2.0)):
+                        bbox[b, a, 0, y, xx] = tx
+                        bbox[b, a, 1, y, xx] = 0.0
+                        bbox[b, a, 2:4, y, xx] = 0.0
+                        bbox[b, a, 4, y, xx] = ob
+                        bbox[b, a, 5, y, xx] = 3.0                        # class 0: no class offset on the corners
+                    k += 1
+
+
 def synth_heads(seed, batch, grid_sizes, num_anchors=3, num_classes=80, regime="mixed",
                 orien_scale=4):
     """Seeded head tensors in the model's output format, for postprocess-only tests.
@@ -99,6 +189,13 @@ def synth_heads(seed, batch, grid_sizes, num_anchors=3, num_classes=80, regime="
             'sparse'      - fewer than nms_pre pairs pass, fewer than nms_post survive NMS
             'sparse_many' - fewer than nms_pre pairs pass, more than nms_post survive NMS
             'empty'       - nothing passes (K = 0)
+            'ties_cut'    - adversarial: ~39 tight clusters (351 strong pairs) plus a LADDER of 120 isolated boxes whose class
+                            logits are 12 float32 ulps apart, so their confidences are 1-3 ulps apart and the
+                            top-nms_pre cut falls inside the ladder; which ladder members survive is visible in the output
+            'ties_thresh' - adversarial: ~40 clear detections plus a ladder of 120 pairs whose confidences step through
+                            conf_thresh = 0.005 about two ulps at a time
+            'ties_iou'    - adversarial: 64 isolated pairs of same-class boxes in neighbouring cells whose IoU steps through
+                            0.5 a fraction of an ulp at a time (log-sizes 0, so the sizes are exact in any exp)
     The orientation maps are smooth fields pointing roughly at random centres so that
     masks are blobs rather than noise.
     """
@@ -106,7 +203,7 @@ def synth_heads(seed, batch, grid_sizes, num_anchors=3, num_classes=80, regime="
     per_anchor = 5 + num_classes
     total = sum(num_anchors * nh * nw for nh, nw in grid_sizes)
     target_active = {"dense": 0, "mixed": 700, "clustered": 60, "sparse": 55, "sparse_many": 260,
-                     "empty": 0}[regime]
+                     "empty": 0, "ties_cut": 0, "ties_thresh": 22, "ties_iou": 0}[regime]
     target_active = min(target_active, total // 3)
     out = []
     oh = grid_sizes[-1][0] * 8 // orien_scale
@@ -153,6 +250,8 @@ def synth_heads(seed, batch, grid_sizes, num_anchors=3, num_classes=80, regime="
                         bbox[b, a, 0, y, x] = 2.0; bbox[b, a, 0, y, x + 1] = -2.0
                         bbox[b, a, 2:4, y, x] = 0.7; bbox[b, a, 2:4, y, x + 1] = 0.7
                         bbox[b, a, 4, y, x + 1] = ob - 0.5
+        if regime.startswith("ties"):
+            _plant_ties(rng, bbox, regime, nh, nw, grid_sizes, num_anchors, num_classes)
         ys = (np.arange(oh, dtype=np.float32) + 0.5) / oh
         xs = (np.arange(ow, dtype=np.float32) + 0.5) / ow
         orien = np.empty((batch, num_anchors, 2, oh, ow), dtype=np.float32)

@@ -20,12 +20,12 @@ def test_library_exports_every_declared_symbol(built):
     L = omlib.load()
     for name in declared:
         assert hasattr(L, name)
-    assert L.om_version() == 110
+    assert L.om_version() == 120
 
 
 def test_struct_layouts_match_header(built):
     assert ctypes.sizeof(omlib.LayerInfo) == 64 + 8 * 4 + 6 * 8
-    assert ctypes.sizeof(omlib.PostCfg) == 4 * (1 + 3 + 3 + 2 + 1 + 9 + 9 + 9 + 1 + 2 + 2 + 1 + 1)
+    assert ctypes.sizeof(omlib.PostCfg) == 4 * (1 + 3 + 3 + 2 + 1 + 9 + 9 + 9 + 1 + 2 + 2 + 1 + 1 + 2)
 
 
 def test_graph_matches_reference_state_dict(built):
@@ -121,6 +121,60 @@ def test_registry_builders_mirror_reference(built):
     assert L.om_postprocess_workspace_bytes(ctypes.byref(c), 1) == 0     # beyond the fused path's limit
 
 
+def test_builder_optional_nms_and_backends(built):
+    """trainer/builder.py:75 pops 'nms' with a default of None (-> the default batched_nms); the NMS backend and
+    batched_nms(normalized=...) travel from the config into the kernel's cfg struct."""
+    from orienmask_amd import builder, eval as om_eval
+    post = builder.build_postprocess(dict(type="OrienMaskYOLOPostProcess", **post_cfg((544, 544))), device=torch.device("cpu"))
+    assert post.nms is om_eval.batched_nms and post.nms_thresh == 0.5 and post.nms_backend == "cpu" and post.nms_normalized
+    c = post.cfg_struct(256)
+    assert (c.nms_semantics, c.nms_normalized) == (0, 1)
+    post = builder.build_postprocess(dict(type="OrienMaskYOLOPostProcess",
+                                          nms=dict(type="batched_nms", threshold=0.6, normalized=False, backend="cuda"),
+                                          **post_cfg((544, 544))), device=torch.device("cpu"))
+    c = post.cfg_struct(256)
+    assert (c.nms_semantics, c.nms_normalized, post.nms_thresh) == (1, 0, pytest.approx(0.6))
+    om_eval.set_nms_backend("cuda")
+    try:
+        assert om_eval.OrienMaskYOLOPostProcess(**post_cfg((96, 96))).nms_backend == "cuda"
+        assert om_eval.OrienMaskYOLOPostProcess(nms_backend="cpu", **post_cfg((96, 96))).nms_backend == "cpu"
+    finally:
+        om_eval.set_nms_backend("cpu")
+    with pytest.raises(ValueError):
+        om_eval.set_nms_backend("rocm")
+    with pytest.raises(ValueError):
+        om_eval.OrienMaskYOLOPostProcess(**dict(post_cfg((96, 96)), nms_pre=2000))
+    with pytest.raises(TypeError):
+        om_eval.OrienMaskYOLOPostProcess(nms_func=functools.partial(om_eval.batched_nms, iou=0.5), **post_cfg((96, 96)))
+
+
+def test_pretrained_loads_in_the_backbone_key_space(tmp_path, built):
+    """model/base.py:48-64: the pretrained file is loaded INSIDE the backbone, so its keys are backbone-relative
+    ('conv1.conv_block.0.weight', as in pretrained_darknet53.pth); foreign / mis-shaped keys are ignored and reported."""
+    import warnings
+    from orienmask_amd import model as om_model
+    sd = synth.synth_state_dict(13)
+    backbone = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+    backbone["fc.weight"] = torch.zeros(1000, 1024)                        # classifier head of the ImageNet checkpoint
+    backbone["conv1.conv_block.0.weight"] = torch.zeros(32, 3, 5, 5)       # wrong shape: ignored
+    path = str(tmp_path / "pretrained_darknet53.pth")
+    torch.save(backbone, path)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        net = om_model.OrienMaskYOLOFPNPlus(3, 80, pretrained=path)
+    assert any("ignored keys" in str(x.message) for x in w)
+    own = net.state_dict()
+    assert torch.equal(own["backbone.conv6.4.conv.1.conv_block.0.weight"], sd["backbone.conv6.4.conv.1.conv_block.0.weight"])
+    assert torch.equal(own["backbone.conv2.0.conv_block.1.running_var"], sd["backbone.conv2.0.conv_block.1.running_var"])
+    assert not torch.equal(own["backbone.conv1.conv_block.0.weight"], sd["backbone.conv1.conv_block.0.weight"])
+    assert not torch.equal(own["neck32.0.conv_block.0.weight"], sd["neck32.0.conv_block.0.weight"])
+    torch.save({"backbone." + k: v for k, v in backbone.items()}, path)    # full-model keys do NOT match (as in the reference)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        om_model.OrienMaskYOLOFPNPlus(3, 80, pretrained=path)
+    assert any("none of its" in str(x.message) for x in w)
+
+
 def test_cpu_tensors_are_rejected_loudly(built):
     from orienmask_amd import eval as om_eval
     from orienmask_amd.model import OrienMaskYOLOFPNPlus
@@ -148,7 +202,7 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
-                assert "nms_ref" not in text and "libnms_ref" not in text, f
+                assert "nms_ref" not in text and "libnms_ref" not in text and "nms_cuda_ref" not in text, f
 
 
 def test_timer_api_mirrors_reference():

@@ -50,6 +50,21 @@ def import_reference():
     return ref_config, ref_model, ref_eval, ref_function
 
 
+class single_thread:
+    """The reference's postprocess under ONE torch thread.  torch's CPU sigmoid is not bit-reproducible across thread
+    counts: TensorIterator hands each thread a LINEAR element range, a range that starts or ends inside a row of class logits
+    is processed as a shorter row, and which of a row's elements fall in the vectorised part (Sleef expf) and which in the
+    scalar tail (glibc expf) then shifts -- the two differ by one ulp on ~4 % of inputs.  With one thread every row is whole,
+    which is also what csrc/ref_math.h restates; so the fixtures are the reference's answer as `OMP_NUM_THREADS=1` gives it."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        torch.set_num_threads(1)
+
+    def __exit__(self, *a):
+        torch.set_num_threads(self.n)
+
+
 def pack_masks(m):
     m = np.asarray(m, dtype=np.uint8)
     return np.packbits(m.reshape(m.shape[0], int(np.prod(m.shape[1:]))), axis=1)
@@ -120,13 +135,20 @@ def main():
         ("p160x128_mixed_b2", (160, 128), 2, "mixed", 20),
         ("p160x128_sparse_b2", (160, 128), 2, "sparse", 21),
         ("p160x128_sparse_many_b2", (160, 128), 2, "sparse_many", 22),
+        # adversarial near-ties: scores 1-3 ulps apart straddling the nms_pre cut, scores stepping
+        # through conf_thresh, IoUs stepping through the NMS threshold a fraction of an ulp at a time
+        ("p544_ties_cut_b2", (544, 544), 2, "ties_cut", 31),
+        ("p544_ties_thresh_b2", (544, 544), 2, "ties_thresh", 32),
+        ("p544_ties_iou_b1", (544, 544), 1, "ties_iou", 33),
     ]
     for name, size, batch, regime, seed in post_cases:
         pc = post_cfg(size)
         post = reval.OrienMaskYOLOPostProcess(nms_func=functools.partial(rfunc.batched_nms, threshold=0.5), **pc)
         heads = synth.synth_heads(seed, batch, pc["grid_size"], regime=regime)
-        with torch.no_grad():
+        with torch.no_grad(), single_thread():
             res = post(heads)
+        if regime.startswith("ties"):
+            check_tie_fixture(post, heads, regime, res)
         rec = dict(size=np.array(size), batch=np.int64(batch), seed=np.int64(seed), regime=np.array(regime))
         for b, r in enumerate(res):
             rec["bbox%d" % b] = r["bbox"].numpy()
@@ -142,12 +164,19 @@ def main():
     mcfg.pop("type"); mcfg["pretrained"] = None
     net = rmodel.OrienMaskYOLOFPNPlus(**mcfg).eval()
     fwd_cases = [
-        ("f96_b2", 1, (96, 96), 2, 21, -22.0),
-        ("f160x128_b1", 2, (160, 128), 1, 22, -16.0),
-        ("f544_b1", 3, (544, 544), 1, 23, -16.0),
+        ("f96_b2", 1, (96, 96), 2, 21, -22.0, 4.0),
+        # head_gain 0.7 / obj_bias -3: logits far from saturation, no two of the 400 best scores equal (with head_gain 4 the
+        # sigmoids saturate and hundreds of pairs tie at exactly 1.0: which of them torch.topk keeps is unspecified)
+        ("f160x128_b1", 2, (160, 128), 1, 22, -3.0, 0.7),
+        ("f544_b1", 3, (544, 544), 1, 23, -16.0, 4.0),           # the bench's weights (saturated heads, some exact score ties)
+        # six images: above the batch size at which om_forward switches the stride-1 3x3 layers from Winograd F(2x2,3x3) to
+        # F(2x4,3x3), so that path is pinned against the reference's own tensors and END-TO-END detections too
+        ("f544_b6", 4, (544, 544), 6, 28, -3.0, 0.7),
+        # few pairs pass: no top-k, survivors are emitted in candidate order (the other branch of postprocess.py:107,150)
+        ("f544_sparse_b2", 5, (544, 544), 2, 29, -8.03, 0.4),
     ]
-    for name, wseed, size, batch, xseed, obj_bias in fwd_cases:
-        sd = synth.synth_state_dict(wseed, obj_bias=obj_bias, head_gain=4.0)
+    for name, wseed, size, batch, xseed, obj_bias, head_gain in fwd_cases:
+        sd = synth.synth_state_dict(wseed, obj_bias=obj_bias, head_gain=head_gain)
         missing = net.load_state_dict(sd, strict=True)       # proves the 524 keys line up
         x = synth.synth_image_batch(xseed, batch, size[0], size[1])
         with torch.no_grad():
@@ -156,7 +185,7 @@ def main():
             feats.update(x32=x32, x16=x16, x8=x8, x4=x4)
             out = net(x)
         rec = dict(size=np.array(size), batch=np.int64(batch), wseed=np.int64(wseed), xseed=np.int64(xseed),
-                   obj_bias=np.float32(obj_bias), head_gain=np.float32(4.0))
+                   obj_bias=np.float32(obj_bias), head_gain=np.float32(head_gain))
         tensors = dict(bbox32=out[0][0], bbox16=out[1][0], bbox8=out[2][0],
                        oriens=torch.cat([out[0][1], out[1][1], out[2][1]], 1), **feats)
         full = size[0] <= 160
@@ -169,15 +198,46 @@ def main():
         # end to end through the reference postprocess
         pc = post_cfg(size)
         post = reval.OrienMaskYOLOPostProcess(nms_func=functools.partial(rfunc.batched_nms, threshold=0.5), **pc)
-        with torch.no_grad():
+        with torch.no_grad(), single_thread():
             res = post(out)
         for b, r in enumerate(res):
             rec["bbox_det%d" % b] = r["bbox"].numpy(); rec["cls_det%d" % b] = r["cls"].numpy()
             rec["mask%d" % b] = pack_masks(r["mask"].numpy()); rec["maskshape%d" % b] = np.array(r["mask"].shape)
         np.savez_compressed(os.path.join(OUT, "fwd_%s.npz" % name), **rec)
         print(name, {k: float(rec[k + "_absmax"]) for k in ("x4", "x32", "bbox32", "bbox8", "oriens")},
-              [int(r["bbox"].shape[0]) for r in res],
+              [int(r["bbox"].shape[0]) for r in res], "exact score ties among the detections:",
+              [int(r["bbox"].shape[0] - np.unique(r["bbox"][:, 4].numpy()).size) for r in res],
               "%.0f KB" % (os.path.getsize(os.path.join(OUT, "fwd_%s.npz" % name)) / 1024))
+
+
+def check_tie_fixture(post, heads, regime, res):
+    """The adversarial fixtures must actually be adversarial: assert the near-tie structure on the reference's own numbers."""
+    for b in range(heads[0][0].shape[0]):
+        confs = []
+        for i in range(post.scales):
+            nA, nH, nW = post.num_anchors[i], post.nHs[i], post.nWs[i]
+            t = heads[i][0][b].view(nA, -1, nH, nW).permute(0, 2, 3, 1).contiguous()
+            _, conf = post.get_boxes(t, nH, nW, post.normalized_anchors[post.anchor_mask[i]], post.grid_x[i], post.grid_y[i])
+            confs.append(conf)
+        conf = torch.cat(confs, 0)
+        passing = np.sort(conf[conf > post.conf_thresh].numpy())[::-1]
+        bits = passing.view(np.int32).astype(np.int64)
+        if regime == "ties_cut":
+            assert passing.size > post.nms_pre
+            gap = bits[post.nms_pre - 1] - bits[post.nms_pre]
+            assert 1 <= gap <= 3, gap                                  # the cut separates scores 1-3 ulps apart
+            lad = bits[passing < 0.5]
+            assert (np.diff(lad) < 0).all() and (np.diff(lad) >= -4).all()
+            assert int((res[b]["bbox"][:, 4] < 0.5).sum()) > 20      # ladder members are visible in the output
+        elif regime == "ties_thresh":
+            thr = np.float32(post.conf_thresh)
+            near = conf[(conf > 0.00499) & (conf < 0.00501)].numpy()
+            d = near.view(np.int32).astype(np.int64) - int(thr.view(np.int32))
+            assert (d > 0).sum() >= 30 and (d <= 0).sum() >= 30 and np.abs(d).min() <= 2
+            assert res[b]["bbox"].shape[0] < post.nms_post             # nothing is cut away after the threshold
+        elif regime == "ties_iou":
+            k = res[b]["bbox"].shape[0]
+            assert 64 + 10 <= k <= 128 - 10 and k <= post.nms_post, k  # the IoU = 0.5 crossing lies inside the ladder
 
 
 def yolo_golden():

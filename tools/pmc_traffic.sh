@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the bench's kernels from PMC counters (two separate passes, kernel-trace only):
 #   gpurun -- 'bash tools/pmc_traffic.sh'
-# Writes gpurun_out/pmc_traffic.json: per kernel name, launches, FETCH_SIZE and WRITE_SIZE sums (KiB as rocprofv3
+# Writes gpurun_out/pmc_traffic.json (copy it to profiles/rNN_pmc_traffic.json; bench.py reads it and checks _meta.lib_sha256): per kernel name, launches, FETCH_SIZE and WRITE_SIZE sums (KiB as rocprofv3
 # reports them).  On gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads: double it
 # (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is used as reported.
 set -e
@@ -17,8 +17,11 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 TAG=$TAG python - <<'PY'
-import csv, glob, collections, json, os
+import csv, glob, collections, hashlib, json, os
 out = collections.OrderedDict()
+out["_meta"] = dict(lib_sha256=hashlib.sha256(open("orienmask_amd/lib/liborienmask_hip.so", "rb").read()).hexdigest(),
+                    batch=32, size=544, command="bench.py --steps 2 --warmup 1 under rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes)",
+                    units="FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; hbm_bytes_per_launch_corrected = (2*FETCH + WRITE)*1024")
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("gpurun_out/pmc_%s/**/*counter_collection.csv" % c, recursive=True)[0]
     per = collections.defaultdict(lambda: [set(), 0.0])
@@ -30,9 +33,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         d = out.setdefault(name, {})
         d["launches"] = len(ids); d[c + "_sum"] = tot; d[c + "_per_launch"] = tot / len(ids)
 for name, d in out.items():
-    if "FETCH_SIZE_per_launch" in d and "WRITE_SIZE_per_launch" in d:
+    if name != "_meta" and "FETCH_SIZE_per_launch" in d and "WRITE_SIZE_per_launch" in d:
         d["hbm_bytes_per_launch_corrected"] = (2.0 * d["FETCH_SIZE_per_launch"] + d["WRITE_SIZE_per_launch"]) * 1024.0
 json.dump(out, open("gpurun_out/pmc_traffic%s.json" % os.environ.get("TAG", ""), "w"), indent=1)
 for name, d in out.items():
+    if name == "_meta": continue
     print("%-60s launches %4d  fetch/launch %10.1f KiB  write/launch %10.1f KiB" % (name[:60], d.get("launches", 0), d.get("FETCH_SIZE_per_launch", 0), d.get("WRITE_SIZE_per_launch", 0)))
 PY
