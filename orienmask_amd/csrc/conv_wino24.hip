@@ -94,7 +94,6 @@ struct Wino24Params {
     int leaky, res_pix_stride, out_pix_stride, vec_io;
 };
 
-template <int EXP>
 __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params p) {
     constexpr int BM = 64, BN = 64, WM = 32, WN = 32;
     constexpr int NWN = BN / WN;
@@ -116,15 +115,15 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
     const int ksteps = 24 * p.kc;
     const size_t v_plane = (size_t)p.T * p.C, u_plane = (size_t)p.cout_pad * p.C;
 
-    for (int iter = 0;; ++iter) {
-        int tile;
-        if constexpr (EXP == 5) {
-            tile = blockIdx.x + iter * gridDim.x;
-        } else {
-            if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
-            __syncthreads();
-            tile = *s_ticket;
-        }
+    for (;;) {
+        // the ticket's round trip is paid by lane 0's wave only: the others wait at a raw barrier, which (unlike __syncthreads)
+        // does not make them drain the previous tile's output stores first.  (Drawing the NEXT ticket at the start of a tile
+        // hides the round trip too, but pins the last partial round of tiles to the workgroups that started first: the
+        // 34 x 34 layers went from 0.33 to 0.44 ms.)
+        if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int tile = *s_ticket;
         if (tile >= p.total_tiles) break;
         tile = __builtin_amdgcn_readfirstlane(tile);
         const int tile_n = tile % p.n_tiles;
@@ -198,14 +197,13 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
                     const int slot = q * 4 + t;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[t], ca[t], acc, 0, 0, 0);
                     if (t == 1 && q < 3) read_frags(na, nb, buf, q + 1);
-                    if constexpr (EXP != 3) { if (slot < NP) issue_piece(slot, buf2, live2); }
+                    if (slot < NP) issue_piece(slot, buf2, live2);
                     if (slot == 12) read_frags(na, nb, buf1, 0);
                     if (slot == 11) {
                         // everything older than this step's NP pieces has landed = the operands of step s+1;
                         // all my reads of the current buffer are done (lgkmcnt) -> raw barrier, no compiler fence
-                        if constexpr (EXP == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NP) : "memory");
-                        if constexpr (EXP != 4) __builtin_amdgcn_s_barrier();
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NP) : "memory");
+                        __builtin_amdgcn_s_barrier();
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -241,13 +239,10 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
-        if constexpr (EXP == 2) {
-            if (p.T == -12345) {        // never true: keeps the accumulators alive without an epilogue
-                for (int e = 0; e < 8; ++e) p.out[tid + e * 256] = outa[e >> 2][e & 3][tid & 15];
-            }
-            continue;
-        }
-        // ---- epilogue: eight output positions through LDS C tiles, three positions per pass (the ring holds 48 KiB)
+        // ---- epilogue: row geometry once per tile; per pass of two output positions the residual loads are issued BEFORE the
+        // LDS staging (they fly during it), C tiles [position][row][channel chunk ^ (row & 7)] go through LDS and leave as 16-byte
+        // rows; the barriers wait for LDS only (a __syncthreads() would also drain the stores: ~2 us of HBM write latency per
+        // pass).  Measured in-network: 15.0 -> 14.3 ms over the 30 layers (profiles/r02_experiments.md).
         f32x4* sC = smem;
         const int n4 = tid % CH, r0 = tid / CH;
         const int n = n0 + n4 * 4;
@@ -255,9 +250,40 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
         const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
         const int nvalid = p.cout - n;
         const bool vec = p.vec_io && nvalid >= 4;
-        constexpr int PPP = 3;                       // positions per pass
+        int pixb[BM / RP];
+        unsigned okb[BM / RP];           // bit py * 4 + px: that output position of the row's tile exists
+#pragma unroll
+        for (int ps = 0; ps < BM / RP; ++ps) {
+            const int m = m0 + ps * RP + r0;
+            const bool mok = m < p.T && nvalid > 0;
+            const int mm = mok ? m : 0;
+            const int bi = mm / (p.TH * p.TW);
+            const int rr = mm - bi * p.TH * p.TW;
+            const int ty = rr / p.TW, tx = rr - ty * p.TW;
+            pixb[ps] = (bi * p.H + 2 * ty) * p.W + 4 * tx;
+            unsigned ok = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                ok |= ((mok && 2 * ty + (q >> 2) < p.H && 4 * tx + (q & 3) < p.W) ? 1u : 0u) << q;
+            okb[ps] = ok;
+        }
+        constexpr int PPP = 2;
 #pragma unroll
         for (int pass = 0; pass < (8 + PPP - 1) / PPP; ++pass) {
+            f32x4 rres[PPP][BM / RP];
+            if (p.res && vec) {
+#pragma unroll
+                for (int e = 0; e < PPP; ++e) {
+                    const int pq = pass * PPP + e;
+                    if (pq >= 8) continue;
+#pragma unroll
+                    for (int ps = 0; ps < BM / RP; ++ps) {
+                        const size_t pix = (size_t)(pixb[ps] + (pq >> 2) * p.W + (pq & 3));
+                        const float* rp = p.res + (((okb[ps] >> pq) & 1u) ? pix * p.res_pix_stride + n : 0);
+                        rres[e][ps] = *reinterpret_cast<const f32x4*>(rp);
+                    }
+                }
+            }
             const int ml = wm * WM + fi;
 #pragma unroll
             for (int e = 0; e < PPP; ++e) {
@@ -271,46 +297,35 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
                     sC[e * BM * CH + ml * CH + (c4 ^ (ml & 7))] = v;
                 }
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (int e = 0; e < PPP; ++e) {
                 const int pq = pass * PPP + e;
                 if (pq >= 8) continue;
-                const int py = pq >> 2, px = pq & 3;
-#pragma unroll 2
+#pragma unroll
                 for (int ps = 0; ps < BM / RP; ++ps) {
+                    if (!((okb[ps] >> pq) & 1u)) continue;
                     const int mr = ps * RP + r0;
-                    const int m = m0 + mr;
-                    if (m >= p.T || nvalid <= 0) continue;
-                    const int bi = m / (p.TH * p.TW);
-                    const int rr = m - bi * p.TH * p.TW;
-                    const int ty = rr / p.TW, tx = rr - ty * p.TW;
-                    const int y = 2 * ty + py, x = 4 * tx + px;
-                    if (y >= p.H || x >= p.W) continue;
-                    const size_t pix = ((size_t)bi * p.H + y) * p.W + x;
+                    const size_t pix = (size_t)(pixb[ps] + (pq >> 2) * p.W + (pq & 3));
                     f32x4 v = sC[e * BM * CH + mr * CH + (n4 ^ (mr & 7))];
-                    if constexpr (EXP == 1) {
-                        if (p.T == -12345) *reinterpret_cast<f32x4*>(p.out + pix) = v;
-                        continue;
-                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         float tv = fmaf(v[k], sc[k], sh[k]);
                         v[k] = p.leaky ? (tv > 0.f ? tv : tv * 0.1f) : tv;
                     }
                     float* o = p.out + pix * p.out_pix_stride + n;
-                    if (p.res) {
-                        const float* rp = p.res + pix * p.res_pix_stride + n;
-                        if (vec) v += *reinterpret_cast<const f32x4*>(rp);
-                        else
-                            for (int k = 0; k < 4 && k < nvalid; ++k) v[k] += rp[k];
+                    if (vec) {
+                        if (p.res) v += rres[e][ps];
+                        *reinterpret_cast<f32x4*>(o) = v;
+                    } else {
+                        const float* rp = p.res ? p.res + pix * p.res_pix_stride + n : nullptr;
+                        for (int k = 0; k < 4 && k < nvalid; ++k) o[k] = rp ? v[k] + rp[k] : v[k];
                     }
-                    if (vec) *reinterpret_cast<f32x4*>(o) = v;
-                    else
-                        for (int k = 0; k < 4 && k < nvalid; ++k) o[k] = v[k];
                 }
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
     }
 }
@@ -350,15 +365,7 @@ int launch_conv_winograd24(const ConvArgs& a, float* scratch, hipStream_t stream
     OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "winograd24: %lld tiles out of range", total);
     p.total_tiles = (int)total;
     const long long grid = total < 512 ? total : 512;        // 2 workgroups per CU (register-bound)
-    static const int exp_ = [] { const char* e = getenv("OM_EXPERIMENT"); return e ? atoi(e) : 0; }();
-    switch (exp_) {
-        case 1: hipLaunchKernelGGL(wino24_gemm_kernel<1>, dim3((unsigned)grid), dim3(256), 0, stream, p); break;
-        case 2: hipLaunchKernelGGL(wino24_gemm_kernel<2>, dim3((unsigned)grid), dim3(256), 0, stream, p); break;
-        case 3: hipLaunchKernelGGL(wino24_gemm_kernel<3>, dim3((unsigned)grid), dim3(256), 0, stream, p); break;
-        case 4: hipLaunchKernelGGL(wino24_gemm_kernel<4>, dim3((unsigned)grid), dim3(256), 0, stream, p); break;
-        case 5: hipLaunchKernelGGL(wino24_gemm_kernel<5>, dim3((unsigned)grid), dim3(256), 0, stream, p); break;
-        default: hipLaunchKernelGGL(wino24_gemm_kernel<0>, dim3((unsigned)grid), dim3(256), 0, stream, p); break;
-    }
+    hipLaunchKernelGGL(wino24_gemm_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }
