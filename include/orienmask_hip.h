@@ -132,9 +132,13 @@ int om_layer_tile_f16(const om_model* m, int index, int B, int H, int W, int* bm
  * Where layer `index`'s output lives inside the workspace of the last om_forward (f16 = 0) / om_forward_f16 (f16 = 1) call
  * at this problem size: an NHWC view [B, H/div, W/div, channels] starting byte_offset bytes into the workspace, pixel
  * stride pix_stride ELEMENTS (a concat buffer's slice has pix_stride > channels).  The four head layers write
- * caller-owned tensors and are rejected. */
+ * caller-owned tensors and are rejected; so is a model without om_model_keep_activations(m, 1). */
 int om_layer_output_view(const om_model* m, int index, int B, int H, int W, int f16, size_t* byte_offset, int* channels,
                          int* pix_stride, int* div);
+/* The forward's activations (and the Winograd scratch) share workspace memory by live range: a tensor's slab is reused once its
+ * last consumer has run.  keep = 1 gives every tensor its own slab again (larger om_forward_workspace_bytes) so that
+ * om_layer_output_view can be read after the forward; it must be set before the workspace is sized. */
+int om_model_keep_activations(om_model* m, int keep);
 
 /* ---- measurement: per-layer durations with HIP events on the stream om_forward launches on
  * (the reference measures with torch.cuda.Event pairs, utils/timer.py:70-82).  While enabled, every

@@ -533,38 +533,50 @@ def rle_counts(mask2d):
     return np.diff(edges).astype(np.int64).tolist()
 
 
+_rle_lib = None
+
+
+def _load_rle_lib():
+    global _rle_lib
+    if _rle_lib is None:
+        path = os.path.join(_HERE, "librle_ref.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/librle_ref.so not built; run `make -C oracle` or __graft_entry__.build()")
+        lib = ctypes.CDLL(path)
+        for f in (lib.rle_ref_encode, lib.rle_ref_to_string, lib.rle_ref_from_string):
+            f.restype = ctypes.c_long
+        _rle_lib = lib
+    return _rle_lib
+
+
 def rle_to_string(counts):
-    """pycocotools rleToString (maskApi.c): delta against the run two back, 5 bits per char. Parity unpinned."""
-    s = []
-    for i, c in enumerate(counts):
-        x = int(c)
-        if i > 2:
-            x -= int(counts[i - 2])
-        more = True
-        while more:
-            ch = x & 0x1F
-            x >>= 5
-            more = (x != -1) if (ch & 0x10) else (x != 0)
-            if more:
-                ch |= 0x20
-            s.append(chr(ch + 48))
-    return "".join(s)
+    """pycocotools rleToString through the C restatement oracle/rle_ref.c (independent of the product's Python version).
+    Parity with pycocotools itself is unpinned: the library is not available offline."""
+    lib = _load_rle_lib()
+    c = np.ascontiguousarray(np.asarray(counts, dtype=np.int64).astype(np.uint32))
+    buf = ctypes.create_string_buffer(6 * max(c.size, 1) + 1)
+    n = lib.rle_ref_to_string(c.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(c.size), buf)
+    return buf.raw[:n].decode("ascii")
 
 
 def rle_string_decode(s, n_pixels):
-    """Inverse of rle_to_string (pycocotools rleFrString), used for a round-trip property test."""
-    counts, p, i = [], 0, 0
-    while p < len(s):
-        x, k, more = 0, 0, True
-        while more:
-            c = ord(s[p]) - 48
-            x |= (c & 0x1F) << (5 * k)
-            more = bool(c & 0x20)
-            p += 1; k += 1
-            if not more and (c & 0x10):
-                x |= -1 << (5 * k)
-        if i > 2:
-            x += counts[i - 2]
-        counts.append(x); i += 1
+    """pycocotools rleFrString (oracle/rle_ref.c): the inverse, for the round-trip property test."""
+    lib = _load_rle_lib()
+    out = np.zeros(len(s) + 1, dtype=np.uint32)
+    m = lib.rle_ref_from_string(ctypes.c_char_p(s.encode("ascii")), out.ctypes.data_as(ctypes.c_void_p))
+    counts = out[:m].astype(np.int64).tolist()
     assert sum(counts) == n_pixels
     return counts
+
+
+def rle_counts_c(mask_hw):
+    """pycocotools rleEncode (oracle/rle_ref.c) on one [h, w] mask: column-major runs, the first one counts zeros."""
+    lib = _load_rle_lib()
+    m = np.asfortranarray(np.asarray(mask_hw, dtype=np.uint8))
+    flat = np.ascontiguousarray(m.reshape(-1, order="F"))
+    out = np.zeros(flat.size + 1, dtype=np.uint32)
+    k = lib.rle_ref_encode(flat.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(m.shape[0]), ctypes.c_long(m.shape[1]),
+                           out.ctypes.data_as(ctypes.c_void_p))
+    return out[:k].astype(np.int64).tolist()
+
+

@@ -223,8 +223,7 @@ static int launch_c3(IgemmHParams p, int cout_pad, hipStream_t stream) {
 // true if the layer can run here: stride-1 3x3 whose input view fits a 2^31-byte buffer descriptor and whose rows are
 // short enough for a patch (any W works: the patch is a run of raster pixels, not an image rectangle)
 bool conv3x3_f16_supported(const ConvArgsH& a) {
-    static const int enabled = [] { const char* e = getenv("OM_CONV3X3_SHARED"); return e ? atoi(e) : 1; }();
-    if (!enabled || a.ks != 3 || a.stride != 1 || a.cin % 32 || a.cout_pad % 64) return false;
+    if (a.ks != 3 || a.stride != 1 || a.cin % 32 || a.cout_pad % 64) return false;
     const long long bytes = ((long long)a.B * a.H * a.W - 1) * a.in_pix_stride * 2 + a.cin * 2;
     return bytes < 0x70000000ll && a.out_mode == 0;      // headroom: patch rows run up to 320 + W pixels past the end
 }
@@ -238,8 +237,6 @@ void conv3x3_tile_for_f16(int M, int cout_pad, int* bm, int* bn) {
     const double c128 = (double)((t128 + 255) / 256) * 128 * 128 / 0.85;
     *bn = 128;
     *bm = c256 <= c128 ? 256 : 128;
-    static const int force = [] { const char* e = getenv("OM_CONV3X3_BM"); return e ? atoi(e) : 0; }();
-    if (force == 128 || force == 256) *bm = force;
 }
 
 int launch_conv3x3_f16(const ConvArgsH& a, hipStream_t stream) {

@@ -62,10 +62,9 @@ struct IgemmParams {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// DMA = true : operands go global -> LDS directly (buffer_load_dwordx4 ... lds); zero padding comes from
-//              the buffer descriptor's bounds check (offset 0x80000000 is out of range -> zeros).
-// DMA = false: operands are staged through registers (global_load_dwordx4 + ds_write_b128).
-template <int BM, int BN, int WM, int WN, bool DMA>
+// Operands go global -> LDS directly (buffer_load_dwordx4 ... lds); zero padding comes from the buffer descriptor's bounds
+// check (offset 0x80000000 is out of range -> zeros).
+template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NWN = BN / WN;
@@ -85,15 +84,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p
     const int wave = tid >> 6;
     const int wm = wave / NWN, wn = wave % NWN;
     const int lrow = tid >> 3, lcol = tid & 7;
-    const int lsw = lcol ^ ((lrow >> 1) & 7);
     const int fi = lane & 31, fk = lane >> 5;
     const int fsw = (fi >> 1) & 7;
 
     for (;;) {
         int tile;
         if (p.ticket) {
+            // lane 0's wave pays the ticket's round trip; the others wait at a raw barrier and do not drain the previous tile's
+            // output stores (a __syncthreads() would make every wave wait for them: ~2 us per tile)
             if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             tile = *s_ticket;
         } else {
             // static grid: XCD-aware, bijective remap of the workgroup id (block b runs on XCD b % 8)
@@ -110,8 +111,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p
         // ---- loader role: thread -> (row lrow + 32*j, 16-byte chunk lcol) ----------------
         int pixbase[A_CH], iy0[A_CH], ix0[A_CH];
         unsigned mokmask = 0;
-        // DMA path: offsets are relative to the first image the tile touches (keeps them < 2^31 bytes)
-        const int b_first = DMA ? (m0 < p.M ? m0 : p.M - 1) / p.HoWo : 0;
+        // offsets are relative to the first image the tile touches (keeps them < 2^31 bytes)
+        const int b_first = (m0 < p.M ? m0 : p.M - 1) / p.HoWo;
 #pragma unroll
         for (int j = 0; j < A_CH; ++j) {
             int m = m0 + lrow + 32 * j;
@@ -126,46 +127,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p
             ix0[j] = ox * p.stride - p.pad;
             mokmask |= (ok ? 1u : 0u) << j;
         }
-        const float* wrow[B_CH];
-#pragma unroll
-        for (int j = 0; j < B_CH; ++j)
-            wrow[j] = p.w + (size_t)(n0 + lrow + 32 * j) * p.taps * p.cin + lcol * 4;
-
-        f32x4 ra[A_CH], rb[B_CH];
-        unsigned okmask = 0;
-
-        auto load_step = [&](int s) {
-            const int tap = s / p.kc;
-            const int cc = s - tap * p.kc;
-            const int kh = tap / p.ks;
-            const int kw = tap - kh * p.ks;
-            const int coff = cc * 32 + lcol * 4;
-            okmask = 0;
-#pragma unroll
-            for (int j = 0; j < A_CH; ++j) {
-                const int iy = iy0[j] + kh, ix = ix0[j] + kw;
-                const bool ok =
-                    ((mokmask >> j) & 1u) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const int pix = ok ? pixbase[j] + iy * p.W + ix : pixbase[j];
-                ra[j] = *reinterpret_cast<const f32x4*>(p.in + (size_t)pix * p.in_pix_stride + coff);
-                okmask |= (ok ? 1u : 0u) << j;
-            }
-            const int woff = tap * p.cin + cc * 32;
-#pragma unroll
-            for (int j = 0; j < B_CH; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] + woff);
-        };
-
-        auto store_step = [&](int buf) {
-            f32x4* sA = smem + buf * (BM + BN) * 8;
-            f32x4* sB = sA + BM * 8;
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < A_CH; ++j) sA[(lrow + 32 * j) * 8 + lsw] = ((okmask >> j) & 1u) ? ra[j] : zero;
-#pragma unroll
-            for (int j = 0; j < B_CH; ++j) sB[(lrow + 32 * j) * 8 + lsw] = rb[j];
-        };
-
-        // ---- DMA path: descriptors and the issue of ONE 1-KiB piece (8 rows x 128 B) per call
+        // ---- descriptors and the issue of ONE 1-KiB piece (8 rows x 128 B) per call
         constexpr int NP = A_CH + B_CH;                     // pieces per wave per k-step
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         const float* in_base = p.in + (size_t)b_first * p.H * p.W * p.in_pix_stride;
@@ -182,7 +144,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p
             }
         };
         auto issue_piece = [&](int piece, int buf, bool live) {
-            if constexpr (DMA) {
+            {
                 const int coff = n_cc * 32 + scol * 4;
                 f32x4* dst = smem + buf * (BM + BN) * 8 + wave_u * 64;
                 if (piece < A_CH) {
@@ -210,29 +172,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-        auto compute = [&](int buf) {
-            const f32x4* sA = smem + buf * (BM + BN) * 8 + (wm * WM + fi) * 8;
-            const f32x4* sB = smem + buf * (BM + BN) * 8 + BM * 8 + (wn * WN + fi) * 8;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ch = (2 * q + fk) ^ fsw;
-                f32x4 fa[TM], fb[TN];
-#pragma unroll
-                for (int a = 0; a < TM; ++a) fa[a] = sA[a * 32 * 8 + ch];
-#pragma unroll
-                for (int b = 0; b < TN; ++b) fb[b] = sB[b * 32 * 8 + ch];
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int a = 0; a < TM; ++a)
-#pragma unroll
-                        for (int b = 0; b < TN; ++b)
-                            // weights first: D[i = channel][j = pixel]
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[b][t], fa[a][t], acc[a][b], 0, 0, 0);
-            }
-        };
-
-        if constexpr (DMA) {
+        {
             // Software pipeline with ONE barrier per k-step and nothing outside the MFMA stream:
             //   slots 0..NP-1   : one DMA piece of step s+1 each
             //   slot (q, t=1)   : ds_reads of fragment group q+1
@@ -299,17 +239,6 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-        } else {
-            load_step(0);
-            store_step(0);
-            __syncthreads();
-            for (int s = 0; s < p.ksteps; ++s) {
-                const bool more = s + 1 < p.ksteps;
-                if (more) load_step(s + 1);
-                compute(s & 1);
-                if (more) store_step((s + 1) & 1);
-                __syncthreads();
-            }
         }
 
         // ---- epilogue, phase 1: accumulators -> LDS C tile [m][n], chunk index swizzled with m & 7.
@@ -394,7 +323,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p
             }
         }
         if (!p.ticket) break;
-        __syncthreads();      // the C tile is dead before the next tile's operands land in LDS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the C tile is dead before the next tile's operands land in
+        __builtin_amdgcn_s_barrier();                            // LDS; the stores keep flying
     }
 }
 
@@ -418,11 +348,6 @@ static TileChoice choose_tile(int M, int cout_pad) {
     return best;
 }
 
-static bool use_dma() {
-    static const int v = [] { const char* e = getenv("OM_CONV_DMA"); return e ? atoi(e) : 1; }();
-    return v != 0;
-}
-
 template <int BM, int BN, int WM, int WN>
 static int launch_tile(IgemmParams p, int cout_pad, int blocks_per_cu, hipStream_t stream) {
     const int m_tiles = (p.M + BM - 1) / BM;
@@ -431,13 +356,8 @@ static int launch_tile(IgemmParams p, int cout_pad, int blocks_per_cu, hipStream
     OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "conv: %lld tiles out of range", total);
     p.total_tiles = (int)total;
     long long grid = total;
-    static const int bpc_override = [] { const char* e = getenv("OM_CONV_BPC"); return e ? atoi(e) : 0; }();
-    if (bpc_override > 0) blocks_per_cu = bpc_override;
     if (p.ticket) grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
-    if (use_dma())
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }
@@ -476,9 +396,7 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t stream) {
     p.vec_io = (a.out_mode != 2 && a.out_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
                 (!a.res || (a.res_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)))
                    ? 1 : 0;
-    TileChoice t = choose_tile(p.M, a.cout_pad);
-    static const int force_tile = [] { const char* e = getenv("OM_CONV_TILE"); return e ? atoi(e) : 0; }();   // e.g. 64128
-    if (force_tile > 0 && a.cout_pad % (force_tile % 1000) == 0) t = TileChoice{force_tile / 1000, force_tile % 1000};
+    const TileChoice t = choose_tile(p.M, a.cout_pad);
     if (t.bm == 128 && t.bn == 128) return launch_tile<128, 128, 64, 64>(p, a.cout_pad, 2, stream);
     if (t.bm == 64 && t.bn == 128) return launch_tile<64, 128, 32, 64>(p, a.cout_pad, 3, stream);
     if (t.bm == 128 && t.bn == 64) return launch_tile<128, 64, 64, 32>(p, a.cout_pad, 3, stream);

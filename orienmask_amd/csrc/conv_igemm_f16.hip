@@ -242,9 +242,7 @@ static TileChoiceH choose_tile_f16(int M, int cout_pad) {
 void conv_tile_for_f16(int M, int cout_pad, int cin, int* bm, int* bn) {
     (void)cin;
     const TileChoiceH t = choose_tile_f16(M, cout_pad);
-    static const int force_tile = [] { const char* e = getenv("OM_CONV16_TILE"); return e ? atoi(e) : 0; }();   // e.g. 128128
     *bm = t.bm; *bn = t.bn;
-    if (force_tile > 0 && cout_pad % (force_tile % 1000) == 0) { *bm = force_tile / 1000; *bn = force_tile % 1000; }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -255,8 +253,6 @@ static int launch_tile_f16(IgemmHParams p, int cout_pad, int blocks_per_cu, hipS
     OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "conv f16: %lld tiles out of range", total);
     p.total_tiles = (int)total;
     long long grid = total;
-    static const int bpc_override = [] { const char* e = getenv("OM_CONV16_BPC"); return e ? atoi(e) : 0; }();
-    if (bpc_override > 0) blocks_per_cu = bpc_override;
     grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
     hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());

@@ -124,8 +124,10 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
     for (;;) {
         int tile;
         if (p.ticket) {
+            // raw barrier: only lane 0's wave pays the ticket's round trip, nobody drains the previous tile's stores
             if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             tile = *s_ticket;
         } else {
             tile = blockIdx.x;
@@ -311,7 +313,8 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
                 else
                     for (int k = 0; k < 4 && k < nvalid; ++k) o[k] = v[k];
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS reads done; the stores keep flying
+            __builtin_amdgcn_s_barrier();
         }
         if (!p.ticket) break;
     }
@@ -355,8 +358,10 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoParams p) 
     for (;;) {
         int tile;
         if (p.ticket) {
+            // raw barrier: only lane 0's wave pays the ticket's round trip, nobody drains the previous tile's stores
             if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             tile = *s_ticket;
         } else {
             tile = blockIdx.x;
@@ -587,7 +592,8 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoParams p) 
                 else
                     for (int k = 0; k < 4 && k < nvalid; ++k) o[k] = v[k];
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS reads done; the stores keep flying
+            __builtin_amdgcn_s_barrier();
         }
         if (!p.ticket) break;
     }
@@ -600,18 +606,12 @@ size_t wino_scratch_floats(int B, int H, int W, int C) {
 
 // The fused loader wins where the transform kernel's HBM round trip is large next to the GEMM (cin <= 64:
 // conv2.1, conv3.x); for wider layers the separate transform + pure-DMA GEMM is faster (measured: 136^2 128->256
-// 1.88 vs 1.79 ms, 34^2 256->512 0.575 vs 0.522 ms).  OM_WINO_FUSED=0/1 forces one variant everywhere.
-static bool wino_fused(int cin) {
-    static const int v = [] { const char* e = getenv("OM_WINO_FUSED"); return e ? atoi(e) : -1; }();
-    return v < 0 ? cin <= 64 : v != 0;
-}
+// 1.88 vs 1.79 ms, 34^2 256->512 0.575 vs 0.522 ms).
+static bool wino_fused(int cin) { return cin <= 64; }
 
 bool wino_fused_for(int cin) { return wino_fused(cin); }
 
-bool wino_enabled() {
-    static const int v = [] { const char* e = getenv("OM_WINOGRAD"); return e ? atoi(e) : 1; }();
-    return v != 0;
-}
+bool wino_enabled() { return true; }
 
 template <int BM, int BN, int WM, int WN>
 static int launch_wino_tile(WinoParams p, int blocks_per_cu, hipStream_t stream) {
@@ -681,8 +681,7 @@ int launch_conv_winograd(const ConvArgs& a, float* scratch, hipStream_t stream) 
     }
     // 64x128 tiles (2 workgroups/CU) win only when there are many of them; with fewer than ~3000 the 64x64 tiles
     // (3 workgroups/CU, finer load balance) are 5-11 % faster (measured at 68^2, 34^2 and 17^2).
-    static const int force64 = [] { const char* e = getenv("OM_WINO_BN64"); return e ? atoi(e) : -1; }();
-    const bool bn64 = force64 >= 0 ? force64 != 0 : wino_bn(p.T, a.cout_pad) == 64;
+    const bool bn64 = wino_bn(p.T, a.cout_pad) == 64;
     if (a.cout_pad % 128 == 0 && !bn64) return launch_wino_tile<64, 128, 32, 64>(p, 2, stream);
     return launch_wino_tile<64, 64, 32, 32>(p, 3, stream);
 }

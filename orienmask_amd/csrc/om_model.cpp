@@ -14,6 +14,7 @@
 //   * the three box heads are written NHWC with a 256-float pixel stride (what the decode kernel
 //     wants), the orientation head NCHW (what the mask kernel wants);
 //   * no allocation, no synchronisation: ~90 launches on the caller's stream.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -95,13 +96,9 @@ struct om_model {
         L.info.wino_alt_off = -1;
         L.info.wino_planes = 0;
         if (ks == 3 && stride == 1 && !stem && L.info.cout_pad % 64 == 0 && cin % 32 == 0) {
-            // F(2x4,3x3) (24 planes) for the layers that run the unfused transform + GEMM pair; the fused-loader layers
-            // (cin <= 64) stay on F(2x2,3x3) (16 planes).  OM_WINO_F24=0 at model creation selects F(2x2) everywhere.
-            static const int f24 = [] { const char* e = getenv("OM_WINO_F24"); return e ? atoi(e) : 1; }();
-            // Not at 1/32 scale either (17 x 17 at 544: 18 % of a 2 x 4 tiling is padding and the GEMM has too few tiles:
+            // F(2x4,3x3) (24 planes), except at 1/32 scale (17 x 17 at 544: 18 % of a 2 x 4 tiling is padding and the GEMM has too few tiles:
             // measured 0.465 vs 0.436 ms per conv6 layer).
-            static const int f24_fused = [] { const char* e = getenv("OM_WINO_F24_ALL"); return e ? atoi(e) : 1; }();
-            L.info.wino_planes = (f24 && (f24_fused || !om::wino_fused_for(cin)) && in_div < 32) ? 24 : 16;
+            L.info.wino_planes = in_div < 32 ? 24 : 16;
             weight_floats = om::align_up(weight_floats, 4);
             L.info.wino_off = (int64_t)weight_floats;
             weight_floats += (size_t)L.info.wino_planes * L.info.cout_pad * cin;
@@ -215,28 +212,83 @@ struct om_model {
     }
 
     // F(2x4,3x3) needs enough tiles to fill the chip: measured at 544^2, bs=4 is 4 % faster with F(2x2) and bs=8 is 4 % faster
-    // with F(2x4); the switch is on the number of 1/32-scale cells in the batch (289 per 544^2 image).  OM_WINO_F24_MIN_CELLS
-    // overrides the threshold.
+    // with F(2x4); the switch is on the number of 1/32-scale cells in the batch (289 per 544^2 image).
     static bool use_f24(int B, int H, int W) {
-        static const long long min_cells = [] { const char* e = getenv("OM_WINO_F24_MIN_CELLS"); return e ? atoll(e) : 1700ll; }();
-        return (long long)B * (H / 32) * (W / 32) >= min_cells;
-    }
-
-    // largest transformed-input scratch any Winograd layer needs at this problem size
-    size_t wino_floats(int B, int H, int W) const {
-        size_t mx = 0;
-        for (const om::LayerDef& L : layers)
-            if (L.info.wino_off >= 0) {
-                const size_t f = (L.info.wino_planes == 24 && use_f24(B, H, W))
-                                     ? om::wino24_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin)
-                                     : om::wino_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin);
-                if (f > mx) mx = f;
-            }
-        return mx;
+        return (long long)B * (H / 32) * (W / 32) >= 1700ll;
     }
 
     size_t buf_floats(int i, int B, int H, int W) const {
         return (size_t)B * (H / bufs[i].div) * (W / bufs[i].div) * bufs[i].C;
+    }
+
+    // ---- workspace layout: activations and the per-layer Winograd scratch share memory by LIVE RANGE.
+    // A buffer lives from the first layer that writes it to the last layer that reads (or writes) it; a layer's transformed-input
+    // scratch lives for that layer only.  Items are placed first-fit by address among the items whose ranges overlap theirs, so
+    // the forward needs the peak of the live set instead of the sum of all ~95 tensors (544x544, B=32: 12.7 GiB -> see
+    // DESIGN.md).  keep_all (om_model_keep_activations) gives every tensor its own slab again so that om_layer_output_view
+    // can be read after the forward.
+    struct Layout {
+        std::vector<size_t> buf_off;        // per activation buffer
+        std::vector<size_t> scratch_off;    // per layer (Winograd layers only)
+        size_t tickets_off = 0, total = 0;
+    };
+    bool keep_all = false;
+
+    size_t layer_scratch_floats(const om::LayerDef& L, int B, int H, int W) const {
+        if (L.info.wino_off < 0) return 0;
+        return (L.info.wino_planes == 24 && use_f24(B, H, W)) ? om::wino24_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin)
+                                                               : om::wino_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin);
+    }
+
+    Layout layout(int B, int H, int W, bool f16) const {
+        const size_t esz = f16 ? 2 : 4;
+        const int nb = (int)bufs.size(), nl = (int)layers.size();
+        struct Item { size_t bytes; int first, last; size_t off; };
+        std::vector<Item> items(nb + nl);
+        for (int i = 0; i < nb; ++i) items[i] = {om::align_up(buf_floats(i, B, H, W) * esz, 256), nl, -1, 0};
+        for (int l = 0; l < nl; ++l) {
+            const om::LayerDef& L = layers[l];
+            auto touch = [&](int buf) {
+                if (buf < 0) return;
+                if (l < items[buf].first) items[buf].first = l;
+                if (l > items[buf].last) items[buf].last = l;
+            };
+            touch(L.in.buf); touch(L.out.buf);
+            if (L.has_res) touch(L.res.buf);
+            items[nb + l] = {f16 ? 0 : om::align_up(layer_scratch_floats(L, B, H, W) * sizeof(float), 256), l, l, 0};
+        }
+        if (keep_all)
+            for (int i = 0; i < nb; ++i) { items[i].first = 0; items[i].last = nl; }
+        // place in order of first use; candidates are the gaps between the already placed items that are live at the same time
+        std::vector<int> order;
+        for (int i = 0; i < nb + nl; ++i)
+            if (items[i].bytes && items[i].last >= items[i].first) order.push_back(i);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return items[a].first < items[b].first; });
+        std::vector<int> placed;
+        size_t peak = 0;
+        for (int id : order) {
+            Item& it = items[id];
+            std::vector<std::pair<size_t, size_t>> busy;      // [off, end) of the items whose live range overlaps
+            for (int o : placed)
+                if (items[o].last >= it.first && items[o].first <= it.last) busy.push_back({items[o].off, items[o].off + items[o].bytes});
+            std::sort(busy.begin(), busy.end());
+            size_t at = 0;
+            for (auto& b : busy) {
+                if (at + it.bytes <= b.first) break;
+                if (b.second > at) at = b.second;
+            }
+            it.off = at;
+            if (at + it.bytes > peak) peak = at + it.bytes;
+            placed.push_back(id);
+        }
+        Layout out;
+        out.buf_off.resize(nb);
+        out.scratch_off.resize(nl);
+        for (int i = 0; i < nb; ++i) out.buf_off[i] = items[i].off;
+        for (int l = 0; l < nl; ++l) out.scratch_off[l] = items[nb + l].off;
+        out.tickets_off = peak;
+        out.total = peak + om::align_up((size_t)nl * sizeof(int), 256);      // one tile-queue ticket per layer
+        return out;
     }
 };
 
@@ -293,12 +345,7 @@ int om_model_load_weights(om_model* m, const void* packed_dev, size_t bytes, int
 
 static size_t forward_workspace_bytes(const om_model* m, int B, int H, int W, bool f16) {
     if (!m || B <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32) return 0;
-    const size_t esz = f16 ? 2 : 4;
-    size_t total = 0;
-    for (size_t i = 0; i < m->bufs.size(); ++i) total += om::align_up(m->buf_floats((int)i, B, H, W) * esz, 256);
-    total += om::align_up(m->layers.size() * sizeof(int), 256);      // one tile-queue ticket per layer
-    if (!f16) total += om::align_up(m->wino_floats(B, H, W) * sizeof(float), 256);   // Winograd transformed-input scratch
-    return total;
+    return m->layout(B, H, W, f16).total;
 }
 
 size_t om_forward_workspace_bytes(const om_model* m, int B, int H, int W) { return forward_workspace_bytes(m, B, H, W, false); }
@@ -317,19 +364,10 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const size_t esz = f16 ? 2 : 4;
 
+    const om_model::Layout lay = m->layout(B, H, W, f16);
     std::vector<char*> base(m->bufs.size());
-    int* tickets = nullptr;
-    float* wino_scratch = nullptr;
-    {
-        char* p = static_cast<char*>(workspace);
-        for (size_t i = 0; i < m->bufs.size(); ++i) {
-            base[i] = p;
-            p += om::align_up(m->buf_floats((int)i, B, H, W) * esz, 256);
-        }
-        tickets = reinterpret_cast<int*>(p);
-        p += om::align_up(m->layers.size() * sizeof(int), 256);
-        wino_scratch = reinterpret_cast<float*>(p);
-    }
+    for (size_t i = 0; i < m->bufs.size(); ++i) base[i] = static_cast<char*>(workspace) + lay.buf_off[i];
+    int* tickets = reinterpret_cast<int*>(static_cast<char*>(workspace) + lay.tickets_off);
     if (int rc = om::launch_zero_words(tickets, m->layers.size(), stream)) return rc;
     // element pointer of a view: workspace buffers hold esz-byte elements, the four outputs are always fp32
     auto ptr_of = [&](const om::View& v) -> void* {
@@ -403,6 +441,7 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             a.out_mode = L.out_mode; a.up = L.up;
             a.ticket = tickets + (&L - m->layers.data());
             if (li.wino_off >= 0 && om::wino_enabled()) {
+                float* wino_scratch = reinterpret_cast<float*>(static_cast<char*>(workspace) + lay.scratch_off[&L - m->layers.data()]);
                 a.mid_event = ev_mid;
                 if (li.wino_planes == 24 && om_model::use_f24(B, H, W)) {
                     a.w = m->weights + li.wino_off;
@@ -475,13 +514,19 @@ int om_layer_output_view(const om_model* m, int index, int B, int H, int W, int 
     OM_REQUIRE(B > 0 && H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, OM_EINVAL, "om_layer_output_view: bad shape");
     const om::LayerDef& L = m->layers[index];
     OM_REQUIRE(L.out.buf >= 0, OM_EINVAL, "om_layer_output_view: layer %s writes a caller-owned head tensor", L.info.name);
+    OM_REQUIRE(m->keep_all, OM_ESTATE, "om_layer_output_view: call om_model_keep_activations(m, 1) before the forward (activations "
+               "share memory by live range otherwise)");
     const size_t esz = f16 ? 2 : 4;
-    size_t off = 0;
-    for (int i = 0; i < L.out.buf; ++i) off += om::align_up(m->buf_floats(i, B, H, W) * esz, 256);
-    *byte_offset = off + (size_t)L.out.ch_off * esz;
+    *byte_offset = m->layout(B, H, W, f16 != 0).buf_off[L.out.buf] + (size_t)L.out.ch_off * esz;
     *channels = L.info.cout;
     *pix_stride = m->bufs[L.out.buf].C;
     *div = m->bufs[L.out.buf].div;      // an up-sampling layer's output is stored replicated at the buffer's resolution
+    return OM_OK;
+}
+
+int om_model_keep_activations(om_model* m, int keep) {
+    OM_REQUIRE(m, OM_EINVAL, "om_model_keep_activations: null model");
+    m->keep_all = keep != 0;
     return OM_OK;
 }
 

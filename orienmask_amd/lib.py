@@ -66,6 +66,7 @@ SIGNATURES = {
     "om_conv2d_winograd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "om_layer_output_view": (_i, [_vp, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int),
                                   ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "om_model_keep_activations": (_i, [_vp, _i]),
     "om_conv2d_winograd24_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "om_conv2d_winograd24": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "om_profile_enable": (_i, [_vp, _i]),

@@ -256,9 +256,17 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         """Record one HIP event pair per layer on the launch stream during forward()."""
         _lib.check(_lib.load().om_profile_enable(self._ensure_handle(), 1 if enable else 0), "om_profile_enable")
 
+    def keep_activations(self, keep=True):
+        """Give every activation its own workspace slab (no reuse by live range) so that layer_output() can be read after a
+        forward.  Drops the cached workspaces: the next forward sizes a new one."""
+        _lib.check(_lib.load().om_model_keep_activations(self._ensure_handle(), 1 if keep else 0), "om_model_keep_activations")
+        self._workspace.clear()
+        return self
+
     def layer_output(self, name, x_shape):
         """NCHW-shaped strided view [B, C, H/div, W/div] of layer `name`'s activation inside the workspace of the last
-        forward() on an input of shape x_shape (one launch, n_streams == 1).  For tests and debugging."""
+        forward() on an input of shape x_shape (one launch, n_streams == 1); needs keep_activations(True) before that
+        forward.  For tests and debugging."""
         h = self._ensure_handle()
         idx = [l["name"] for l in self._layers].index(name)
         B, _, H, W = x_shape

@@ -978,6 +978,9 @@ def test_backbone_features_bs8_match_oracle(dev):
     sd = synth.synth_state_dict(8, obj_bias=-16.0, head_gain=4.0)
     x = synth.synth_image_batch(25, 8, 544, 544)
     net = _hip_model(sd, dev)
+    with pytest.raises(omlib.OrienMaskHipError):
+        net(torch.zeros(1, 3, 64, 64, device=dev)); net.layer_output("backbone.conv3.2.conv.1", (1, 3, 64, 64))
+    net.keep_activations(True)          # activations share memory by live range unless asked to stay
     with torch.no_grad():
         net(x.to(dev))
     torch.cuda.synchronize()
