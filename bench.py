@@ -111,17 +111,18 @@ def post_occupancy(B, post_cfg_):
         omlib.check(L.om_post_kernel_occupancy(i, ctypes.byref(t), ctypes.byref(v), ctypes.byref(l), ctypes.byref(nb)),
                     "om_post_kernel_occupancy")
         waves_per_wg = t.value // 64
-        alloc = (v.value + 7) // 8 * 8
-        by_regs = min(8, 512 // max(alloc, 1))
-        by_lds = (160 * 1024) // l.value if l.value else 99
+        alloc = (v.value + 7) // 8 * 8                                  # register allocation granule (MI355X_MICROARCH.md)
+        by_regs = min(8, 512 // max(alloc, 1))                          # waves per SIMD the register file allows
+        by_lds = ((160 * 1024) // l.value) * waves_per_wg / 4.0 if l.value else 99.0
+        limits = {"wave slots": 8.0, "registers": float(by_regs), "lds": by_lds}
         wg_per_cu = nb.value
         waves_per_simd = min(8.0, wg_per_cu * waves_per_wg / 4.0)
+        limited_by = min(limits, key=limits.get)
         resident_wgs = min(grids[i], wg_per_cu * 256)
         out[name] = dict(threads_per_workgroup=t.value, vgprs=v.value, lds_bytes_per_workgroup=l.value,
                          workgroups_per_cu=wg_per_cu, waves_per_simd=waves_per_simd, limit_waves_per_simd=8,
                          occupancy_frac=round(waves_per_simd / 8.0, 3),
-                         limited_by=("registers" if by_regs * 4 // waves_per_wg <= min(by_lds, 32 // waves_per_wg) else
-                                     "lds" if by_lds < 32 // waves_per_wg else "waves"),
+                         limited_by=limited_by,
                          grid_workgroups=grids[i],
                          chip_wave_slots_used_frac=round(resident_wgs * waves_per_wg / (256 * 32.0), 4))
     return out

@@ -595,18 +595,25 @@ __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
             vx[e] = fmaf(tx0, wy0, bx0 * wy1);
             vy[e] = fmaf(ty0, wy0, by0 * wy1);
         }
+        // P = (v * grid_anchor) / 2 + base (postprocess.py:142-143) depends on the ANCHOR only, not on the detection: once per
+        // pixel; the loop over the field's detections keeps only the two |P - c| < t tests
+        const float gax = dpar[first * 8 + 4], gay = dpar[first * 8 + 5];
+        float Px[MASK_PX], Py[MASK_PX];
+#pragma unroll
+        for (int e = 0; e < MASK_PX; ++e) {
+            const int x = g * MASK_PX + e;
+            const float base_x = ((float)x / (float)W) * nW;
+            Px[e] = (vx[e] * gax) / 2.0f + base_x;
+            Py[e] = (vy[e] * gay) / 2.0f + base_y;
+        }
         for (int k = first; k < count; ++k) {
             const float* dp = dpar + k * 8;
             if (__float_as_int(dp[6]) != field * 2) continue;              // uniform
-            const float cx = dp[0], cy = dp[1], tx = dp[2], ty = dp[3], gax = dp[4], gay = dp[5];
+            const float cx = dp[0], cy = dp[1], tx = dp[2], ty = dp[3];
             unsigned packed[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < MASK_PX; ++e) {
-                const int x = g * MASK_PX + e;
-                const float base_x = ((float)x / (float)W) * nW;
-                const float Px = (vx[e] * gax) / 2.0f + base_x;                  // postprocess.py:142-143
-                const float Pyy = (vy[e] * gay) / 2.0f + base_y;
-                const bool inside = (fabsf(Px - cx) < tx) && (fabsf(Pyy - cy) < ty);
+                const bool inside = (fabsf(Px[e] - cx) < tx) && (fabsf(Py[e] - cy) < ty);
                 packed[e >> 2] |= (inside ? 1u : 0u) << ((e & 3) * 8);
             }
             uint4 o;
