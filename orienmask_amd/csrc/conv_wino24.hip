@@ -92,8 +92,27 @@ struct Wino24Params {
     int H, W, cout, cout_pad;
     int n_tiles, total_tiles;
     int leaky, res_pix_stride, out_pix_stride, vec_io;
+    // stream-K form only
+    float* partial;       // [slots][32][256] f32x4: the eight raw accumulators a slot publishes for the tile it shares
+    int* flags;           // [slots], zeroed before the launch: slot s has published
+    int slots;
 };
 
+// SK = false: whole tiles from a dynamic ticket queue.
+// SK = true : STREAM-K.  The (tile, plane) units of the launch are dealt out EVENLY to the resident workgroups: with whole
+// tiles a launch runs ceil(tiles / 512) rounds although it has work for tiles / 512 of them -- the 34 x 34 layers (616 tiles)
+// kept their waves resident for 74 % of the kernel's duration, the 68 x 68 layers for 85 % (rocprofv3 PMC,
+// profiles/r02_experiments.md).  Slot s owns units [s U / S, (s + 1) U / S), U = 24 tiles: whole tiles in the middle, possibly
+// the HEAD planes of one tile at the end of its range and the TAIL planes of another at its start.  A slot
+//   1. computes its head part FIRST and publishes the eight raw output accumulators (128 KiB: write-through stores, every
+//      wave drains, one lane raises a flag -- Guideline 16 R1 of cdna_hip_programming.md),
+//   2. runs its whole tiles,
+//   3. finishes the tile whose head the PREVIOUS slot published long ago: it STARTS from those accumulators and continues
+//      with the remaining planes, so every output is the same sequence of fp32 operations as in an unsplit tile -- results do
+//      not depend on where a tile was cut (bit-identical to SK = false, batch-size invariant).
+// Slot numbers are drawn from the ticket word in start order, so a finisher never waits for a workgroup that has not started
+// (placement- and dispatch-order independent).  Needs tiles >= slots (a tile is cut at most once).
+template <bool SK>
 __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params p) {
     constexpr int BM = 64, BN = 64, WM = 32, WN = 32;
     constexpr int NWN = BN / WN;
@@ -112,29 +131,59 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
     const int scol = lcol ^ ((lrow >> 1) & 7);
     const int fi = lane & 31, fk = lane >> 5;
     const int fsw = (fi >> 1) & 7;
-    const int ksteps = 24 * p.kc;
     const size_t v_plane = (size_t)p.T * p.C, u_plane = (size_t)p.cout_pad * p.C;
 
-    for (;;) {
-        // the ticket's round trip is paid by lane 0's wave only: the others wait at a raw barrier, which (unlike __syncthreads)
-        // does not make them drain the previous tile's output stores first.  (Drawing the NEXT ticket at the start of a tile
-        // hides the round trip too, but pins the last partial round of tiles to the workgroups that started first: the
-        // 34 x 34 layers went from 0.33 to 0.44 ms.)
+    // ---- stream-K: my slot and its unit range
+    int slot = 0, t_lead = 0, x_lead = 0, t_trail = 0, x_trail = 0, t_full0 = 0, n_full = 0, nseg = 0;
+    if constexpr (SK) {
         if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int tile = *s_ticket;
-        if (tile >= p.total_tiles) break;
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        const int tile_n = tile % p.n_tiles;
-        const int tile_m = tile / p.n_tiles;
+        __syncthreads();
+        slot = __builtin_amdgcn_readfirstlane(*s_ticket);
+        const long long U = (long long)p.total_tiles * 24;
+        const long long u0 = U * slot / p.slots, u1 = U * (slot + 1) / p.slots;
+        t_lead = (int)(u0 / 24); x_lead = (int)(u0 - (long long)t_lead * 24);      // finish tile t_lead from plane x_lead on
+        t_trail = (int)(u1 / 24); x_trail = (int)(u1 - (long long)t_trail * 24);   // head planes [0, x_trail) of tile t_trail
+        t_full0 = t_lead + (x_lead != 0);
+        n_full = t_trail - t_full0;
+        nseg = (x_trail != 0) + n_full + (x_lead != 0);
+    }
+
+    for (int seg = 0;; ++seg) {
+        int tile, xb = 0, xe = 24, mode = 0;     // mode 1: produce the head planes of a tile, 2: finish from the partner's
+        if constexpr (SK) {
+            // order: head part (published early) -> whole tiles -> tail part (its partner published long ago)
+            if (seg >= nseg) break;
+            const int has_trail = x_trail != 0;
+            if (has_trail && seg == 0) { tile = t_trail; xe = x_trail; mode = 1; }
+            else if (seg - has_trail < n_full) { tile = t_full0 + seg - has_trail; }
+            else { tile = t_lead; xb = x_lead; mode = 2; }
+        } else {
+            // the ticket's round trip is paid by lane 0's wave only: the others wait at a raw barrier, which (unlike
+            // __syncthreads) does not make them drain the previous tile's output stores first.  (Drawing the NEXT ticket at the
+            // start of a tile hides the round trip too, but pins the last partial round of tiles to the workgroups that started
+            // first: the 34 x 34 layers went from 0.33 to 0.44 ms.)
+            if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            tile = *s_ticket;
+            if (tile >= p.total_tiles) break;
+            tile = __builtin_amdgcn_readfirstlane(tile);
+        }
+        const int ksteps = (xe - xb) * p.kc;
+        // ticket queue: N fastest (the n_tiles workgroups that draw consecutive tickets share a transformed-input panel while it
+        // is hot).  Stream-K region: M fastest -- a slot walks consecutive M tiles of one N tile, and the slots working on the
+        // other N tiles of the same panels run at the same time, slots / n_tiles further on (N fastest there re-read every panel
+        // n_tiles times a whole tile-time apart: +4 % on the whole set of layers).
+        const int m_tiles = p.total_tiles / p.n_tiles;
+        const int tile_n = SK ? tile / m_tiles : tile % p.n_tiles;
+        const int tile_m = SK ? tile - tile_n * m_tiles : tile / p.n_tiles;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
         const int rows_valid = min(BM, p.T - m0);
 
         const int voff0 = (lrow * p.C + scol * 4) * 4;
         const int voff_rows32 = 32 * p.C * 4;
 
-        int n_xi = 0, n_cc = 0;     // (transform index, channel chunk) of the step being fetched
+        int n_xi = xb, n_cc = 0;     // (transform index, channel chunk) of the step being fetched
         auto advance = [&]() {
             if (++n_cc == p.kc) { n_cc = 0; ++n_xi; }
         };
@@ -164,6 +213,29 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
 #pragma unroll
             for (int e = 0; e < 8; ++e) outa[e >> 2][e & 3][r] = 0.f;
         }
+        if constexpr (SK) {
+            if (mode == 2) {
+                // the partner (slot - 1) published this tile's head planes as its first action
+                if (tid == 0) {
+                    // bounded (a few seconds): the partner started before this workgroup and publishes within one tile's time
+                    for (int spins = 0; spins < (1 << 22) &&
+                                        __hip_atomic_load(p.flags + slot - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spins)
+                        __builtin_amdgcn_s_sleep(16);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                const auto rs_part = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, 0x7FFFFFFF, 0x00020000);
+                const int pbase = ((slot - 1) * 32 * 256 + tid) * 16;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_part, pbase, (e * 4 + g) * 256 * 16, 16));
+                        outa[e >> 2][e & 3][4 * g] = v[0]; outa[e >> 2][e & 3][4 * g + 1] = v[1];
+                        outa[e >> 2][e & 3][4 * g + 2] = v[2]; outa[e >> 2][e & 3][4 * g + 3] = v[3];
+                    }
+            }
+        }
 
         const f32x4* fragA = smem + (wm * WM + fi) * 8;
         const f32x4* fragB = smem + BM * 8 + (wn * WN + fi) * 8;
@@ -184,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NP) : "memory");   // step 0 landed, step 1 may still fly
         __builtin_amdgcn_s_barrier();
         read_frags(ca, cb, 0, 0);
-        int xi = 0, cc = 0;
+        int xi = xb, cc = 0;
         int buf = 0;
         for (int s = 0; s < ksteps; ++s) {
             const int buf1 = buf == NBUF - 1 ? 0 : buf + 1;      // step s+1
@@ -194,12 +266,12 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int slot = q * 4 + t;
+                    const int sl = q * 4 + t;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cb[t], ca[t], acc, 0, 0, 0);
                     if (t == 1 && q < 3) read_frags(na, nb, buf, q + 1);
-                    if (slot < NP) issue_piece(slot, buf2, live2);
-                    if (slot == 12) read_frags(na, nb, buf1, 0);
-                    if (slot == 11) {
+                    if (sl < NP) issue_piece(sl, buf2, live2);
+                    if (sl == 12) read_frags(na, nb, buf1, 0);
+                    if (sl == 11) {
                         // everything older than this step's NP pieces has landed = the operands of step s+1;
                         // all my reads of the current buffer are done (lgkmcnt) -> raw barrier, no compiler fence
                         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NP) : "memory");
@@ -239,6 +311,27 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
+        if constexpr (SK) {
+            if (mode == 1) {
+                // publish the raw accumulators: write-through (sc1) 16-byte stores, every wave drains, one lane raises the flag
+                const auto rs_part = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, 0x7FFFFFFF, 0x00020000);
+                const int pbase = (slot * 32 * 256 + tid) * 16;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x16& o = outa[e >> 2][e & 3];
+                        const f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                                               rs_part, pbase, (e * 4 + g) * 256 * 16, 16);
+                    }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(p.flags + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            }
+        }
+
         // ---- epilogue: row geometry once per tile; per pass of two output positions the residual loads are issued BEFORE the
         // LDS staging (they fly during it), C tiles [position][row][channel chunk ^ (row & 7)] go through LDS and leave as 16-byte
         // rows; the barriers wait for LDS only (a __syncthreads() would also drain the stores: ~2 us of HBM write latency per
@@ -267,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
                 ok |= ((mok && 2 * ty + (q >> 2) < p.H && 4 * tx + (q & 3) < p.W) ? 1u : 0u) << q;
             okb[ps] = ok;
         }
-        constexpr int PPP = 2;
+        constexpr int PPP = SK ? 1 : 2;       // output positions per pass (the stream-K form has fewer registers to spare)
 #pragma unroll
         for (int pass = 0; pass < (8 + PPP - 1) / PPP; ++pass) {
             f32x4 rres[PPP][BM / RP];
@@ -365,7 +458,15 @@ int launch_conv_winograd24(const ConvArgs& a, float* scratch, hipStream_t stream
     OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "winograd24: %lld tiles out of range", total);
     p.total_tiles = (int)total;
     const long long grid = total < 512 ? total : 512;        // 2 workgroups per CU (register-bound)
-    hipLaunchKernelGGL(wino24_gemm_kernel, dim3((unsigned)grid), dim3(256), 0, stream, p);
+    p.partial = a.sk_partial; p.flags = a.ticket + SK_FLAG_OFF; p.slots = (int)grid;
+    // Stream-K only where the last partial round hurts most (fewer than two tiles per slot: the 34 x 34 layers, 616 tiles,
+    // -9 %).  A static split is only as fast as the slowest workgroup -- dealt out statically, whole layers ran 2-4 % slower
+    // than from the queue -- so from two tiles per slot on the two effects cancel (68 x 68: +-0, 136 x 136: +1-2 %), and a
+    // hybrid (bulk from the queue, only the last round cut evenly) lost to both (profiles/r02_experiments.md).
+    if (a.sk_partial && total >= SK_SLOTS && total < 2 * SK_SLOTS)
+        hipLaunchKernelGGL(wino24_gemm_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(wino24_gemm_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }

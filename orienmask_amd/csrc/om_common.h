@@ -40,7 +40,9 @@ struct ConvArgs {
     const float* shift;     // [cout_pad]
     const float* res;       // optional NHWC view [B,Ho,Wo,cout], added after the activation
     float* out;
-    int* ticket = nullptr;  // device int zeroed before the launch (dynamic tile queue); nullptr = static grid
+    int* ticket = nullptr;  // SYNC_WORDS device ints zeroed before the launch: [0] the tile / slot queue, [SK_FLAG_OFF + s] the
+                            // "slot s has published" flags of the stream-K Winograd GEMM; nullptr = static grid
+    float* sk_partial = nullptr;      // SK_PARTIAL_BYTES of device memory for stream-K partial tiles (nullptr: whole tiles only)
     hipEvent_t mid_event = nullptr;   // profiling: recorded between the two kernels of a Winograd layer
     int B, H, W, cin, in_pix_stride;
     int Ho, Wo, cout, cout_pad;
@@ -52,6 +54,11 @@ struct ConvArgs {
                             // 2: NCHW contiguous [B,cout,Ho,Wo]
     int up;
 };
+
+constexpr int SK_SLOTS = 512;                           // resident workgroups of the stream-K GEMM (2 per CU)
+constexpr int SK_FLAG_OFF = 16;
+constexpr int SYNC_WORDS = SK_FLAG_OFF + SK_SLOTS;      // ints per launch
+constexpr size_t SK_PARTIAL_BYTES = (size_t)SK_SLOTS * 32 * 256 * 16;   // 8 accumulators x 16 floats x 256 threads per slot (64 MiB)
 
 int launch_conv_igemm(const ConvArgs& a, hipStream_t stream);
 

@@ -230,7 +230,7 @@ struct om_model {
     struct Layout {
         std::vector<size_t> buf_off;        // per activation buffer
         std::vector<size_t> scratch_off;    // per layer (Winograd layers only)
-        size_t tickets_off = 0, total = 0;
+        size_t tickets_off = 0, partial_off = 0, total = 0;
     };
     bool keep_all = false;
 
@@ -286,8 +286,9 @@ struct om_model {
         out.scratch_off.resize(nl);
         for (int i = 0; i < nb; ++i) out.buf_off[i] = items[i].off;
         for (int l = 0; l < nl; ++l) out.scratch_off[l] = items[nb + l].off;
-        out.tickets_off = peak;
-        out.total = peak + om::align_up((size_t)nl * sizeof(int), 256);      // one tile-queue ticket per layer
+        out.tickets_off = peak;                 // queue word + stream-K flags per layer (zeroed by every forward)
+        out.partial_off = peak + om::align_up((size_t)nl * om::SYNC_WORDS * sizeof(int), 256);
+        out.total = out.partial_off + (f16 ? 0 : om::SK_PARTIAL_BYTES);
         return out;
     }
 };
@@ -368,7 +369,8 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
     std::vector<char*> base(m->bufs.size());
     for (size_t i = 0; i < m->bufs.size(); ++i) base[i] = static_cast<char*>(workspace) + lay.buf_off[i];
     int* tickets = reinterpret_cast<int*>(static_cast<char*>(workspace) + lay.tickets_off);
-    if (int rc = om::launch_zero_words(tickets, m->layers.size(), stream)) return rc;
+    float* sk_partial = f16 ? nullptr : reinterpret_cast<float*>(static_cast<char*>(workspace) + lay.partial_off);
+    if (int rc = om::launch_zero_words(tickets, m->layers.size() * om::SYNC_WORDS, stream)) return rc;
     // element pointer of a view: workspace buffers hold esz-byte elements, the four outputs are always fp32
     auto ptr_of = [&](const om::View& v) -> void* {
         switch (v.buf) {
@@ -425,7 +427,7 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             a.out_pix_stride = m->pix_stride(L.out.buf);
             a.out_mode = L.out_mode; a.up = L.up;
             a.out_f32 = L.out.buf < 0 ? 1 : 0;
-            a.ticket = tickets + (&L - m->layers.data());
+            a.ticket = tickets + (&L - m->layers.data()) * om::SYNC_WORDS;
             if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
             rc = om::launch_conv_igemm_f16(a, stream);
         } else {
@@ -439,7 +441,8 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             a.res_pix_stride = L.has_res ? m->pix_stride(L.res.buf) : 0;
             a.out_pix_stride = m->pix_stride(L.out.buf);
             a.out_mode = L.out_mode; a.up = L.up;
-            a.ticket = tickets + (&L - m->layers.data());
+            a.ticket = tickets + (&L - m->layers.data()) * om::SYNC_WORDS;
+            a.sk_partial = sk_partial;
             if (li.wino_off >= 0 && om::wino_enabled()) {
                 float* wino_scratch = reinterpret_cast<float*>(static_cast<char*>(workspace) + lay.scratch_off[&L - m->layers.data()]);
                 a.mid_event = ev_mid;
@@ -613,8 +616,8 @@ int om_conv2d(const float* in, int B, int H, int W, int cin, int in_pix_stride, 
     // unit-test entry only: a library-owned ticket word so that the persistent tile queue (what om_forward
     // uses, with tickets carved from the caller's workspace) is what gets tested and benchmarked
     static int* g_ticket = nullptr;
-    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), 256));
-    if (int rc = om::launch_zero_words(g_ticket, 1, static_cast<hipStream_t>(stream))) return rc;
+    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), om::SYNC_WORDS * sizeof(int)));
+    if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;
     a.ticket = g_ticket;
     return om::launch_conv_igemm(a, static_cast<hipStream_t>(stream));
 }
@@ -638,8 +641,8 @@ int om_conv2d_winograd(const float* in, int B, int H, int W, int cin, int in_pix
     a.ks = 3; a.stride = 1; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
     a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1;
     static int* g_ticket = nullptr;
-    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), 256));
-    if (int rc = om::launch_zero_words(g_ticket, 1, static_cast<hipStream_t>(stream))) return rc;
+    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), om::SYNC_WORDS * sizeof(int)));
+    if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;
     a.ticket = g_ticket;
     return om::launch_conv_winograd(a, static_cast<float*>(scratch), static_cast<hipStream_t>(stream));
 }
@@ -656,8 +659,8 @@ int om_conv2d_f16(const void* in, int B, int H, int W, int cin, int in_pix_strid
     a.ks = ksize; a.stride = stride; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
     a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1; a.out_f32 = out_f32;
     static int* g_ticket = nullptr;
-    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), 256));
-    if (int rc = om::launch_zero_words(g_ticket, 1, static_cast<hipStream_t>(stream))) return rc;
+    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), om::SYNC_WORDS * sizeof(int)));
+    if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;
     a.ticket = g_ticket;
     return om::launch_conv_igemm_f16(a, static_cast<hipStream_t>(stream));
 }
@@ -669,7 +672,7 @@ int om_conv2d_stem_f16(const float* in, int B, int H, int W, const float* w, con
 
 size_t om_conv2d_winograd24_scratch_bytes(int B, int H, int W, int cin) {
     if (B <= 0 || H <= 0 || W <= 0 || cin <= 0) return 0;
-    return om::align_up(om::wino24_scratch_floats(B, H, W, cin) * sizeof(float), 256);
+    return om::align_up(om::wino24_scratch_floats(B, H, W, cin) * sizeof(float), 256) + om::SK_PARTIAL_BYTES;
 }
 
 int om_conv2d_winograd24(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* u,
@@ -686,9 +689,10 @@ int om_conv2d_winograd24(const float* in, int B, int H, int W, int cin, int in_p
     a.ks = 3; a.stride = 1; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
     a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1;
     static int* g_ticket = nullptr;
-    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), 256));
-    if (int rc = om::launch_zero_words(g_ticket, 1, static_cast<hipStream_t>(stream))) return rc;
+    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), om::SYNC_WORDS * sizeof(int)));
+    if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;
     a.ticket = g_ticket;
+    a.sk_partial = reinterpret_cast<float*>(static_cast<char*>(scratch) + om::align_up(om::wino24_scratch_floats(B, H, W, cin) * sizeof(float), 256));
     return om::launch_conv_winograd24(a, static_cast<float*>(scratch), static_cast<hipStream_t>(stream));
 }
 
