@@ -53,7 +53,7 @@ def post_config(h, w):
 
 
 def cpu_baseline(sd, x_cpu, f16=False, budget_s=30.0):
-    """Oracle forward and postprocess on the host cores: thread sweep {8, 32, all} on one image, then with
+    """Oracle forward and postprocess on the host cores: thread sweep {8, 16, 32, 64} on one image, then with
     the best count: bs=1 forward / postprocess, and the bench batch itself (or as many images of it as the budget allows)."""
     from oracle import orienmask_ref as R
     fwd = R.forward_f16 if f16 else R.forward
@@ -65,7 +65,9 @@ def cpu_baseline(sd, x_cpu, f16=False, budget_s=30.0):
     t_start = time.perf_counter()
     one = x_cpu[:1]
     sweep = {}
-    for nt in sorted({min(8, ncpu), min(32, ncpu), ncpu}):
+    # {8, 16, 32, 64} and "all" only up to 64: on the 256-thread GPU host one 544x544 forward took 69.7 s with all threads
+    # (oversubscribed MKL-DNN), against 0.18-0.27 s with 8-32 -- measured once (profiles/r02_bench.json), not repeated every run
+    for nt in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu)}):
         torch.set_num_threads(nt)
         fwd(sd, one)                                                   # warm-up at this thread count
         t0 = time.perf_counter()
@@ -319,9 +321,16 @@ def main():
             meta = pmc.pop("_meta", {})
             norm = lambda k: k.replace(" ", "")
             def find(kname):
-                key = [k for k in pmc if norm(k).startswith(norm(kname).rstrip(">"))] or \
-                      [k for k in pmc if k.split("<")[0] == kname.split("<")[0]]   # a non-template kernel has no <BM,BN> in its symbol
-                return pmc[key[0]] if key else None
+                """PMC record of a kernel as bench.py names it; a kernel compiled in several variants (e.g. the whole-tile and
+                the stream-K form of one GEMM, <false> / <true> in the symbol) is the launch-weighted mean of its variants."""
+                keys = [k for k in pmc if norm(k).startswith(norm(kname).rstrip(">"))] or \
+                       [k for k in pmc if k.split("<")[0] == kname.split("<")[0]]
+                keys = [k for k in keys if "hbm_bytes_per_launch_corrected" in pmc[k]]
+                if not keys:
+                    return None
+                n = sum(pmc[k]["launches"] for k in keys)
+                return dict(launches=n, variants=keys,
+                            hbm_bytes_per_launch_corrected=sum(pmc[k]["hbm_bytes_per_launch_corrected"] * pmc[k]["launches"] for k in keys) / n)
             if meta.get("lib_sha256") != lib_sha256():
                 traffic_src = ("%s was measured with another build of liborienmask_hip.so (sha256 %s...): not reported; rerun "
                                "tools/pmc_traffic.sh" % (os.path.relpath(pmc_file, REPO), str(meta.get("lib_sha256"))[:12]))

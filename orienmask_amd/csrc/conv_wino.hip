@@ -94,9 +94,14 @@ struct WinoParams {
     int H, W, cout, cout_pad;
     int n_tiles, total_tiles;
     int leaky, res_pix_stride, out_pix_stride, vec_io;
+    // stream-K form only (see conv_wino24.hip)
+    float* partial;       // [slots][4 * BM * BN] floats: the four raw output accumulators a slot publishes
+    int* flags;           // [slots], zeroed before the launch
+    int slots;
 };
 
-template <int BM, int BN, int WM, int WN>
+// SK = true: the stream-K form of conv_wino24.hip with units = (tile, plane), 16 planes per tile (bit-identical results).
+template <int BM, int BN, int WM, int WN, bool SK>
 __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NWN = BN / WN;
@@ -118,24 +123,46 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
     const int scol = lcol ^ ((lrow >> 1) & 7);
     const int fi = lane & 31, fk = lane >> 5;
     const int fsw = (fi >> 1) & 7;
-    const int ksteps = 16 * p.kc;
     const size_t v_plane = (size_t)p.T * p.C, u_plane = (size_t)p.cout_pad * p.C;
 
-    for (;;) {
-        int tile;
-        if (p.ticket) {
+    int slot = 0, t_lead = 0, x_lead = 0, t_trail = 0, x_trail = 0, t_full0 = 0, n_full = 0, nseg = 0;
+    if constexpr (SK) {
+        if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+        __syncthreads();
+        slot = __builtin_amdgcn_readfirstlane(*s_ticket);
+        const long long U = (long long)p.total_tiles * 16;
+        const long long u0 = U * slot / p.slots, u1 = U * (slot + 1) / p.slots;
+        t_lead = (int)(u0 / 16); x_lead = (int)(u0 - (long long)t_lead * 16);
+        t_trail = (int)(u1 / 16); x_trail = (int)(u1 - (long long)t_trail * 16);
+        t_full0 = t_lead + (x_lead != 0);
+        n_full = t_trail - t_full0;
+        nseg = (x_trail != 0) + n_full + (x_lead != 0);
+    }
+
+    for (int seg = 0;; ++seg) {
+        int tile, xb = 0, xe = 16, mode = 0;      // mode 1: produce the head planes of a tile, 2: finish from the partner's
+        if constexpr (SK) {
+            if (seg >= nseg) break;
+            const int has_trail = x_trail != 0;
+            if (has_trail && seg == 0) { tile = t_trail; xe = x_trail; mode = 1; }
+            else if (seg - has_trail < n_full) { tile = t_full0 + seg - has_trail; }
+            else { tile = t_lead; xb = x_lead; mode = 2; }
+        } else if (p.ticket) {
             // raw barrier: only lane 0's wave pays the ticket's round trip, nobody drains the previous tile's stores
             if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             tile = *s_ticket;
+            if (tile >= p.total_tiles) break;
         } else {
             tile = blockIdx.x;
+            if (tile >= p.total_tiles) break;
         }
-        if (tile >= p.total_tiles) break;
         tile = __builtin_amdgcn_readfirstlane(tile);
-        const int tile_n = tile % p.n_tiles;
-        const int tile_m = tile / p.n_tiles;
+        const int ksteps = (xe - xb) * p.kc;
+        const int m_tiles = p.total_tiles / p.n_tiles;
+        const int tile_n = SK ? tile / m_tiles : tile % p.n_tiles;
+        const int tile_m = SK ? tile - tile_n * m_tiles : tile / p.n_tiles;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
         const int rows_valid = min(BM, p.T - m0);
 
@@ -144,7 +171,7 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
         const int voff0 = (lrow * p.C + scol * 4) * 4;
         const int voff_rows32 = 32 * p.C * 4;
 
-        int n_xi = 0, n_cc = 0;     // (transform index, channel chunk) of the step being fetched
+        int n_xi = xb, n_cc = 0;     // (transform index, channel chunk) of the step being fetched
         auto advance = [&]() {
             if (++n_cc == p.kc) { n_cc = 0; ++n_xi; }
         };
@@ -179,6 +206,32 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
                     outa[0][0][a][b][r] = 0.f; outa[0][1][a][b][r] = 0.f;
                     outa[1][0][a][b][r] = 0.f; outa[1][1][a][b][r] = 0.f;
                 }
+        if constexpr (SK) {
+            if (mode == 2) {
+                if (tid == 0) {
+                    for (int spins = 0; spins < (1 << 22) &&
+                                        __hip_atomic_load(p.flags + slot - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spins)
+                        __builtin_amdgcn_s_sleep(16);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                const auto rs_part = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, 0x7FFFFFFF, 0x00020000);
+                const int pbase = ((slot - 1) * (16 * TM * TN) * 256 + tid) * 16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                    rs_part, pbase, (((e * TM + a) * TN + b) * 4 + g) * 256 * 16, 16));
+                                f32x16& o = outa[e >> 1][e & 1][a][b];
+                                o[4 * g] = v[0]; o[4 * g + 1] = v[1]; o[4 * g + 2] = v[2]; o[4 * g + 3] = v[3];
+                            }
+            }
+        }
 
         const f32x4* fragA = smem + (wm * WM + fi) * 8;
         const f32x4* fragB = smem + BM * 8 + (wn * WN + fi) * 8;
@@ -201,7 +254,7 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NP) : "memory");   // step 0 landed, step 1 may still fly
         __builtin_amdgcn_s_barrier();
         read_frags(ca, cb, 0, 0);
-        int xi = 0, cc = 0;
+        int xi = xb, cc = 0;
         int buf = 0;
         for (int s = 0; s < ksteps; ++s) {
             const int buf1 = buf == NBUF - 1 ? 0 : buf + 1;      // step s+1
@@ -260,6 +313,31 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
+        if constexpr (SK) {
+            if (mode == 1) {
+                const auto rs_part = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, 0x7FFFFFFF, 0x00020000);
+                const int pbase = (slot * (16 * TM * TN) * 256 + tid) * 16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x16& o = outa[e >> 1][e & 1][a][b];
+                                const f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+                                __builtin_amdgcn_raw_buffer_store_b128(
+                                    __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), rs_part, pbase,
+                                    (((e * TM + a) * TN + b) * 4 + g) * 256 * 16, 16);
+                            }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(p.flags + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            }
+        }
+
         // ---- epilogue: four output positions, each through the LDS C tile
         f32x4* sC = smem;
         const int n4 = tid % CH, r0 = tid / CH;
@@ -316,7 +394,7 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS reads done; the stores keep flying
             __builtin_amdgcn_s_barrier();
         }
-        if (!p.ticket) break;
+        if (!SK && !p.ticket) break;
     }
 }
 
@@ -622,7 +700,17 @@ static int launch_wino_tile(WinoParams p, int blocks_per_cu, hipStream_t stream)
     p.total_tiles = (int)total;
     long long grid = total;
     if (p.ticket) grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
-    hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    // stream-K between one and two tiles per slot; with fewer tiles than resident workgroups (the 17 x 17 layers: 656 tiles for
+    // 768 slots, i.e. two or three per CU) on 512 slots, so that every CU gets the same 2 x 1.28 tiles' worth
+    long long sk_slots = grid;
+    if (p.partial && p.ticket && total < grid && total >= 512) sk_slots = 512;
+    if (p.partial && p.ticket && total >= sk_slots && total < 2 * sk_slots && sk_slots <= SK_SLOTS &&
+        (size_t)sk_slots * 4 * BM * BN * sizeof(float) <= SK_PARTIAL_BYTES) {
+        p.slots = (int)sk_slots;
+        hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN, true>), dim3((unsigned)sk_slots), dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    }
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }
@@ -671,6 +759,7 @@ int launch_conv_winograd(const ConvArgs& a, float* scratch, hipStream_t stream) 
     p.T = (int)T; p.TH = TH; p.TW = TW; p.C = a.cin; p.kc = a.cin / 32;
     p.H = a.H; p.W = a.W; p.cout = a.cout; p.cout_pad = a.cout_pad;
     p.n_tiles = 0; p.total_tiles = 0;
+    p.partial = a.sk_partial; p.flags = a.ticket ? a.ticket + SK_FLAG_OFF : nullptr; p.slots = 0;
     p.leaky = a.leaky; p.res_pix_stride = a.res_pix_stride; p.out_pix_stride = a.out_pix_stride;
     p.vec_io = (a.out_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
                 (!a.res || (a.res_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)))

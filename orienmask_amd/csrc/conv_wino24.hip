@@ -463,7 +463,7 @@ int launch_conv_winograd24(const ConvArgs& a, float* scratch, hipStream_t stream
     // -9 %).  A static split is only as fast as the slowest workgroup -- dealt out statically, whole layers ran 2-4 % slower
     // than from the queue -- so from two tiles per slot on the two effects cancel (68 x 68: +-0, 136 x 136: +1-2 %), and a
     // hybrid (bulk from the queue, only the last round cut evenly) lost to both (profiles/r02_experiments.md).
-    if (a.sk_partial && total >= SK_SLOTS && total < 2 * SK_SLOTS)
+    if (a.sk_partial && total >= 512 && total < 2 * 512)
         hipLaunchKernelGGL(wino24_gemm_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, p);
     else
         hipLaunchKernelGGL(wino24_gemm_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, p);

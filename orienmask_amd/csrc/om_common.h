@@ -55,10 +55,10 @@ struct ConvArgs {
     int up;
 };
 
-constexpr int SK_SLOTS = 512;                           // resident workgroups of the stream-K GEMM (2 per CU)
+constexpr int SK_SLOTS = 1024;                          // most resident workgroups of a stream-K launch (4 per CU)
 constexpr int SK_FLAG_OFF = 16;
 constexpr int SYNC_WORDS = SK_FLAG_OFF + SK_SLOTS;      // ints per launch
-constexpr size_t SK_PARTIAL_BYTES = (size_t)SK_SLOTS * 32 * 256 * 16;   // 8 accumulators x 16 floats x 256 threads per slot (64 MiB)
+constexpr size_t SK_PARTIAL_BYTES = (size_t)512 * 32 * 256 * 16;   // Winograd F(2x4): 512 slots x 8 accumulators x 16 floats x 256 threads (64 MiB)
 
 int launch_conv_igemm(const ConvArgs& a, hipStream_t stream);
 

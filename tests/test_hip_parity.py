@@ -199,6 +199,7 @@ WINO24_CASES = WINO_CASES + [
     (2, 9, 13, 128, 64, 1, False),       # width and height not multiples of the 2 x 4 tile
     (1, 3, 5, 64, 128, 0, True),
     (4, 34, 34, 256, 512, 1, True),
+    (8, 68, 68, 32, 512, 1, True),       # 584 tiles for 512 resident workgroups: the stream-K form (tiles cut between slots)
 ]
 
 
