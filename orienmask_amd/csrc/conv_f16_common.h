@@ -66,7 +66,10 @@ __device__ __forceinline__ void f16_epilogue(const IgemmHParams& p, f32x4* smem,
                     }
             }
         }
-        __syncthreads();
+        // LDS-only barriers in this loop: a __syncthreads() also waits for the previous pass's output stores (~2 us of HBM write
+        // latency per pass, per tile of a few microseconds of MFMA work)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         // phase 2
         if (p.out_mode != 2) {
 #pragma unroll 2
@@ -148,7 +151,8 @@ __device__ __forceinline__ void f16_epilogue(const IgemmHParams& p, f32x4* smem,
                 outf[((size_t)bi * p.cout + nn) * p.HoWo + rr] = t;
             }
         }
-        __syncthreads();      // the C rows are dead before the next pass / the next tile's operands land in LDS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the C rows are dead before the next pass / the next tile's
+        __builtin_amdgcn_s_barrier();                            // operands land in LDS; the stores keep flying
     }
 }
 

@@ -67,8 +67,10 @@ __global__ __launch_bounds__(256, (f16_blocks_per_cu<BM, BN>())) void conv_igemm
     const int fsw = (fi >> 2) & 3;
 
     for (;;) {
+        // raw barrier: only lane 0's wave pays the ticket's round trip, nobody drains the previous tile's stores
         if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         int tile = *s_ticket;
         if (tile >= p.total_tiles) break;
         tile = __builtin_amdgcn_readfirstlane(tile);
