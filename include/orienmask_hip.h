@@ -159,12 +159,21 @@ int om_profile_enable(om_model* m, int enable);
 int om_profile_enable_layers(om_model* m, const unsigned char* layer_mask, int n_layers);
 int om_profile_read(om_model* m, float* layer_ms, float* layer_pre_ms, int n_layers, int* n_forwards);
 
-/* ---- one convolution (unit-test entry) ----------------------------------------------------- */
+/* ---- one convolution (unit-test entries) ---------------------------------------------------
+ * These entries exist so that parity tests can check single layers; unlike the hot path they own a few device words (the
+ * tile-queue ticket, hipMalloc'ed on first use and never freed), which om_forward carves from the caller's workspace. */
 /* in: [B,H,W,cin] NHWC (pixel stride in_pix_stride floats); w/scale/shift as in om_layer_info;
  * res: optional [B,Ho,Wo,cout] NHWC added after the activation; out: [B,Ho,Wo,cout] NHWC. */
 int om_conv2d(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* w,
               const float* scale, const float* shift, int cout, int ksize, int stride, int leaky,
               const float* res, int res_pix_stride, float* out, int out_pix_stride, om_stream stream);
+/* The same with the output layouts om_forward uses: out_mode 0 = NHWC; 1 = NHWC with every output pixel replicated up x up
+ * (NearestUpsample fused into the producer, model/base.py:95-101: out is [B, Ho*up, Wo*up, ...]); 2 = NCHW contiguous
+ * [B, cout, Ho, Wo] (the orientation head). */
+int om_conv2d_mode(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* w,
+                   const float* scale, const float* shift, int cout, int ksize, int stride, int leaky,
+                   const float* res, int res_pix_stride, float* out, int out_pix_stride, int out_mode, int up,
+                   om_stream stream);
 /* The same layer through Winograd F(2x2,3x3) (3x3, stride 1): u = G g G^T as [16][cout_pad][cin];
  * scratch: om_conv2d_winograd_scratch_bytes(B,H,W,cin) bytes of device memory for the transformed input. */
 size_t om_conv2d_winograd_scratch_bytes(int B, int H, int W, int cin);

@@ -602,17 +602,19 @@ int om_profile_read(om_model* m, float* layer_ms, float* layer_pre_ms, int n_lay
     return OM_OK;
 }
 
-int om_conv2d(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* w, const float* scale,
-              const float* shift, int cout, int ksize, int stride, int leaky, const float* res, int res_pix_stride,
-              float* out, int out_pix_stride, om_stream stream) {
+int om_conv2d_mode(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* w, const float* scale,
+                   const float* shift, int cout, int ksize, int stride, int leaky, const float* res, int res_pix_stride,
+                   float* out, int out_pix_stride, int out_mode, int up, om_stream stream) {
     OM_REQUIRE(B > 0 && H > 0 && W > 0 && stride >= 1 && H % stride == 0 && W % stride == 0, OM_EINVAL,
                "om_conv2d: bad shape");
+    OM_REQUIRE(out_mode >= 0 && out_mode <= 2 && up >= 1 && (out_mode == 1 || up == 1), OM_EINVAL,
+               "om_conv2d_mode: out_mode=%d up=%d (0 NHWC, 1 NHWC replicated up x up, 2 NCHW)", out_mode, up);
     om::ConvArgs a;
     a.in = in; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.out = out;
     a.B = B; a.H = H; a.W = W; a.cin = cin; a.in_pix_stride = in_pix_stride;
     a.Ho = H / stride; a.Wo = W / stride; a.cout = cout; a.cout_pad = om::round_up(cout, 32);
     a.ks = ksize; a.stride = stride; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
-    a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1;
+    a.out_pix_stride = out_pix_stride; a.out_mode = out_mode; a.up = up;
     // unit-test entry only: a library-owned ticket word so that the persistent tile queue (what om_forward
     // uses, with tickets carved from the caller's workspace) is what gets tested and benchmarked
     static int* g_ticket = nullptr;
@@ -620,6 +622,13 @@ int om_conv2d(const float* in, int B, int H, int W, int cin, int in_pix_stride, 
     if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;
     a.ticket = g_ticket;
     return om::launch_conv_igemm(a, static_cast<hipStream_t>(stream));
+}
+
+int om_conv2d(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* w, const float* scale,
+              const float* shift, int cout, int ksize, int stride, int leaky, const float* res, int res_pix_stride,
+              float* out, int out_pix_stride, om_stream stream) {
+    return om_conv2d_mode(in, B, H, W, cin, in_pix_stride, w, scale, shift, cout, ksize, stride, leaky, res, res_pix_stride, out,
+                          out_pix_stride, 0, 1, stream);
 }
 
 size_t om_conv2d_winograd_scratch_bytes(int B, int H, int W, int cin) {

@@ -148,6 +148,39 @@ def test_conv_layer_matches_torch(dev, case):
     assert _rel_err(got, want) < 2e-6, case
 
 
+@pytest.mark.parametrize("up,cin,cout,hw,cstride,coff", [(2, 512, 256, (5, 7), 768, 0), (8, 512, 64, (3, 3), 256, 64),
+                                                       (4, 256, 64, (6, 5), 256, 128)])
+def test_conv_upsample_epilogue_matches_torch(dev, up, cin, cout, hw, cstride, coff):
+    """NearestUpsample fused into the producing 1x1 convolution (model/base.py:95-101, fpnplus.py:78-86): every output pixel
+    is written up x up times into its channel slice of the concat buffer; the other channels of the buffer stay untouched."""
+    L = omlib.load()
+    H, W = hw
+    B = 2
+    g = torch.Generator().manual_seed(up * 100 + cout)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.2
+    want = torch.nn.functional.conv2d(x.double(), w.double()) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    want = torch.where(want > 0, want, want * 0.1)
+    want = torch.nn.functional.interpolate(want, scale_factor=float(up), mode="nearest")
+    cpad = (cout + 31) // 32 * 32
+    wp = torch.zeros(cpad, cin); wp[:cout] = w.reshape(cout, cin)
+    sp = torch.zeros(cpad); sp[:cout] = scale
+    hp = torch.zeros(cpad); hp[:cout] = shift
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd, sd_, hd = wp.to(dev), sp.to(dev), hp.to(dev)
+    buf = torch.full((B, H * up, W * up, cstride), 7.0, device=dev)          # the concat buffer
+    view = buf[..., coff:]
+    rc = L.om_conv2d_mode(_p(xd), B, H, W, cin, cin, _p(wd), _p(sd_), _p(hd), cout, 1, 1, 1, None, 0,
+                          ctypes.c_void_p(view.data_ptr()), cstride, 1, up, omlib.current_stream_ptr(dev))
+    omlib.check(rc, "om_conv2d_mode")
+    got = buf[..., coff:coff + cout].cpu().permute(0, 3, 1, 2).double()
+    assert _rel_err(got, want) < 2e-6
+    rest = torch.cat([buf[..., :coff], buf[..., coff + cout:]], -1)
+    assert (rest == 7.0).all()
+
+
 WINO_CASES = [
     # B, H, W, cin, cout, leaky, residual
     (2, 16, 16, 32, 64, 1, True),
