@@ -183,6 +183,11 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="forward as N sub-batches on N HIP streams in the timed region (model.set_streams); the default 1 is "
                          "what the roofline figures assume (per-kernel events time overlapping kernels otherwise)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight in the timed region behind `value` (orienmask_amd.pipeline.InFlightPipeline: whole "
+                         "batches on alternating HIP streams, so that one batch's draining tile queues overlap the other's "
+                         "kernels).  1 = the reference's loop, one batch at a time; that region is ALWAYS timed too (it carries "
+                         "the per-kernel events of the roofline object) and reported as `one_batch_in_flight`")
     ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
                     help="f32: the parity path and the headline metric (default).  f16: BASELINE configs[4], fp16 "
                          "activations and weights with fp32 accumulation -- a separate, clearly labelled line")
@@ -275,6 +280,30 @@ def main():
     timed_ms, timed_fw = net.profile_read()
     net.profile_enable(False)
     net.set_streams(1)
+
+    # ---- the same K steps with args.in_flight whole batches in flight (no per-kernel events: kernels of different batches
+    # overlap here, their individual durations say nothing)
+    elapsed_serial = elapsed
+    if args.in_flight > 1:
+        import itertools
+        from orienmask_amd.pipeline import InFlightPipeline
+        pipe = InFlightPipeline(net, post, depth=args.in_flight)
+        for dets in pipe.map(itertools.repeat(x, 2 * args.in_flight)):     # allocates the per-slot workspaces, untimed
+            pass
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for dets in pipe.map(itertools.repeat(x, args.steps)):
+            pass
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = t.item()
     timed_fw //= max(args.streams, 1)                              # one om_forward per sub-batch
     dom_main_ms = sum(ms for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw      # per step, all launches
     dom_timed_ms = dom_main_ms + sum(pre for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw
@@ -370,7 +399,7 @@ def main():
                         avg_launch_ms_with_pre_pass=round(dom_timed_ms / d["launches"], 4),
                         kernel_ms_per_step=round(dom_timed_ms, 3),
                         measured="HIP events on the launch stream around every launch of this kernel (and of its pre-pass) inside the "
-                                 "timed region; the other per-kernel figures come from an untimed pass with events around all layers",
+                                 "timed one-batch-in-flight region; the other per-kernel figures come from an untimed pass with events around all layers",
                         achieved_algorithmic=round(achieved_alg, 2),
                         achieved_without_pre_pass=round(executed_main_only, 2),
                         note=("fp16 operands, fp32 accumulate on v_mfma_f32_32x32x16_f16 (dense peak 2.5 PFLOP/s); direct "
@@ -414,8 +443,13 @@ def main():
                                          "%s heads (dense: >400 candidates pass conf_thresh per image, NMS, 100 masks per image; "
                                          "sparse: a few tens of detections per image)"
                                          % (B, H, W, WEIGHT_SEED, obj_bias, HEAD_GAIN, args.heads),
-                                per_gpu_batch=B, image_size=[H, W], forward_streams=args.streams, detections_per_image=round(sum(int(d_["bbox"].shape[0]) for d_ in dets) / B, 1),
+                                per_gpu_batch=B, image_size=[H, W], forward_streams=args.streams, batches_in_flight=args.in_flight, detections_per_image=round(sum(int(d_["bbox"].shape[0]) for d_ in dets) / B, 1),
                                 parallelism="batch shard x%d, one RCCL weight broadcast, no collective in the step" % world),
+                    one_batch_in_flight=dict(value=round(total_images / elapsed_serial, 2), ms_per_step=round(elapsed_serial / args.steps * 1e3, 3),
+                                             note="the same K steps one batch at a time (the reference's loop: forward, postprocess, "
+                                                  "host reads the counts, next batch); the roofline object's per-kernel events were "
+                                                  "recorded in THIS region, where kernels do not overlap.  `value` keeps "
+                                                  "batches_in_flight whole batches enqueued on alternating HIP streams"),
                     roofline=roofline)
         if not args.no_extras:
             line["extras"] = measure_neighbours(dev, dets, B)

@@ -509,6 +509,32 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bil_row(float v0, float v1, float w0, float w1) { return fmaf(v0, w0, v1 * w1); }
 
+// The mask predicate (postprocess.py:156-164), |Px - cx| < tx && |Py - cy| < ty, WITHOUT floating-point compares.
+// The obvious form compiles to 32 v_cmp_lt_f32_e64 per detection, each writing an SGPR pair, combined by s_and_b64 and
+// expanded again by v_cndmask.  On MI355X that sequence returns wrong lane masks (the previous detection's) in a few waves per
+// launch while fp16-MFMA waves of another stream's convolution are resident on the same SIMD: every input is bit-identical,
+// the masks differ in ~1e-5 of the bytes, and a stand-alone copy of just this loop reproduces it (tools/hazard_probe;
+// profiles/r02_experiments.md section 6).  Alone on the GPU, or beside fp32 kernels, the compare form is exact.  The form
+// below keeps every intermediate in VGPRs:
+//   for non-negative floats (sign bit cleared; +inf and NaN included) the IEEE order is the order of the bit patterns as
+//   integers, and a NaN pattern is larger than every number, so  a < t  <=>  bits(a) < bits(t)  for a number t >= 0;
+//   a threshold that is negative, -0 or NaN can never be exceeded downwards: threshold_bits() maps it to 0 (a < 0 is false);
+//   both patterns are below 2^31, so the unsigned difference has its top bit set exactly when bits(a) < bits(t).
+// fp32 denormals are preserved in this library's kernels (.amdhsa_float_denorm_mode_32 3), like on the reference's CPU, so the
+// integer order also agrees for them.  The subtraction is inline asm so that the compiler cannot turn it back into a compare.
+__device__ __forceinline__ unsigned threshold_bits(float t) {
+    const unsigned u = __float_as_uint(t);
+    return u <= 0x7f800000u ? u : 0u;
+}
+__device__ __forceinline__ unsigned sub_u32_opaque(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_sub_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned inside_bit(unsigned ax, unsigned tx, unsigned ay, unsigned ty) {
+    return (sub_u32_opaque(ax, tx) & sub_u32_opaque(ay, ty)) >> 31;
+}
+
 __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
     // blockIdx.y = (image, anchor field): the x4 bilinear up-sampling of an anchor's two orientation planes is shared by
     // every detection of that anchor (9 fields but up to 100 detections per image), so it is evaluated ONCE per block of
@@ -518,13 +544,32 @@ __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
     // and the horizontal taps are done once per block instead of once per row.
     const int nfields = p.cfg.num_scales * p.cfg.anchors_per_scale;
     const int b = blockIdx.y / nfields, field = blockIdx.y - b * nfields;
-    const int count = p.out_count[b];
-    const float* dpar = p.det_par + (size_t)b * p.cfg.nms_post * 8;
-    // does this image have a detection on this field at all?  (uniform: scalar loads)
-    int first = -1;
-    for (int k = 0; k < count; ++k)
-        if (__float_as_int(dpar[k * 8 + 6]) == field * 2) { first = k; break; }
-    if (first < 0) return;
+    // The detections of this (image, anchor field), compacted into LDS once per workgroup: {cx, cy, bits(tx), bits(ty)} and
+    // the output slot k; the loop over them below touches no global memory but its own stores.
+    __shared__ float4 s_det[SEL_MAXN];
+    __shared__ int s_slot[SEL_MAXN];
+    __shared__ float s_anchor[2];
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    {
+        const int count = p.out_count[b];
+        const float* dpar = p.det_par + (size_t)b * p.cfg.nms_post * 8;
+        for (int k = threadIdx.x; k < count; k += 256) {
+            const float* dp = dpar + k * 8;
+            if (__float_as_int(dp[6]) != field * 2) continue;
+            const int slot = atomicAdd(&s_n, 1);
+            s_det[slot] = make_float4(dp[0], dp[1], __uint_as_float(threshold_bits(dp[2])), __uint_as_float(threshold_bits(dp[3])));
+            s_slot[slot] = k;
+            if (slot == 0) {        // grid_anchors of the field: the same for every detection on it
+                s_anchor[0] = dp[4];
+                s_anchor[1] = dp[5];
+            }
+        }
+    }
+    __syncthreads();
+    const int n_det = s_n;
+    if (n_det == 0) return;         // no detection of this image on this field
     const int H = p.cfg.image_h, W = p.cfg.image_w;
     const int groups = W / MASK_PX;
     const int oh = H / 4, ow = W / 4;
@@ -597,7 +642,7 @@ __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
         }
         // P = (v * grid_anchor) / 2 + base (postprocess.py:142-143) depends on the ANCHOR only, not on the detection: once per
         // pixel; the loop over the field's detections keeps only the two |P - c| < t tests
-        const float gax = dpar[first * 8 + 4], gay = dpar[first * 8 + 5];
+        const float gax = s_anchor[0], gay = s_anchor[1];
         float Px[MASK_PX], Py[MASK_PX];
 #pragma unroll
         for (int e = 0; e < MASK_PX; ++e) {
@@ -606,15 +651,17 @@ __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
             Px[e] = (vx[e] * gax) / 2.0f + base_x;
             Py[e] = (vy[e] * gay) / 2.0f + base_y;
         }
-        for (int k = first; k < count; ++k) {
-            const float* dp = dpar + k * 8;
-            if (__float_as_int(dp[6]) != field * 2) continue;              // uniform
-            const float cx = dp[0], cy = dp[1], tx = dp[2], ty = dp[3];
+        for (int i = 0; i < n_det; ++i) {
+            const float4 d = s_det[i];                                     // uniform: one LDS broadcast
+            const int k = s_slot[i];
+            const float cx = d.x, cy = d.y;
+            const unsigned tx = __float_as_uint(d.z), ty = __float_as_uint(d.w);
             unsigned packed[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < MASK_PX; ++e) {
-                const bool inside = (fabsf(Px[e] - cx) < tx) && (fabsf(Py[e] - cy) < ty);
-                packed[e >> 2] |= (inside ? 1u : 0u) << ((e & 3) * 8);
+                // inside = (|Px - cx| < tx) && (|Py - cy| < ty), evaluated on the bit patterns (see inside_bit)
+                const unsigned ax = __float_as_uint(Px[e] - cx) & 0x7fffffffu, ay = __float_as_uint(Py[e] - cy) & 0x7fffffffu;
+                packed[e >> 2] |= inside_bit(ax, tx, ay, ty) << ((e & 3) * 8);
             }
             uint4 o;
             o.x = packed[0]; o.y = packed[1]; o.z = packed[2]; o.w = packed[3];

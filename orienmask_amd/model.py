@@ -13,6 +13,7 @@ Differences a caller can observe (documented in INTEGRATION.md):
     channels-last memory (NHWC, 256-float pixel stride); the orientation tensors are views of one
     contiguous [B, 6A, H/4, W/4] buffer exactly as torch.split returns them in the reference.
 """
+import contextlib
 import ctypes
 import math
 
@@ -83,7 +84,9 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         self.n_streams = 1           # set_streams(): sub-batches on side HIP streams
         self._side_streams = {}
         self._packed_device = None
-        self._workspace = {}         # (device, B, H, W) -> uint8 tensor
+        self._workspace = {}         # (device, B, H, W) -> uint8 tensor (workspace slot 0)
+        self._slot = 0               # workspace_slot(): which workspace forward() uses
+        self._slot_workspaces = {}   # slot > 0 -> {key: uint8 tensor}
         if pretrained is not None:
             self._load_pretrained_backbone(pretrained)
 
@@ -167,6 +170,19 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         self.n_streams = int(n)
         return self
 
+    @contextlib.contextmanager
+    def workspace_slot(self, slot):
+        """forward() calls inside the block use workspace number `slot` (each slot owns its activation buffers and tile
+        queues), so that batches enqueued on different HIP streams can be in flight together (pipeline.InFlightPipeline).
+        The model handle itself is stateless across calls: weights are only read."""
+        if int(slot) < 0:
+            raise ValueError("slot must be >= 0")
+        prev, self._slot = self._slot, int(slot)
+        try:
+            yield self
+        finally:
+            self._slot = prev
+
     def packed_weights_f16(self, device):
         h = self._ensure_handle()
         if self._packed16 is None or self._packed16.device != device:
@@ -214,13 +230,14 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         n_sub = self.n_streams if (self.n_streams > 1 and B % self.n_streams == 0) else 1
         Bs = B // n_sub
         key = (dev, Bs, H, W, f16, n_sub)
-        ws = self._workspace.get(key)
+        cache = self._workspace if self._slot == 0 else self._slot_workspaces.setdefault(self._slot, {})
+        ws = cache.get(key)
         if ws is None:
             nbytes = (L.om_forward_f16_workspace_bytes if f16 else L.om_forward_workspace_bytes)(h, Bs, H, W)
             nbytes = (nbytes + 255) // 256 * 256
-            self._workspace.clear()
+            cache.clear()
             ws = torch.empty(nbytes * n_sub, dtype=torch.uint8, device=dev)
-            self._workspace[key] = ws
+            cache[key] = ws
         ws_each = ws.numel() // n_sub
         A = self.num_anchors
         bbox_dim = A * (5 + self.num_classes)
@@ -261,6 +278,7 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         forward.  Drops the cached workspaces: the next forward sizes a new one."""
         _lib.check(_lib.load().om_model_keep_activations(self._ensure_handle(), 1 if keep else 0), "om_model_keep_activations")
         self._workspace.clear()
+        self._slot_workspaces.clear()
         return self
 
     def layer_output(self, name, x_shape):

@@ -189,6 +189,33 @@ def test_cpu_tensors_are_rejected_loudly(built):
         post(heads)
 
 
+def test_in_flight_pipeline_host_logic(built):
+    """The pipeline's bookkeeping without a GPU: argument checks, slot-local postprocess workspaces, workspace_slot scoping."""
+    from orienmask_amd import eval as om_eval
+    from orienmask_amd.model import OrienMaskYOLOFPNPlus
+    from orienmask_amd.pipeline import InFlightPipeline
+    net = OrienMaskYOLOFPNPlus(3, 80).eval()
+    post = om_eval.OrienMaskYOLOPostProcess(**post_cfg((96, 96)))
+    with pytest.raises(ValueError):
+        InFlightPipeline(net, post, depth=0)
+    pipe = InFlightPipeline(net, post, depth=3)
+    assert pipe._posts[0] is post and len({id(p._ws) for p in pipe._posts}) == 3
+    assert all(p.cfg_struct(256).nms_pre == post.nms_pre for p in pipe._posts)
+    with pytest.raises(omlib.OrienMaskHipError):
+        pipe.submit(torch.zeros(1, 3, 96, 96))            # CPU tensor: no fallback
+    assert len(pipe) == 0
+    with pytest.raises(RuntimeError):
+        pipe.result()
+    assert net._slot == 0
+    with net.workspace_slot(2):
+        assert net._slot == 2
+        with pytest.raises(ValueError):
+            with net.workspace_slot(-1):
+                pass
+        assert net._slot == 2
+    assert net._slot == 0
+
+
 def test_missing_library_is_fatal(monkeypatch, built):
     monkeypatch.setattr(omlib, "_lib", None)
     monkeypatch.setattr(omlib, "LIB_PATH", "/nonexistent/liborienmask_hip.so")

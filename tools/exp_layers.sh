@@ -2,7 +2,7 @@
 # per-layer times of the Winograd layers for a list of OM_EXPERIMENT values, side by side
 VARS=$1; shift
 for v in $VARS; do
-  OM_EXPERIMENT=$v timeout 100 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --layers "$@" 2> /tmp/expl_$v.err > /dev/null
+  OM_EXPERIMENT=$v timeout 100 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --in-flight 1 --layers "$@" 2> /tmp/expl_$v.err > /dev/null
 done
 python - $VARS <<'PY'
 import sys, re

@@ -4,7 +4,7 @@
 VARS=$1; shift
 for v in $VARS; do
   echo "=== OM_EXPERIMENT=$v"
-  OM_EXPERIMENT=$v timeout 100 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --layers "$@" 2> /tmp/exp_$v.err | python -c "
+  OM_EXPERIMENT=$v timeout 100 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --in-flight 1 --layers "$@" 2> /tmp/exp_$v.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print('value', d['value'], 'ms/step', d['ms_per_step'], 'dom', r['kernel'], 'avg_launch_ms', r['avg_launch_ms'], 'frac', r['frac'], 'fwd_ms', r['forward_kernels_ms_per_step'])"
