@@ -188,6 +188,9 @@ def main():
                          "batches on alternating HIP streams, so that one batch's draining tile queues overlap the other's "
                          "kernels).  1 = the reference's loop, one batch at a time; that region is ALWAYS timed too (it carries "
                          "the per-kernel events of the roofline object) and reported as `one_batch_in_flight`")
+    ap.add_argument("--lib", default=None,
+                    help="path of another build of liborienmask_hip.so to load instead of the in-tree one (A/B runs of two "
+                         "builds on the same GPU box: tools/ab_bench.sh)")
     ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
                     help="f32: the parity path and the headline metric (default).  f16: BASELINE configs[4], fp16 "
                          "activations and weights with fp32 accumulation -- a separate, clearly labelled line")
@@ -207,6 +210,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.lib:
+        from orienmask_amd import lib as _omlib
+        _omlib.LIB_PATH = os.path.abspath(args.lib)
     from orienmask_amd import arch, synth
     from orienmask_amd.dist import broadcast_packed_weights
     from orienmask_amd.eval import OrienMaskYOLOPostProcess

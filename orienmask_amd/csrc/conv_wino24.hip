@@ -68,12 +68,12 @@ __global__ __launch_bounds__(256) void wino24_input_kernel(const float* __restri
         const f32x4 a12 = t[1] + t[2], s12 = t[1] - t[2];           // shared sub-expressions
         const f32x4 a34 = t[3] + t[4], s34 = t[4] - t[3];
         float* op = o + (size_t)(i * 6) * plane;
-        *reinterpret_cast<f32x4*>(op + 0 * plane) = 4.f * t[0] - 5.f * t[2] + t[4];
-        *reinterpret_cast<f32x4*>(op + 1 * plane) = a34 - 4.f * a12;
-        *reinterpret_cast<f32x4*>(op + 2 * plane) = 4.f * s12 + s34;
-        *reinterpret_cast<f32x4*>(op + 3 * plane) = (t[4] - t[2]) + 2.f * (t[3] - t[1]);
-        *reinterpret_cast<f32x4*>(op + 4 * plane) = (t[4] - t[2]) - 2.f * (t[3] - t[1]);
-        *reinterpret_cast<f32x4*>(op + 5 * plane) = 4.f * t[1] - 5.f * t[3] + t[5];
+        __builtin_nontemporal_store((f32x4)(4.f * t[0] - 5.f * t[2] + t[4]), reinterpret_cast<f32x4*>(op + 0 * plane));
+        __builtin_nontemporal_store((f32x4)(a34 - 4.f * a12), reinterpret_cast<f32x4*>(op + 1 * plane));
+        __builtin_nontemporal_store((f32x4)(4.f * s12 + s34), reinterpret_cast<f32x4*>(op + 2 * plane));
+        __builtin_nontemporal_store((f32x4)((t[4] - t[2]) + 2.f * (t[3] - t[1])), reinterpret_cast<f32x4*>(op + 3 * plane));
+        __builtin_nontemporal_store((f32x4)((t[4] - t[2]) - 2.f * (t[3] - t[1])), reinterpret_cast<f32x4*>(op + 4 * plane));
+        __builtin_nontemporal_store((f32x4)(4.f * t[1] - 5.f * t[3] + t[5]), reinterpret_cast<f32x4*>(op + 5 * plane));
     }
 }
 
