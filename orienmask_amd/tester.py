@@ -44,7 +44,13 @@ class Tester:
         self.device = device
         self.on_batch = on_batch
 
-    def test(self, verbose=True):
+    def test(self, verbose=True, in_flight=1):
+        """in_flight = 1: the reference's loop and timers.  in_flight > 1: the same batches through
+        pipeline.InFlightPipeline (forward + postprocess of consecutive batches overlap on alternating HIP streams, so the two
+        stages cannot be timed apart): one 'Forward & Postprocess' figure, wall time of the loop over its images; detections
+        reach `on_batch` in the same order."""
+        if in_flight > 1:
+            return self._test_in_flight(verbose, in_flight)
         _timer.reset()
         _timer.cpu() if str(self.device) == "cpu" else _timer.cuda()
         self.model.eval()
@@ -68,6 +74,41 @@ class Tester:
             print("Speed Statistics (batch size = {})".format(bs))
             for k, v in log.items():
                 print("%s: %.3fms (%.3ffps)" % (k, v / bs, 1000 * bs / v))
+        stats["detections"] = n_det
+        return stats
+
+
+    def _test_in_flight(self, verbose, depth):
+        import time
+        from .pipeline import InFlightPipeline
+        self.model.eval()
+        pipe = InFlightPipeline(self.model, self.postprocess, depth=depth)
+        infos, n_det, n_img = [], 0, 0
+        convert_ms = 0.0
+
+        def batches():
+            for sample in self.test_loader:
+                infos.append(sample[2])
+                yield sample[0].to(self.device)
+
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        for i, detections in enumerate(pipe.map(batches())):
+            n_det += sum(int(d["bbox"].shape[0]) for d in detections)
+            n_img += len(detections)
+            if self.on_batch is not None:
+                c0 = time.perf_counter()
+                self.on_batch(infos[i], detections)
+                convert_ms += (time.perf_counter() - c0) * 1e3
+        torch.cuda.synchronize(self.device)
+        total_ms = (time.perf_counter() - t0) * 1e3 - convert_ms
+        stats = {"Forward & Postprocess": dict(ms_per_image=total_ms / max(n_img, 1), fps=1000.0 * n_img / total_ms)}
+        if self.on_batch is not None:
+            stats["Convert Format"] = dict(ms_per_image=convert_ms / max(n_img, 1), fps=1000.0 * n_img / max(convert_ms, 1e-9))
+        if verbose:
+            print("Speed Statistics (batch size = {}, {} batches in flight)".format(self.test_loader.batch_size, depth))
+            for k, v in stats.items():
+                print("%s: %.3fms (%.3ffps)" % (k, v["ms_per_image"], v["fps"]))
         stats["detections"] = n_det
         return stats
 

@@ -710,6 +710,16 @@ def test_tester_and_infer_loops(dev):
     assert set(stats) >= {"Network Forward", "Postprocess", "Convert Format", "detections"}
     assert stats["Network Forward"]["fps"] > 0 and len(seen) == 2 and [len(s[1]) for s in seen] == [4, 2]
     assert [i["id"] for s in seen for i in s[0]] == list(range(6))
+    # the same loader with two batches in flight: same detections in the same order, one combined timer
+    seen2 = []
+    tester2 = Tester(net, post, SyntheticLoader(6, 4, seed=500), dev,
+                     on_batch=lambda info, dets: seen2.append((info, [{k: v.clone() for k, v in d.items()} for d in dets])))
+    stats2 = tester2.test(verbose=False, in_flight=2)
+    assert set(stats2) == {"Forward & Postprocess", "Convert Format", "detections"} and stats2["detections"] == stats["detections"]
+    assert [i["id"] for s_ in seen2 for i in s_[0]] == list(range(6))
+    for (_, a), (_, b) in zip(seen, seen2):
+        for da, db in zip(a, b):
+            assert torch.equal(da["bbox"], db["bbox"]) and torch.equal(da["cls"], db["cls"]) and torch.equal(da["mask"], db["mask"])
     tf = FastCOCOTransform([FastCOCOTransform.Resize((544, 544)), FastCOCOTransform.Normalize((0, 0, 0), (255, 255, 255))])
     imgs = [synth.synth_photo_batch(900 + i, 1, 240 + 16 * i, 320)[0] for i in range(3)]
     dets, pads, log = infer_loop(net, tf, post, imgs, dev, warmup=2)
