@@ -1086,15 +1086,15 @@ def test_in_flight_pipeline_matches_eager(dev, prec, depth):
         pipe.submit(xs[0].cpu())
 
 
-@pytest.mark.parametrize("other", ["f16", "f32"])
-def test_postprocess_and_forward_are_stable_beside_other_streams(dev, other):
+@pytest.mark.parametrize("prec,other", [("f32", "f16"), ("f32", "f32"), ("f16", "f16")])
+def test_postprocess_and_forward_are_stable_beside_other_streams(dev, prec, other):
     """Kernels of two HIP streams share compute units (InFlightPipeline relies on it).  Results must not depend on what the
     other stream runs: the postprocess of a fixed prediction and a forward of a fixed batch are repeated while a second
     model instance runs forwards on another stream, and compared bit for bit with the launch that ran alone.
     (The mask kernel's floating-point-compare predicate failed exactly this beside fp16 convolutions: post.hip inside_bit,
     tools/hazard_probe.)"""
     sd = synth.synth_state_dict(3, obj_bias=-16.0, head_gain=4.0)
-    net = _hip_model(sd, dev)
+    net = _hip_model(sd, dev).set_precision(prec)
     busy = _hip_model(sd, dev).set_precision(other)
     post = _hip_post((544, 544), dev)
     x = synth.synth_image_batch(900, 2, 544, 544).to(dev)

@@ -1,13 +1,13 @@
-"""Does a dense run of floating-point compares survive fp16-MFMA waves of another stream on the same SIMD?
+"""Does a dense run of floating-point compares survive matrix-instruction waves of another stream on the same SIMD?
 
     gpurun -- 'python tools/hazard_probe/run.py'
 
-Builds probe.hip (hipcc, gfx950), then launches the compare form and the arithmetic form of the mask predicate
-(a) alone and (b) while 60 launches of one fp16 3x3 convolution of this library (om_conv2d_f16, 1 x 136 x 136, 128 -> 256)
-run on a second HIP stream, and counts the output words that differ from the launch that ran alone.  Also checks that the two
-forms agree bit for bit on random and special operands (NaN, +-inf, denormals, +-0, negative and NaN thresholds).
-Result on MI355X (ROCm 7.2), profiles/r02_experiments.md section 6: compare form ~12 000 wrong words of 52 M per launch in (b),
-0 in (a); arithmetic form 0 in both.
+Builds probe.hip (hipcc, gfx950), then launches four forms of the mask predicate (compare: v_cmp_e64 -> SGPR pair -> s_and_b64 ->
+v_cndmask; arithmetic: bit patterns in VGPRs; vcc: VOPC -> VCC -> v_cndmask; branches: v_cmp -> s_and_saveexec) alone and while a
+second HIP stream runs, in turn: kernels that only issue one matrix instruction on registers, one fp16 / fp32 3x3 convolution of
+this library, rocBLAS GEMMs, an elementwise kernel; and counts the output words that differ from the launch that ran alone.  Also
+checks that the forms agree bit for bit on random and special operands (NaN, +-inf, denormals, +-0, negative and NaN thresholds).
+Result on MI355X (ROCm 7.2): profiles/r02_experiments.md section 6.
 """
 import ctypes
 import os
@@ -62,19 +62,58 @@ def conv_on(stream):
                                 ctypes.c_void_p(stream.cuda_stream)), "om_conv2d_f16")
 
 
+# other neighbours, to see what about the fp16 convolution matters
+xf = torch.randn(B, H, W, cin, generator=g).to(dev)
+wf = (torch.randn(cout, 9 * cin, generator=g) / (cin * 9) ** 0.5).to(dev)
+yf = torch.empty((B, H, W, cout), device=dev)
+h16 = torch.randn(4096, 4096, generator=g).half().to(dev)
+f32m = torch.randn(2048, 2048, generator=g).to(dev)
+big = torch.randn(1 << 26, generator=g).to(dev)
+
+
+def conv32_on(stream):
+    omlib.check(L.om_conv2d(_p(xf), B, H, W, cin, cin, _p(wf), _p(sp), _p(hp), cout, 3, 1, 1, None, 0, _p(yf), cout,
+                            ctypes.c_void_p(stream.cuda_stream)), "om_conv2d")
+
+
+sink = torch.zeros(4, device=dev)
+
+
+def mfma_only(kind):
+    return lambda s: P.neighbour_launch(kind, _p(sink), 2048, 20000, ctypes.c_void_p(s.cuda_stream))
+
+
+NEIGHBOURS = [
+    ("alone", None, 0),
+    ("only v_mfma_f32_32x32x16_f16", mfma_only(0), 2),
+    ("only v_mfma_f32_32x32x2_f32", mfma_only(1), 2),
+    ("only v_mfma_f32_32x32x16_bf16", mfma_only(2), 2),
+    ("only v_mfma_f32_16x16x32_f16", mfma_only(3), 2),
+    ("this library's fp16 3x3 conv", conv_on, 60),
+    ("this library's fp32 3x3 conv", conv32_on, 12),
+    ("rocBLAS fp16 GEMM 4096^3", lambda s: torch.mm(h16, h16), 12),
+    ("rocBLAS fp32 GEMM 2048^3", lambda s: torch.mm(f32m, f32m), 12),
+    ("elementwise sin over 64 M floats", lambda s: torch.sin(big), 12),
+]
+
+FORMS = ("compare", "arithmetic", "vcc", "branches")
 with torch.cuda.stream(s0):
-    ref_c, ref_a = probe(0), probe(1)
+    refs = [probe(f) for f in range(4)]
 torch.cuda.synchronize()
-print("alone: compare form vs arithmetic form, differing words: %d of %d (fraction of set bytes %.3f)"
-      % (int((ref_c != ref_a).sum()), ref_c.numel(), float((ref_c & 1).float().mean())))
-for it in range(6):
-    for beside in (False, True):
-        torch.cuda.synchronize()
-        if beside:
-            for _ in range(60):
-                conv_on(s1)
-        with torch.cuda.stream(s0):
-            c, a = probe(0), probe(1)
-        torch.cuda.synchronize()
-        print("run %d %-28s compare form: %6d wrong words   arithmetic form: %6d wrong words"
-              % (it, "beside the fp16 convolution" if beside else "alone", int((c != ref_c).sum()), int((a != ref_a).sum())), flush=True)
+print("alone: forms agree with the compare form: %s (%d words, fraction of set bytes %.3f)"
+      % ([int((r != refs[0]).sum()) for r in refs], refs[0].numel(), float((refs[0] & 1).float().mean())))
+for it in range(2):
+    for name, fn, reps in NEIGHBOURS:
+        wrong = []
+        for f in range(4):
+            torch.cuda.synchronize()
+            if fn is not None:
+                with torch.cuda.stream(s1):
+                    for _ in range(reps):
+                        fn(s1)
+            with torch.cuda.stream(s0):
+                got = probe(f)
+            torch.cuda.synchronize()
+            wrong.append(int((got != refs[f]).sum()))
+            del got
+        print("run %d beside %-36s wrong words: %s" % (it, name, "  ".join("%s %7d" % (FORMS[f], wrong[f]) for f in range(4))), flush=True)
