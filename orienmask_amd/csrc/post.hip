@@ -512,12 +512,9 @@ __device__ __forceinline__ float bil_row(float v0, float v1, float w0, float w1)
 // The mask predicate (postprocess.py:156-164), |Px - cx| < tx && |Py - cy| < ty, WITHOUT floating-point compares.
 // The obvious form compiles to 32 v_cmp_lt_f32_e64 per detection, each writing an SGPR pair, combined by s_and_b64 and
 // expanded again by v_cndmask.  On MI355X that sequence returns wrong lane masks (the previous detection's) in a few waves per
-// launch while waves of ANOTHER kernel issue gfx950's wide-K matrix instructions on the same SIMD: every input is bit-identical
-// and ~1e-5 of the mask bytes differ.  tools/hazard_probe reproduces it with a neighbour that does nothing but
-// v_mfma_f32_32x32x16_bf16 on registers (0.3-0.5 % of the output words wrong), v_mfma_f32_16x16x32_f16 (3e-4) or
-// v_mfma_f32_32x32x16_f16 (this library's fp16 convolutions: 4e-5); v_mfma_f32_32x32x2_f32, rocBLAS GEMMs, copies: none.
-// Compares that go VOPC -> VCC -> v_cndmask, and real divergent branches (v_cmp -> s_and_saveexec), are NOT affected; only the
-// dense run of VALU compares into arbitrary SGPR pairs that SALU then combines (profiles/r02_experiments.md section 6).  The form
+// launch while waves of ANOTHER kernel issue gfx950's wide-K matrix instructions (v_mfma_f32_32x32x16_bf16 / _f16, 16x16x32_f16:
+// e.g. this library's fp16 convolutions) on the same SIMD; compares through VCC and divergent branches are not affected
+// (tools/hazard_probe, profiles/r02_experiments.md section 6).  Alone, or beside fp32 kernels, the compare form is exact.  The form
 // below keeps every intermediate in VGPRs:
 //   for non-negative floats (sign bit cleared; +inf and NaN included) the IEEE order is the order of the bit patterns as
 //   integers, and a NaN pattern is larger than every number, so  a < t  <=>  bits(a) < bits(t)  for a number t >= 0;
