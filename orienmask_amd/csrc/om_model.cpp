@@ -96,9 +96,11 @@ struct om_model {
         L.info.wino_alt_off = -1;
         L.info.wino_planes = 0;
         if (ks == 3 && stride == 1 && !stem && L.info.cout_pad % 64 == 0 && cin % 32 == 0) {
-            // F(2x4,3x3) (24 planes), except at 1/32 scale (17 x 17 at 544: 18 % of a 2 x 4 tiling is padding and the GEMM has too few tiles:
-            // measured 0.465 vs 0.436 ms per conv6 layer).
-            L.info.wino_planes = in_div < 32 ? 24 : 16;
+            // F(2x4,3x3) (24 planes) at every scale.  At 1/32 scale (17 x 17 at 544: 18 % of a 2 x 4 tiling is padding, 368 tiles for 512
+            // resident workgroups) a layer takes the same time as with F(2x2) when it runs alone (0.441 vs 0.443 ms at bs=32) but
+            // leaves a quarter of the chip to the other batch in flight: +0.9 % end to end with two in flight, -0.5 % one at a time
+            // (same-box A/B, profiles/r02_experiments.md).
+            L.info.wino_planes = 24;
             weight_floats = om::align_up(weight_floats, 4);
             L.info.wino_off = (int64_t)weight_floats;
             weight_floats += (size_t)L.info.wino_planes * L.info.cout_pad * cin;

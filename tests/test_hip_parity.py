@@ -970,7 +970,7 @@ def test_forward_bs6_uses_f24_and_matches_oracle(dev):
     torch.cuda.synchronize()
     k6 = dict(net.layer_kernels(6, 544, 544)); k2 = dict(net.layer_kernels(2, 544, 544))
     assert k6["orien_head.2"].startswith("wino24_gemm") and k2["orien_head.2"].startswith("wino_gemm")
-    assert k6["backbone.conv6.2.conv.1"].startswith("wino_gemm")          # 1/32 scale: always F(2x2)
+    assert k6["backbone.conv6.2.conv.1"].startswith("wino24_gemm") and k2["backbone.conv6.2.conv.1"].startswith("wino_gemm")
     ref = R.forward(sd, x)
     for (gb, go), (rb, ro) in zip(out, ref):
         assert _rel_err(gb.cpu(), rb) < REL_TOL and _rel_err(go.cpu(), ro) < REL_TOL

@@ -92,8 +92,12 @@ def test_pack_folds_batchnorm(built):
     else:
         assert torch.equal(u[0], w[:, :, 0, 0] / 4) and torch.equal(u[23], w[:, :, 2, 2])
         assert torch.allclose(u[7], -(w.double().sum((2, 3)) / 12).float(), rtol=1e-6, atol=1e-8)
-    # the 1/32-scale layers keep F(2x2): too few 2 x 4 tiles at 17 x 17
-    assert by_name["backbone.conv6.1.conv.1"]["wino_planes"] == 16
+    # every stride-1 3x3 layer carries both transforms: F(2x4) for full batches, F(2x2) (wino_alt_off) for a few images
+    l6 = by_name["backbone.conv6.1.conv.1"]
+    assert l6["wino_planes"] == 24 and l6["wino_alt_off"] > l6["wino_off"]
+    u22 = blob[l6["wino_alt_off"]:l6["wino_alt_off"] + 16 * 1024 * 512].view(16, 1024, 512)
+    w6 = sd["backbone.conv6.1.conv.1.conv_block.0.weight"]
+    assert torch.equal(u22[0], w6[:, :, 0, 0]) and torch.equal(u22[15], w6[:, :, 2, 2])
 
 
 def test_registry_builders_mirror_reference(built):
