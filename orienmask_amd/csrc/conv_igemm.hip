@@ -58,22 +58,13 @@ struct IgemmParams {
     int vec_io;           // 1: out/res rows are 16-byte aligned (float4 epilogue)
     int total_in_pixels;  // B*H*W
     int w_bytes;          // cout_pad*taps*cin*4
-    // stream-K form only (see conv_wino24.hip)
-    float* partial;       // [slots][BM * BN] floats: the raw accumulators a slot publishes for the tile it shares
-    int* flags;           // [slots], zeroed before the launch
-    int slots;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // Operands go global -> LDS directly (buffer_load_dwordx4 ... lds); zero padding comes from the buffer descriptor's bounds
 // check (offset 0x80000000 is out of range -> zeros).
-// SK = true: the stream-K form of conv_wino24.hip with units = (tile, k-step): slot s owns units [s U / S, (s + 1) U / S), computes
-// the head k-steps of the tile at the end of its range FIRST and publishes the raw accumulators, runs its whole tiles, then
-// finishes the tile at the start of its range starting from the accumulators the previous slot published -- the same sequence
-// of MFMAs as in an unsplit tile, so the results are bit-identical.  Used where the last partial round of whole tiles hurts
-// most (fewer than two tiles per resident workgroup: the 1x1 layers at 1/32 and 1/16 scale, conv6.0).
-template <int BM, int BN, int WM, int WN, bool SK>
+template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NWN = BN / WN;
@@ -96,49 +87,25 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p
     const int fi = lane & 31, fk = lane >> 5;
     const int fsw = (fi >> 1) & 7;
 
-    int slot = 0, t_lead = 0, k_lead = 0, t_trail = 0, k_trail = 0, t_full0 = 0, n_full = 0, nseg = 0;
-    if constexpr (SK) {
-        if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
-        __syncthreads();
-        slot = __builtin_amdgcn_readfirstlane(*s_ticket);
-        const long long U = (long long)p.total_tiles * p.ksteps;
-        const long long u0 = U * slot / p.slots, u1 = U * (slot + 1) / p.slots;
-        t_lead = (int)(u0 / p.ksteps); k_lead = (int)(u0 - (long long)t_lead * p.ksteps);     // finish t_lead from step k_lead on
-        t_trail = (int)(u1 / p.ksteps); k_trail = (int)(u1 - (long long)t_trail * p.ksteps);  // head steps [0, k_trail) of t_trail
-        t_full0 = t_lead + (k_lead != 0);
-        n_full = t_trail - t_full0;
-        nseg = (k_trail != 0) + n_full + (k_lead != 0);
-    }
-
-    for (int seg = 0;; ++seg) {
-        int tile, ks0 = 0, ks1 = p.ksteps, mode = 0;      // mode 1: produce the head steps of a tile, 2: finish from the partner's
-        if constexpr (SK) {
-            if (seg >= nseg) break;
-            const int has_trail = k_trail != 0;
-            if (has_trail && seg == 0) { tile = t_trail; ks1 = k_trail; mode = 1; }
-            else if (seg - has_trail < n_full) { tile = t_full0 + seg - has_trail; }
-            else { tile = t_lead; ks0 = k_lead; mode = 2; }
-        } else if (p.ticket) {
+    for (;;) {
+        int tile;
+        if (p.ticket) {
             // lane 0's wave pays the ticket's round trip; the others wait at a raw barrier and do not drain the previous tile's
             // output stores (a __syncthreads() would make every wave wait for them: ~2 us per tile)
             if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             tile = *s_ticket;
-            if (tile >= p.total_tiles) break;
         } else {
             // static grid: XCD-aware, bijective remap of the workgroup id (block b runs on XCD b % 8)
             const int nblk = gridDim.x, bid = blockIdx.x;
             const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, i = bid >> 3;
             tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-            if (tile >= p.total_tiles) break;
         }
+        if (tile >= p.total_tiles) break;
         tile = __builtin_amdgcn_readfirstlane(tile);
-        const int nsteps = ks1 - ks0;
-        // queue: N fastest; stream-K: M fastest (the slots that share an input panel then run at the same time, conv_wino24.hip)
-        const int m_tiles = p.total_tiles / p.n_tiles;
-        const int tile_n = SK ? tile / m_tiles : tile % p.n_tiles;
-        const int tile_m = SK ? tile - tile_n * m_tiles : tile / p.n_tiles;
+        const int tile_n = tile % p.n_tiles;
+        const int tile_m = tile / p.n_tiles;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
 
         // ---- loader role: thread -> (row lrow + 32*j, 16-byte chunk lcol) ----------------
@@ -169,7 +136,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p
         const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_base), 0,
                                                              in_left < 0x7FFFFFFFull ? (int)in_left : 0x7FFFFFFF, 0x00020000);
         const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
-        int n_cc = ks0 % p.kc, n_kw = (ks0 / p.kc) % p.ks, n_kh = (ks0 / p.kc) / p.ks;   // (cin chunk, tap col, tap row) being fetched
+        int n_kh = 0, n_kw = 0, n_cc = 0;                   // (tap row, tap col, cin chunk) of the step being fetched
         auto advance = [&]() {
             if (++n_cc == p.kc) {
                 n_cc = 0;
@@ -204,30 +171,6 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-        if constexpr (SK) {
-            if (mode == 2) {
-                // the partner (slot - 1) published this tile's head steps as its first action
-                if (tid == 0) {
-                    for (int spins = 0; spins < (1 << 22) &&
-                                        __hip_atomic_load(p.flags + slot - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spins)
-                        __builtin_amdgcn_s_sleep(16);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                }
-                __syncthreads();
-                const auto rs_part = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, 0x7FFFFFFF, 0x00020000);
-                const int pbase = ((slot - 1) * (TM * TN * 4) * 256 + tid) * 16;
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                rs_part, pbase, ((a * TN + b) * 4 + g) * 256 * 16, 16));
-                            acc[a][b][4 * g] = v[0]; acc[a][b][4 * g + 1] = v[1]; acc[a][b][4 * g + 2] = v[2]; acc[a][b][4 * g + 3] = v[3];
-                        }
-            }
-        }
 
         {
             // Software pipeline with ONE barrier per k-step and nothing outside the MFMA stream:
@@ -255,9 +198,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             read_frags(ca, cb, 0, 0);
-            for (int s = 0; s < nsteps; ++s) {
+            for (int s = 0; s < p.ksteps; ++s) {
                 const int buf = s & 1;
-                const bool live = s + 1 < nsteps;
+                const bool live = s + 1 < p.ksteps;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -296,29 +239,6 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-        }
-
-        if constexpr (SK) {
-            if (mode == 1) {
-                // publish the raw accumulators: write-through (sc1) 16-byte stores, every wave drains, one lane raises the flag
-                const auto rs_part = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, 0x7FFFFFFF, 0x00020000);
-                const int pbase = (slot * (TM * TN * 4) * 256 + tid) * 16;
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
-                            __builtin_amdgcn_raw_buffer_store_b128(
-                                __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), rs_part, pbase,
-                                ((a * TN + b) * 4 + g) * 256 * 16, 16);
-                        }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) __hip_atomic_store(p.flags + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                continue;
-            }
         }
 
         // ---- epilogue, phase 1: accumulators -> LDS C tile [m][n], chunk index swizzled with m & 7.
@@ -402,7 +322,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const IgemmParams p
                 p.out[((size_t)bi * p.cout + n) * p.HoWo + rr] = t;
             }
         }
-        if (!SK && !p.ticket) break;
+        if (!p.ticket) break;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the C tile is dead before the next tile's operands land in
         __builtin_amdgcn_s_barrier();                            // LDS; the stores keep flying
     }
@@ -437,15 +357,7 @@ static int launch_tile(IgemmParams p, int cout_pad, int blocks_per_cu, hipStream
     p.total_tiles = (int)total;
     long long grid = total;
     if (p.ticket) grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
-    // stream-K where the last partial round of whole tiles hurts most: between one and two tiles per resident workgroup
-    // (from two on, the static split's own cost -- it is only as fast as the slowest workgroup -- cancels the gain)
-    if (p.partial && p.ticket && total >= grid && total < 2 * grid && grid <= SK_SLOTS &&
-        (size_t)grid * BM * BN * sizeof(float) <= SK_PARTIAL_BYTES) {
-        p.slots = (int)grid;
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-    } else {
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-    }
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }
@@ -479,7 +391,6 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t stream) {
     p.leaky = a.leaky; p.res_pix_stride = a.res_pix_stride; p.out_pix_stride = a.out_pix_stride;
     p.out_mode = a.out_mode; p.up = a.up;
     p.n_tiles = 0; p.total_tiles = 0;
-    p.partial = a.sk_partial; p.flags = a.ticket ? a.ticket + SK_FLAG_OFF : nullptr; p.slots = 0;
     p.total_in_pixels = a.B * a.H * a.W;
     p.w_bytes = a.cout_pad * p.taps * a.cin * 4;
     p.vec_io = (a.out_mode != 2 && a.out_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
