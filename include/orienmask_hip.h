@@ -260,6 +260,13 @@ int om_nms(const float* dets, int n, float thresh, int64_t* keep, int32_t* n_kee
 int om_nms_ex(const float* dets, int n, float thresh, int semantics, int64_t* keep, int32_t* n_keep, void* workspace,
               size_t ws_bytes, om_stream stream);
 
+/* ---- Several batches in flight.  Every entry point only enqueues kernels on the caller's stream and keeps no per-call state in
+ *      the model handle (profiling apart): om_forward / om_forward_f16 / om_postprocess may be issued for different batches
+ *      on different HIP streams at the same time, provided each batch in flight has its OWN workspace (and output buffers);
+ *      the weights are only read.  Kernels of the streams then share compute units, and results do not depend on what the
+ *      other stream runs (tests/test_hip_parity.py::test_postprocess_and_forward_are_stable_beside_other_streams).  The host
+ *      side of this is orienmask_amd/pipeline.py (InFlightPipeline): +13 % fp32 / +19 % fp16 images/s at 32 x 544 x 544. */
+
 #ifdef __cplusplus
 }
 #endif
