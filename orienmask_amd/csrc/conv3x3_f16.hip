@@ -232,11 +232,14 @@ bool conv3x3_f16_supported(const ConvArgsH& a) {
 
 void conv3x3_tile_for_f16(int M, int cout_pad, int* bm, int* bn) {
     if (cout_pad % 128) { *bm = 128; *bn = 64; return; }
-    // 256x128 when it fills the chip for at least a few rounds, else the finer 128x128
+    // the tile with the least matrix-pipe time over all its tiles: 256x128 unless its M padding costs more than the finer
+    // tile's 15 % lower efficiency.  Whole rounds of tiles are NOT part of the cost any more: with two batches in flight
+    // (pipeline.py) the other batch's kernels use the compute units a partial round leaves idle -- same-box A/B +4 % with two in
+    // flight, -1.7 % one batch at a time (profiles/r02_experiments.md).
     const long long t256 = (long long)((M + 255) / 256) * (cout_pad / 128);
     const long long t128 = (long long)((M + 127) / 128) * (cout_pad / 128);
-    const double c256 = (double)((t256 + 255) / 256) * 256 * 128 / 1.0;
-    const double c128 = (double)((t128 + 255) / 256) * 128 * 128 / 0.85;
+    const double c256 = (double)t256 * 256 * 128 / 1.0;
+    const double c128 = (double)t128 * 128 * 128 / 0.85;
     *bn = 128;
     *bm = c256 <= c128 ? 256 : 128;
 }

@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256, (f16_blocks_per_cu<BM, BN>())) void conv_igemm
 
 struct TileChoiceH { int bm, bn; };
 
-// Same cost model as the f32 kernel: ceil(tiles / CUs) tile-times weighted by how well the shape feeds the pipe.
+// Matrix-pipe time over all tiles, weighted by how well the shape feeds the pipe; partial rounds are not charged (the other
+// batch in flight fills them: conv3x3_f16.hip, conv3x3_tile_for_f16).
 static TileChoiceH choose_tile_f16(int M, int cout_pad) {
     struct Cand { int bm, bn; double eff; };
     const Cand cands[] = {{256, 128, 1.00}, {128, 128, 0.85}, {128, 64, 0.70}, {64, 64, 0.55}, {128, 32, 0.45}};
@@ -234,8 +235,7 @@ static TileChoiceH choose_tile_f16(int M, int cout_pad) {
     for (const Cand& c : cands) {
         if (cout_pad % c.bn) continue;
         const long long tiles = (long long)((M + c.bm - 1) / c.bm) * (cout_pad / c.bn);
-        const long long rounds = (tiles + 255) / 256;
-        const double cost = (double)rounds * c.bm * c.bn / c.eff;
+        const double cost = (double)tiles * c.bm * c.bn / c.eff;
         if (cost < best_cost) { best_cost = cost; best = TileChoiceH{c.bm, c.bn}; }
     }
     return best;
