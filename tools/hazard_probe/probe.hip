@@ -5,6 +5,8 @@
 //   form 1 (arithmetic): the same predicate on the bit patterns, everything in VGPRs
 //   form 2 (vcc):        every compare as VOPC -> VCC -> v_cndmask, combined with VALU and
 //   form 3 (branches):   nested divergent branches, v_cmp -> s_and_saveexec_b64
+//   forms 4, 5, 6:       the compare form in inline asm with 0 / 4+1 / 15+1 wait states (s_nop) between the VALU compares and
+//                        the s_and_b64 that reads their SGPR pairs
 // Both write one uint4 (16 predicate bytes) per thread and detection; run.py compares the outputs of repeated launches with
 // and without another stream's fp16 convolution resident.
 #include <hip/hip_runtime.h>
@@ -58,6 +60,53 @@ __global__ __launch_bounds__(256) void probe_kernel(const float* __restrict__ se
                 unsigned iy = (fabsf(Py[e] - d.y) < d.w) ? 1u : 0u;
                 asm("" : "+v"(iy));
                 packed[e >> 2] |= (ix & iy) << ((e & 3) * 8);
+            }
+        } else if constexpr (FORM == 7) {
+            // as the compiler schedules it: the lane masks are combined into VCC by SALU, further VALU compares (writing other SGPR
+            // pairs) are issued, THEN v_cndmask_b32_e32 reads VCC
+            unsigned long long mx[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float ax = Px[e] - d.x;
+                asm volatile("v_cmp_lt_f32_e64 %0, |%1|, %2" : "=s"(mx[e]) : "v"(ax), "v"(d.z));
+            }
+            unsigned long long my;
+            {
+                const float ay0 = Py[0] - d.y;
+                asm volatile("v_cmp_lt_f32_e64 %0, |%1|, %2" : "=s"(my) : "v"(ay0), "v"(d.w));
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float ay1 = Py[(e + 1) & 15] - d.y;
+                unsigned long long mynext;
+                unsigned bit;
+                const unsigned one = 1u << ((e & 3) * 8);
+                asm volatile("s_and_b64 vcc, %2, %3\n\tv_cmp_lt_f32_e64 %1, |%4|, %5\n\tv_cndmask_b32_e32 %0, 0, %6, vcc"
+                             : "=v"(bit), "=&s"(mynext) : "s"(mx[e]), "s"(my), "v"(ay1), "v"(d.w), "v"(one) : "vcc", "scc");
+                my = mynext;
+                packed[e >> 2] |= bit;
+            }
+        } else if constexpr (FORM >= 4) {
+            // the compare form written by hand with NOPS wait states between the VALU compares and the SALU that reads their
+            // SGPR pairs: 16 v_cmp_e64 into 16 SGPR pairs back to back (x), s_nop, then per element v_cmp (y) + s_and_b64 + v_cndmask
+            constexpr int NOPS = FORM == 4 ? 0 : FORM == 5 ? 4 : 15;
+            unsigned long long mx[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float ax = fabsf(Px[e] - d.x);
+                asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(mx[e]) : "v"(ax), "v"(d.z));
+            }
+            asm volatile("s_nop %0" ::"i"(NOPS));
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float ay = fabsf(Py[e] - d.y);
+                unsigned long long my, both;
+                unsigned bit;
+                asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(my) : "v"(ay), "v"(d.w));
+                asm volatile("s_nop %0" ::"i"(NOPS));
+                asm volatile("s_and_b64 %0, %1, %2" : "=s"(both) : "s"(mx[e]), "s"(my) : "scc");
+                asm volatile("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(bit) : "s"(both));
+                packed[e >> 2] |= bit << ((e & 3) * 8);
             }
         } else {
             // real divergent branches: v_cmp -> s_and_saveexec_b64 (the asm cannot be if-converted)
@@ -124,6 +173,10 @@ extern "C" int probe_launch(int form, const float* seed, const float4* dets, int
     if (form == 0) hipLaunchKernelGGL(probe_kernel<0>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
     else if (form == 1) hipLaunchKernelGGL(probe_kernel<1>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
     else if (form == 2) hipLaunchKernelGGL(probe_kernel<2>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
-    else hipLaunchKernelGGL(probe_kernel<3>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
+    else if (form == 3) hipLaunchKernelGGL(probe_kernel<3>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
+    else if (form == 4) hipLaunchKernelGGL(probe_kernel<4>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
+    else if (form == 5) hipLaunchKernelGGL(probe_kernel<5>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
+    else if (form == 6) hipLaunchKernelGGL(probe_kernel<6>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
+    else hipLaunchKernelGGL(probe_kernel<7>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
     return (int)hipGetLastError();
 }

@@ -96,16 +96,16 @@ NEIGHBOURS = [
     ("elementwise sin over 64 M floats", lambda s: torch.sin(big), 12),
 ]
 
-FORMS = ("compare", "arithmetic", "vcc", "branches")
+FORMS = ("compare", "arithmetic", "vcc", "branches", "asm+0nop", "asm+5nop", "asm+16nop", "asm vcc interleaved")
 with torch.cuda.stream(s0):
-    refs = [probe(f) for f in range(4)]
+    refs = [probe(f) for f in range(len(FORMS))]
 torch.cuda.synchronize()
 print("alone: forms agree with the compare form: %s (%d words, fraction of set bytes %.3f)"
       % ([int((r != refs[0]).sum()) for r in refs], refs[0].numel(), float((refs[0] & 1).float().mean())))
 for it in range(2):
     for name, fn, reps in NEIGHBOURS:
         wrong = []
-        for f in range(4):
+        for f in range(len(FORMS)):
             torch.cuda.synchronize()
             if fn is not None:
                 with torch.cuda.stream(s1):
@@ -116,4 +116,4 @@ for it in range(2):
             torch.cuda.synchronize()
             wrong.append(int((got != refs[f]).sum()))
             del got
-        print("run %d beside %-36s wrong words: %s" % (it, name, "  ".join("%s %7d" % (FORMS[f], wrong[f]) for f in range(4))), flush=True)
+        print("run %d beside %-36s wrong words: %s" % (it, name, "  ".join("%s %7d" % (FORMS[f], wrong[f]) for f in range(len(FORMS)))), flush=True)
