@@ -459,6 +459,17 @@ def main():
                                                   "recorded in THIS region, where kernels do not overlap.  `value` keeps "
                                                   "batches_in_flight whole batches enqueued on alternating HIP streams"),
                     roofline=roofline)
+        # whole-step utilisation over the time behind `value` (kernels of the batches in flight overlap: per-kernel figures above
+        # come from the one-at-a-time region, these from the step time itself)
+        step_s = elapsed / args.steps
+        line["roofline"]["step"] = dict(
+            ms=round(step_s * 1e3, 3), batches_in_flight=args.in_flight,
+            executed_tflops=round(total_exec / step_s / 1e12, 2), executed_frac=round(total_exec / step_s / 1e12 / peak_tf, 4),
+            hbm_algorithmic_gbs=round(total_bytes / step_s / 1e9, 1), hbm_algorithmic_frac=round(total_bytes / step_s / 1e9 / PEAK_HBM_GBS, 4),
+            hbm_pmc_gbs=round(conv_stack["bytes_per_step"] / step_s / 1e9, 1) if conv_stack else None,
+            hbm_pmc_frac=round(conv_stack["bytes_per_step"] / step_s / 1e9 / PEAK_HBM_GBS, 4) if conv_stack else None,
+            note="forward flops the matrix pipe executed / algorithmic forward bytes / PMC conv-stack bytes, each per step, over the "
+                 "step time of the timed region behind `value` (forward + postprocess, batches_in_flight batches overlapping)")
         if not args.no_extras:
             line["extras"] = measure_neighbours(dev, dets, B)
         if world == 1 and not args.no_cpu_baseline:
