@@ -13,12 +13,19 @@ for row in csv.DictReader(open(P("rocprofv3_kernel_stats.csv"))):
         tot += float(row["TotalDurationNs"]); n += int(row["Calls"])
 rp = round(tot / n / 1e6, 3)
 sw = c["thread_sweep_forward_bs1_ms"]
+step_row = ""
+if "step" in r and "step" in h["roofline"]:
+    a, b = r["step"], h["roofline"]["step"]
+    step_row = ("| whole step (`roofline.step`, over the step time behind `value`) | fp32: %s TF executed = %s of the matrix peak, PMC "
+                "conv-stack bytes %s GB/s = %s of 8 TB/s (algorithmic %s); fp16: %s TF = %s of 2.5 PF, PMC %s GB/s = %s of 8 TB/s "
+                "(algorithmic %s) |\n" % (a["executed_tflops"], a["executed_frac"], a["hbm_pmc_gbs"], a["hbm_pmc_frac"], a["hbm_algorithmic_frac"],
+                                          b["executed_tflops"], b["executed_frac"], b["hbm_pmc_gbs"], b["hbm_pmc_frac"], b["hbm_algorithmic_frac"]))
 rows = '''| end-to-end, two batches in flight (`value`) | **%s images/s** (%s ms/step); round 1: 990. Sparse heads (`--heads sparse`, ~25 detections per image, `%s_bench_sparse_heads.json`): %s |
 | end-to-end, one batch at a time (`one_batch_in_flight`) | %s images/s (%s ms/step; forward kernels %s ms, postprocess kernels %s ms) |
 | `roofline` (what the hardware did) | dominant kernel `%s`, %d launches/step incl. their input-transform pre-pass: **%s TFLOP/s executed = %s of the 157.3 TF f32-MFMA peak**; without the pre-pass %s TF (%s); the direct-convolution ("algorithmic") rate of the same layers is %s TF and is reported as `achieved_algorithmic`, no longer as `frac` (round 1 printed 1.66). Avg launch %s ms (HIP events in the timed one-at-a-time region) vs %s ms (rocprofv3, all variants weighted) |
 | algorithmic bytes per launch / PMC traffic | %.2f GB algorithmic (layer-fused model, §3) vs %s GB measured per launch (GEMM + pre-pass; `(2·FETCH_SIZE + WRITE_SIZE)·1024`, separate `--pmc` passes): the transformed input V (3× the activation) is written once and re-fetched once per 64-channel N tile. `traffic` is printed only when `profiles/%s_pmc_traffic.json` was measured with the library binary that is running (sha256 in `_meta`), else null |
 | conv stack HBM (north_star: "rocprof-reported HBM GB/s for the conv stack") | `roofline.conv_stack_hbm_pmc`: %s GB per step over %s ms of convolution kernels = **%s GB/s = %s of 8 TB/s** by PMC; algorithmic (layer-fused) %s GB/s = %s — the fp32 forward is FLOP-bound (forward overall %s TF executed = %s of the matrix peak) |
-| postprocess occupancy (north_star: "occupancy for NMS/mask-assembly") | §3.2 last bullet; `roofline.postprocess_occupancy` in the bench line |
+%s| postprocess occupancy (north_star: "occupancy for NMS/mask-assembly") | §3.2 last bullet; `roofline.postprocess_occupancy` in the bench line |
 | cpu_baseline (oracle, GPU box's host, 256 hardware threads) | thread sweep on one image (forward): 8 → %.0f ms, 16 → %.0f ms, 32 → %.0f ms, 64 → %.0f ms (256 threads took 69.7 s: the sweep is capped at 64); best: %s images/s end to end on %s threads; bs=1 forward %s ms, postprocess %s ms (the oracle's decode runs single-threaded for reproducibility, §3.2); reported baseline, not a target |
 | fp16 configuration (`--dtype f16`, `%s_bench_f16.json`) | %s images/s (bs=32) with two batches in flight, %s one at a time (kernels unchanged from round 1); now also tested at its own bs=64 |
 ''' % (d["value"], d["ms_per_step"], tag, sp["value"], d["one_batch_in_flight"]["value"], d["one_batch_in_flight"]["ms_per_step"],
@@ -26,7 +33,7 @@ rows = '''| end-to-end, two batches in flight (`value`) | **%s images/s** (%s ms
        r["achieved"], r["frac"], r["achieved_without_pre_pass"], round(r["achieved_without_pre_pass"] / r["peak"], 3),
        r["achieved_algorithmic"], r["avg_launch_ms"], rp, r["algorithmic_bytes_per_launch"] / 1e9, round(r["traffic"] / 1e9, 2) if r["traffic"] else "n/a", tag,
        round(st["bytes_per_step"] / 1e9, 1), st["kernels_ms_per_step"], st["gbs"], st["frac_of_8tbs"],
-       r["forward_hbm_algorithmic_gbs"], r["forward_hbm_frac"], r["forward_tflops_executed"], r["forward_executed_frac"],
+       r["forward_hbm_algorithmic_gbs"], r["forward_hbm_frac"], r["forward_tflops_executed"], r["forward_executed_frac"], step_row,
        sw["8"], sw["16"], sw["32"], sw["64"], c["value"], c["cores"], c["bs1"]["forward_ms"], c["bs1"]["postprocess_ms"],
        tag, h["value"], h["one_batch_in_flight"]["value"])
 path = os.path.join(REPO, "DESIGN.md")
