@@ -107,6 +107,10 @@ def load():
         raise OrienMaskHipError(
             "%s not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C orienmask_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    # torch first: its wheel bundles a HIP runtime, and the process must end up with ONE runtime -- the one whose streams and device
+    # pointers the callers hand to this library.  Loaded the other way round (this library before torch) the library binds to
+    # /opt/rocm's runtime, torch initialises its own, and every launch fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

@@ -697,6 +697,16 @@ def test_preprocess_feeds_the_model(dev):
         assert _rel_err(gb.cpu(), rb) < REL_TOL and _rel_err(go.cpu(), ro) < REL_TOL
 
 
+def test_library_loaded_before_torch_still_works(dev):
+    """A process that loads liborienmask_hip.so before it imports torch (as __graft_entry__.build() followed by smoke() does)
+    must end up with one HIP runtime: lib.load() imports torch first.  Runs in a fresh interpreter."""
+    import subprocess, sys
+    code = ("from orienmask_amd import lib; lib.load(); import __graft_entry__ as g; g.smoke(); print('ok')")
+    out = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
 def test_tester_and_infer_loops(dev):
     """The reference's two callers on the HIP path: Tester.test (tester.py:26-62) and the infer.py loop."""
     from orienmask_amd.tester import SyntheticLoader, Tester, infer_loop
