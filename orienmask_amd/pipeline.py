@@ -6,7 +6,8 @@ layer n+1 needs all of layer n.  A second batch has no such dependency: with two
 hardware places the other batch's workgroups on the compute units a draining launch frees.  Per-kernel efficiency is
 unchanged (whole batches, unlike model.set_streams' sub-batches); each batch in flight owns a forward workspace
 (model.workspace_slot) and a postprocess workspace.  Measured on MI355X at 32 x 544 x 544, forward only
-(tools/pipelined_steps.py): fp32 29.6 -> 27.4 ms per batch, fp16 9.5 -> 8.4 ms; a third batch adds nothing.
+(tools/pipelined_steps.py): fp32 29.6 -> 27.4 ms per batch, fp16 9.5 -> 8.4 ms.  End to end (bench.py) a third batch in flight
+changes nothing in fp32 and adds 2.5 % in fp16, whose steps are a third as long; a fourth costs 3 %.
 
 The reference runs one batch at a time (/root/reference/infer.py:92-110, /root/reference/eval/evaluator.py: one
 `model(image)` + `postprocess(predict)` per loader iteration, synchronising on `.cpu()` each time); its loop
