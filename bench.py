@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--lib", default=None,
                     help="path of another build of liborienmask_hip.so to load instead of the in-tree one (A/B runs of two "
                          "builds on the same GPU box: tools/ab_bench.sh)")
-    ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
+    ap.add_argument("--dtype", choices=("f32", "f32_split", "f16"), default="f32",
                     help="f32: the parity path and the headline metric (default).  f16: BASELINE configs[4], fp16 "
                          "activations and weights with fp32 accumulation -- a separate, clearly labelled line")
     args = ap.parse_args()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define OM_VERSION 120          /* 0.1.2: om_post_cfg.nms_semantics / nms_normalized, om_nms_ex, om_ref_math */
+#define OM_VERSION 130          /* 0.1.3: split-operand precision mode (om_layer_info.wsplit_off, om_model_set_precision, ...) */
 
 #define OM_OK 0
 #define OM_EINVAL (-1)          /* bad argument (null pointer, shape not supported) */
@@ -61,6 +61,13 @@ typedef struct om_layer_info {
                                    the batch is too small for the 2 x 4 tiling to fill the chip; -1 otherwise */
     int64_t w16_off;            /* fp16 path: offset IN HALFS into the fp16 weight blob (om_model_load_weights_f16):
                                    [cout_pad][ksize*ksize][cin] fp16 (rows >= cout zero); -1: the stem (always fp32) */
+    int64_t wsplit_off;         /* split-operand mode (om_model_set_precision(m, 1)): offset in 4-BYTE WORDS into the split blob
+                                   (om_model_load_weights_split) of the F(2x4,3x3) weights as hi/lo fp16 pairs,
+                                   [24][cout_pad][cin / 16][2][16] halfs: per row and group of 16 input channels the 16 hi
+                                   halfs, then the 16 lo halfs of  U * 2^e[cout]  (hi = fp16(x), lo = fp16(x - hi));
+                                   -1: the layer has no F(2x4) form */
+    int64_t wsplit_scale_off;   /* offset in 4-byte words into the split blob of [cout_pad] floats scale * 2^-e[cout] (the
+                                   power of two is exact, so the epilogue rounds as with the unscaled weights) */
 } om_layer_info;
 
 /* Constants of OrienMaskYOLOPostProcess.__init__ (eval/orienmask_yolo_postprocess.py:9-37). */
@@ -104,6 +111,20 @@ size_t om_model_weight_floats(const om_model* m);
 /* packed_dev: device pointer to the blob described by om_model_layer_info; it must stay alive
  * (and unchanged) for as long as om_forward is called.  dtype: 0 = float32. */
 int om_model_load_weights(om_model* m, const void* packed_dev, size_t bytes, int dtype);
+
+/* ---- precision of om_forward's F(2x4,3x3) Winograd GEMMs (no counterpart in the reference, whose convolutions are
+ * whatever cuDNN / MKLDNN run) ------------------------------------------------------------------------------------------
+ * 0 (default): operands fp32 on v_mfma_f32_32x32x2_f32 (products exact, fp32 accumulate).
+ * 1: SPLIT operands.  Every fp32 operand x is carried as hi = fp16(x), lo = fp16(x - hi) and a product is
+ *    hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (the lo*lo term, <= 2^-22 of the product, is
+ *    dropped): 5.3x the matrix rate at the same bytes per element.  Representation error <= 2^-22 |x| (floor 2^-25
+ *    absolute), i.e. ~4x an fp32 rounding; measured end to end in DESIGN.md 3.6.  Transformed inputs must stay below
+ *    65504 in magnitude (activations below ~3000); weights are pre-scaled per output channel by the packer.
+ *    Needs om_model_load_weights_split; activations between layers stay fp32, every other layer is unchanged. */
+size_t om_model_weight_split_words(const om_model* m);
+int om_model_load_weights_split(om_model* m, const void* packed_split_dev, size_t bytes);
+int om_model_set_precision(om_model* m, int mode);
+int om_model_get_precision(const om_model* m);
 
 size_t om_forward_workspace_bytes(const om_model* m, int B, int H, int W);
 /* x: [B,3,H,W] float32 NCHW, H and W multiples of 32.
@@ -194,6 +215,12 @@ int om_conv2d_winograd24(const float* in, int B, int H, int W, int cin, int in_p
                          const float* scale, const float* shift, int cout, int leaky, const float* res,
                          int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
                          om_stream stream);
+/* ... with split operands (om_model_set_precision mode 1): u_split as om_layer_info.wsplit_off describes, scale_split =
+ * scale * 2^-e per output channel; scratch as for om_conv2d_winograd24. */
+int om_conv2d_winograd24_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* u_split,
+                               const float* scale_split, const float* shift, int cout, int leaky, const float* res,
+                               int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
+                               om_stream stream);
 /* first layer: in [B,3,H,W] NCHW -> out [B,H,W,cout] NHWC, 3x3 stride 1. */
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale,
                    const float* shift, int cout, float* out, om_stream stream);

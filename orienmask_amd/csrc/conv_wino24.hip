@@ -25,11 +25,44 @@ namespace om {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// SPLIT operands (precision mode "f32_split"): every fp32 operand x of the 24 GEMMs is carried as two fp16
+// numbers hi = fp16(x), lo = fp16(x - hi) (x = hi + lo to ~2^-22 |x|, absolute floor 2^-25), and a product is
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation: three matrix instructions of 32 cycles for
+// 16 channels instead of eight v_mfma_f32_32x32x2_f32 of 64 cycles -- 5.3x the matrix rate of the f32-input pipe at the
+// same bytes per operand element (4).  A row of 32 channels (one k-step, 128 bytes) is laid out as two groups of
+// [16 hi | 16 lo] halfs, so that 16-byte chunk 2 q + fk of the row is exactly the 8-half MFMA operand of lane half fk for
+// q = 0: hi of channels 0-15, 1: lo of 0-15, 2: hi of 16-31, 3: lo of 16-31 -- the LDS image, the LDS-DMA pieces and the
+// swizzle are those of the fp32 kernel.
+template <bool SPLIT>
+__device__ __forceinline__ void wino24_store_v(float* row, int c4, f32x4 v) {
+    if constexpr (!SPLIT) {
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(row + c4 * 4));
+    } else {
+        const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        const f16x4 l = {(_Float16)(v[0] - (float)h[0]), (_Float16)(v[1] - (float)h[1]), (_Float16)(v[2] - (float)h[2]),
+                         (_Float16)(v[3] - (float)h[3])};
+        const u32x2 hw = __builtin_bit_cast(u32x2, h), lw = __builtin_bit_cast(u32x2, l);
+        // lanes 2k / 2k+1 hold channels 8k'..8k'+3 / +4..+7 of the same tile: the even lane stores the 8 hi halfs, the odd
+        // lane the 8 lo halfs, 16 bytes each
+        const bool odd = c4 & 1;
+        const u32x2 send = odd ? hw : lw;
+        const u32x2 recv = {(unsigned)__shfl_xor((int)send[0], 1), (unsigned)__shfl_xor((int)send[1], 1)};
+        const u32x4 st = odd ? u32x4{recv[0], recv[1], lw[0], lw[1]} : u32x4{hw[0], hw[1], recv[0], recv[1]};
+        float* dst = row + (c4 >> 2) * 16 + (odd ? 8 + ((c4 - 1) & 3) * 2 : (c4 & 3) * 2);
+        __builtin_nontemporal_store(st, reinterpret_cast<u32x4*>(dst));
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // input transform: rows B_y^T = F(2,3), columns B_x^T = F(4,3) with points {0, +-1, +-2}
 // ------------------------------------------------------------------------------------------------
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void wino24_input_kernel(const float* __restrict__ in, float* __restrict__ V, int H,
                                                            int W, int C, int pix_stride, int TH, int TW, int T) {
     const int c4n = C >> 2;
@@ -42,7 +75,7 @@ __global__ __launch_bounds__(256) void wino24_input_kernel(const float* __restri
     const int ty = r / TW, tx = r - ty * TW;
     const float* base = in + (size_t)b * H * W * pix_stride + c4 * 4;
     const size_t plane = (size_t)T * C;
-    float* o = V + (size_t)tile * C + c4 * 4;
+    float* o = V + (size_t)tile * C;        // this tile's row of C four-byte words in plane 0
     f32x4 d[4][6];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -68,12 +101,12 @@ __global__ __launch_bounds__(256) void wino24_input_kernel(const float* __restri
         const f32x4 a12 = t[1] + t[2], s12 = t[1] - t[2];           // shared sub-expressions
         const f32x4 a34 = t[3] + t[4], s34 = t[4] - t[3];
         float* op = o + (size_t)(i * 6) * plane;
-        __builtin_nontemporal_store((f32x4)(4.f * t[0] - 5.f * t[2] + t[4]), reinterpret_cast<f32x4*>(op + 0 * plane));
-        __builtin_nontemporal_store((f32x4)(a34 - 4.f * a12), reinterpret_cast<f32x4*>(op + 1 * plane));
-        __builtin_nontemporal_store((f32x4)(4.f * s12 + s34), reinterpret_cast<f32x4*>(op + 2 * plane));
-        __builtin_nontemporal_store((f32x4)((t[4] - t[2]) + 2.f * (t[3] - t[1])), reinterpret_cast<f32x4*>(op + 3 * plane));
-        __builtin_nontemporal_store((f32x4)((t[4] - t[2]) - 2.f * (t[3] - t[1])), reinterpret_cast<f32x4*>(op + 4 * plane));
-        __builtin_nontemporal_store((f32x4)(4.f * t[1] - 5.f * t[3] + t[5]), reinterpret_cast<f32x4*>(op + 5 * plane));
+        wino24_store_v<SPLIT>(op + 0 * plane, c4, 4.f * t[0] - 5.f * t[2] + t[4]);
+        wino24_store_v<SPLIT>(op + 1 * plane, c4, a34 - 4.f * a12);
+        wino24_store_v<SPLIT>(op + 2 * plane, c4, 4.f * s12 + s34);
+        wino24_store_v<SPLIT>(op + 3 * plane, c4, (t[4] - t[2]) + 2.f * (t[3] - t[1]));
+        wino24_store_v<SPLIT>(op + 4 * plane, c4, (t[4] - t[2]) - 2.f * (t[3] - t[1]));
+        wino24_store_v<SPLIT>(op + 5 * plane, c4, 4.f * t[1] - 5.f * t[3] + t[5]);
     }
 }
 
@@ -112,7 +145,7 @@ struct Wino24Params {
 //      not depend on where a tile was cut (bit-identical to SK = false, batch-size invariant).
 // Slot numbers are drawn from the ticket word in start order, so a finisher never waits for a workgroup that has not started
 // (placement- and dispatch-order independent).  Needs tiles >= slots (a tile is cut at most once).
-template <bool SK>
+template <bool SK, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params p) {
     constexpr int BM = 64, BN = 64, WM = 32, WN = 32;
     constexpr int NWN = BN / WN;
@@ -258,10 +291,38 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
         read_frags(ca, cb, 0, 0);
         int xi = xb, cc = 0;
         int buf = 0;
+        f32x4 ca1, cb1;                                      // SPLIT: lo halves of channels 0-15 of the current step
+        if constexpr (SPLIT) read_frags(ca1, cb1, 0, 1);
         for (int s = 0; s < ksteps; ++s) {
             const int buf1 = buf == NBUF - 1 ? 0 : buf + 1;      // step s+1
             const int buf2 = buf1 == NBUF - 1 ? 0 : buf1 + 1;    // step s+2 (last read during step s-1)
             const bool live2 = s + 2 < ksteps;
+            if constexpr (SPLIT) {
+                // six matrix instructions per k-step: per group of 16 channels hi*lo + lo*hi + hi*hi (fp32 accumulate)
+                f32x4 a2, b2, a3, b3;
+                read_frags(a2, b2, buf, 2);
+                read_frags(a3, b3, buf, 3);
+#pragma unroll
+                for (int piece = 0; piece < NP; ++piece) issue_piece(piece, buf2, live2);
+                const f16x8 ah = __builtin_bit_cast(f16x8, ca), al = __builtin_bit_cast(f16x8, ca1);
+                const f16x8 bh = __builtin_bit_cast(f16x8, cb), bl = __builtin_bit_cast(f16x8, cb1);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const f16x8 ah2 = __builtin_bit_cast(f16x8, a2), al2 = __builtin_bit_cast(f16x8, a3);
+                const f16x8 bh2 = __builtin_bit_cast(f16x8, b2), bl2 = __builtin_bit_cast(f16x8, b3);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh2, al2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl2, ah2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh2, ah2, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // step s+1's operands have landed (only this step's NP pieces may still fly); my reads of `buf` are done
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NP) : "memory");
+                __builtin_amdgcn_s_barrier();
+                read_frags(ca, cb, buf1, 0);
+                read_frags(ca1, cb1, buf1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -281,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
                 }
                 ca = na;
                 cb = nb;
+            }
             }
             buf = buf1;
             advance();
@@ -428,6 +490,8 @@ size_t wino24_scratch_floats(int B, int H, int W, int C) {
 }
 
 // a.w must point at the transformed weights U [24][cout_pad][cin]; scratch holds V (wino24_scratch_floats).
+// a.split: U and V are hi/lo fp16 pairs in the [16 hi | 16 lo] row layout described at the top (same sizes); a.scale
+// then already carries the per-output-channel power of two that the packer multiplied U's rows with.
 int launch_conv_winograd24(const ConvArgs& a, float* scratch, hipStream_t stream) {
     OM_REQUIRE(a.in && a.w && a.scale && a.shift && a.out && scratch && a.ticket, OM_EINVAL, "winograd24: null pointer");
     OM_REQUIRE(a.ks == 3 && a.stride == 1 && a.out_mode == 0, OM_EINVAL, "winograd24: 3x3 stride-1 NHWC layers only");
@@ -440,8 +504,12 @@ int launch_conv_winograd24(const ConvArgs& a, float* scratch, hipStream_t stream
     const long long T = (long long)a.B * TH * TW;
     OM_REQUIRE(T < (1ll << 31) && 24 * T * a.cin < (1ll << 40), OM_EINVAL, "winograd24: problem too large");
     const long long threads = T * (a.cin / 4);
-    hipLaunchKernelGGL(wino24_input_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a.in, scratch, a.H,
-                       a.W, a.cin, a.in_pix_stride, TH, TW, (int)T);
+    if (a.split)
+        hipLaunchKernelGGL(wino24_input_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a.in,
+                           scratch, a.H, a.W, a.cin, a.in_pix_stride, TH, TW, (int)T);
+    else
+        hipLaunchKernelGGL(wino24_input_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a.in,
+                           scratch, a.H, a.W, a.cin, a.in_pix_stride, TH, TW, (int)T);
     OM_CHECK_HIP(hipGetLastError());
     if (a.mid_event) OM_CHECK_HIP(hipEventRecord(a.mid_event, stream));
     Wino24Params p;
@@ -463,10 +531,14 @@ int launch_conv_winograd24(const ConvArgs& a, float* scratch, hipStream_t stream
     // -9 %).  A static split is only as fast as the slowest workgroup -- dealt out statically, whole layers ran 2-4 % slower
     // than from the queue -- so from two tiles per slot on the two effects cancel (68 x 68: +-0, 136 x 136: +1-2 %), and a
     // hybrid (bulk from the queue, only the last round cut evenly) lost to both (profiles/r02_experiments.md).
-    if (a.sk_partial && total >= 512 && total < 2 * 512)
-        hipLaunchKernelGGL(wino24_gemm_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL(wino24_gemm_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, p);
+    const bool sk = a.sk_partial && total >= 512 && total < 2 * 512;
+    if (a.split) {
+        if (sk) hipLaunchKernelGGL((wino24_gemm_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((wino24_gemm_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    } else {
+        if (sk) hipLaunchKernelGGL((wino24_gemm_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((wino24_gemm_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    }
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }

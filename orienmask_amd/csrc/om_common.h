@@ -53,6 +53,7 @@ struct ConvArgs {
     int out_mode;           // 0: NHWC   1: NHWC, each output replicated up x up (nearest upsample)
                             // 2: NCHW contiguous [B,cout,Ho,Wo]
     int up;
+    int split = 0;          // Winograd F(2x4) only: operands as hi/lo fp16 pairs (conv_wino24.hip)
 };
 
 constexpr int SK_SLOTS = 1024;                          // most resident workgroups of a stream-K launch (4 per CU)

@@ -66,6 +66,9 @@ struct om_model {
     const float* weights = nullptr;
     size_t weight_halfs = 0;             // fp16 copy of the convolution weights (om_model_load_weights_f16)
     const _Float16* weights16 = nullptr;
+    size_t split_words = 0;              // hi/lo fp16 pairs of the F(2x4) weights + their scales (om_model_load_weights_split)
+    const float* weights_split = nullptr;
+    int precision = 0;                   // 0: fp32 operands, 1: split operands in the F(2x4) GEMMs
     // optional per-layer timing with HIP events on the launch stream (om_profile_*)
     bool profiling = false;
     std::vector<unsigned char> prof_mask;    // empty: every layer; else 1 = record events for this layer
@@ -110,6 +113,13 @@ struct om_model {
                 L.info.wino_alt_off = (int64_t)weight_floats;
                 weight_floats += (size_t)16 * L.info.cout_pad * cin;
             }
+        }
+        L.info.wsplit_off = L.info.wsplit_scale_off = -1;
+        if (L.info.wino_planes == 24) {
+            L.info.wsplit_off = (int64_t)split_words;
+            split_words += (size_t)24 * L.info.cout_pad * cin;
+            L.info.wsplit_scale_off = (int64_t)split_words;
+            split_words = om::align_up(split_words + L.info.cout_pad, 4);
         }
         L.info.w16_off = -1;
         if (!stem) {
@@ -346,6 +356,27 @@ int om_model_load_weights(om_model* m, const void* packed_dev, size_t bytes, int
     return OM_OK;
 }
 
+size_t om_model_weight_split_words(const om_model* m) { return m ? m->split_words : 0; }
+
+int om_model_load_weights_split(om_model* m, const void* packed_split_dev, size_t bytes) {
+    OM_REQUIRE(m && packed_split_dev, OM_EINVAL, "om_model_load_weights_split: null argument");
+    OM_REQUIRE(bytes == m->split_words * 4, OM_EINVAL, "om_model_load_weights_split: blob is %zu bytes, the graph needs %zu",
+               bytes, m->split_words * 4);
+    OM_REQUIRE((reinterpret_cast<uintptr_t>(packed_split_dev) & 15) == 0, OM_EINVAL,
+               "om_model_load_weights_split: blob not 16-byte aligned");
+    m->weights_split = static_cast<const float*>(packed_split_dev);
+    return OM_OK;
+}
+
+int om_model_set_precision(om_model* m, int mode) {
+    OM_REQUIRE(m, OM_EINVAL, "om_model_set_precision: null model");
+    OM_REQUIRE(mode == 0 || mode == 1, OM_EINVAL, "om_model_set_precision: mode %d (0 = fp32 operands, 1 = split operands)", mode);
+    m->precision = mode;
+    return OM_OK;
+}
+
+int om_model_get_precision(const om_model* m) { return m ? m->precision : OM_EINVAL; }
+
 static size_t forward_workspace_bytes(const om_model* m, int B, int H, int W, bool f16) {
     if (!m || B <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32) return 0;
     return m->layout(B, H, W, f16).total;
@@ -359,6 +390,8 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
     OM_REQUIRE(m && x && bbox32 && bbox16 && bbox8 && oriens && workspace, OM_EINVAL, "om_forward: null argument");
     OM_REQUIRE(m->weights, OM_ESTATE, "om_forward: call om_model_load_weights first");
     OM_REQUIRE(!f16 || m->weights16, OM_ESTATE, "om_forward_f16: call om_model_load_weights_f16 first");
+    OM_REQUIRE(f16 || m->precision == 0 || m->weights_split, OM_ESTATE,
+               "om_forward: precision mode 1 needs om_model_load_weights_split first");
     OM_REQUIRE(B > 0 && H > 0 && W > 0 && H % 32 == 0 && W % 32 == 0, OM_EINVAL,
                "om_forward: B=%d H=%d W=%d (H and W must be positive multiples of 32)", B, H, W);
     const size_t need = forward_workspace_bytes(m, B, H, W, f16);
@@ -450,6 +483,11 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
                 a.mid_event = ev_mid;
                 if (li.wino_planes == 24 && om_model::use_f24(B, H, W)) {
                     a.w = m->weights + li.wino_off;
+                    if (m->precision == 1) {
+                        a.w = m->weights_split + li.wsplit_off;
+                        a.scale = m->weights_split + li.wsplit_scale_off;
+                        a.split = 1;
+                    }
                     rc = om::launch_conv_winograd24(a, wino_scratch, stream);
                 } else {
                     a.w = m->weights + (li.wino_planes == 24 ? li.wino_alt_off : li.wino_off);
@@ -541,7 +579,7 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
     const om::LayerDef& L = m->layers[index];
     if (L.stem) { *bm = 0; *bn = 0; *algo = 0; return OM_OK; }
     if (L.info.wino_off >= 0 && om::wino_enabled() && L.info.wino_planes == 24 && om_model::use_f24(B, H, W)) {
-        *algo = 5; *bm = 64; *bn = 64;
+        *algo = m->precision == 1 ? 6 : 5; *bm = 64; *bn = 64;
         return OM_OK;
     }
     if (L.info.wino_off >= 0 && om::wino_enabled()) {
@@ -681,6 +719,11 @@ int om_conv2d_stem_f16(const float* in, int B, int H, int W, const float* w, con
     return om::launch_conv_stem_f16(in, B, H, W, w, scale, shift, cout, out, static_cast<hipStream_t>(stream));
 }
 
+static int conv2d_winograd24_impl(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* u,
+                                  const float* scale, const float* shift, int cout, int leaky, const float* res,
+                                  int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
+                                  om_stream stream, int split);
+
 size_t om_conv2d_winograd24_scratch_bytes(int B, int H, int W, int cin) {
     if (B <= 0 || H <= 0 || W <= 0 || cin <= 0) return 0;
     return om::align_up(om::wino24_scratch_floats(B, H, W, cin) * sizeof(float), 256) + om::SK_PARTIAL_BYTES;
@@ -690,6 +733,14 @@ int om_conv2d_winograd24(const float* in, int B, int H, int W, int cin, int in_p
                          const float* scale, const float* shift, int cout, int leaky, const float* res,
                          int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
                          om_stream stream) {
+    return conv2d_winograd24_impl(in, B, H, W, cin, in_pix_stride, u, scale, shift, cout, leaky, res, res_pix_stride, out,
+                                  out_pix_stride, scratch, scratch_bytes, stream, 0);
+}
+
+static int conv2d_winograd24_impl(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* u,
+                                  const float* scale, const float* shift, int cout, int leaky, const float* res,
+                                  int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
+                                  om_stream stream, int split) {
     OM_REQUIRE(B > 0 && H > 0 && W > 0, OM_EINVAL, "om_conv2d_winograd24: bad shape");
     OM_REQUIRE(scratch && scratch_bytes >= om_conv2d_winograd24_scratch_bytes(B, H, W, cin), OM_ENOMEM,
                "om_conv2d_winograd24: scratch too small");
@@ -698,13 +749,21 @@ int om_conv2d_winograd24(const float* in, int B, int H, int W, int cin, int in_p
     a.B = B; a.H = H; a.W = W; a.cin = cin; a.in_pix_stride = in_pix_stride;
     a.Ho = H; a.Wo = W; a.cout = cout; a.cout_pad = om::round_up(cout, 64);
     a.ks = 3; a.stride = 1; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
-    a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1;
+    a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1; a.split = split;
     static int* g_ticket = nullptr;
     if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), om::SYNC_WORDS * sizeof(int)));
     if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;
     a.ticket = g_ticket;
     a.sk_partial = reinterpret_cast<float*>(static_cast<char*>(scratch) + om::align_up(om::wino24_scratch_floats(B, H, W, cin) * sizeof(float), 256));
     return om::launch_conv_winograd24(a, static_cast<float*>(scratch), static_cast<hipStream_t>(stream));
+}
+
+int om_conv2d_winograd24_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* u_split,
+                               const float* scale_split, const float* shift, int cout, int leaky, const float* res,
+                               int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
+                               om_stream stream) {
+    return conv2d_winograd24_impl(in, B, H, W, cin, in_pix_stride, static_cast<const float*>(u_split), scale_split, shift, cout,
+                                  leaky, res, res_pix_stride, out, out_pix_stride, scratch, scratch_bytes, stream, 1);
 }
 
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale, const float* shift,

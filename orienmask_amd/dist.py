@@ -54,6 +54,10 @@ def broadcast_packed_weights(net, device, src=0):
         n16 = _lib.load().om_model_weight_halfs(h)
         b16 = _pack.pack_state_dict_f16(net.state_dict(), net._layers, n16) if rank == src else None
         net.bind_packed_f16(broadcast_blob(b16, n16, device, src, dtype=torch.float16))
+    if getattr(net, "precision", "f32") == "f32_split":     # split-operand mode: the hi/lo fp16 pairs of the F(2x4) weights
+        ns = _lib.load().om_model_weight_split_words(h)
+        bs = _pack.pack_state_dict_split(net.state_dict(), net._layers, ns, blob.cpu()) if rank == src else None
+        net.bind_packed_split(broadcast_blob(bs, ns, device, src))
     return blob
 
 

@@ -19,7 +19,8 @@ class LayerInfo(ctypes.Structure):
                 ("ksize", ctypes.c_int32), ("stride", ctypes.c_int32),
                 ("has_bn", ctypes.c_int32), ("leaky", ctypes.c_int32), ("wino_planes", ctypes.c_int32),
                 ("w_off", ctypes.c_int64), ("scale_off", ctypes.c_int64), ("shift_off", ctypes.c_int64),
-                ("wino_off", ctypes.c_int64), ("wino_alt_off", ctypes.c_int64), ("w16_off", ctypes.c_int64)]
+                ("wino_off", ctypes.c_int64), ("wino_alt_off", ctypes.c_int64), ("w16_off", ctypes.c_int64),
+                ("wsplit_off", ctypes.c_int64), ("wsplit_scale_off", ctypes.c_int64)]
 
 
 class PostCfg(ctypes.Structure):
@@ -50,6 +51,11 @@ SIGNATURES = {
     "om_model_layer_info": (_i, [_vp, _i, ctypes.POINTER(LayerInfo)]),
     "om_model_weight_floats": (_sz, [_vp]),
     "om_model_load_weights": (_i, [_vp, _vp, _sz, _i]),
+    "om_model_weight_split_words": (_sz, [_vp]),
+    "om_model_load_weights_split": (_i, [_vp, _vp, _sz]),
+    "om_model_set_precision": (_i, [_vp, _i]),
+    "om_model_get_precision": (_i, [_vp]),
+    "om_conv2d_winograd24_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "om_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "om_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "om_layer_tile": (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),

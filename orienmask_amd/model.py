@@ -80,6 +80,7 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         self._layers = None
         self._packed = None          # device blob currently bound to the handle
         self._packed16 = None        # fp16 convolution weights (precision == "f16")
+        self._packed_split = None    # hi/lo fp16 pairs of the F(2x4) weights (precision == "f32_split")
         self.precision = "f32"
         self.n_streams = 1           # set_streams(): sub-batches on side HIP streams
         self._side_streams = {}
@@ -130,6 +131,7 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         """Call after mutating parameters in place; load_state_dict/.to() do it themselves."""
         self._packed = None
         self._packed16 = None
+        self._packed_split = None
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
@@ -153,12 +155,30 @@ class OrienMaskYOLOFPNPlus(nn.Module):
 
     # ------------------------------------------------------------------ fp16-activation configuration
     def set_precision(self, precision):
-        """'f32' (default; the parity path) or 'f16': fp16 activations and convolution weights, fp32 accumulation,
-        fp32 head tensors (BASELINE.json configs[4]; include/orienmask_hip.h: om_forward_f16)."""
-        if precision not in ("f32", "f16"):
-            raise ValueError("precision must be 'f32' or 'f16', got %r" % (precision,))
+        """'f32' (default; the parity path), 'f32_split' (fp32 tensors everywhere; the F(2x4) Winograd GEMMs carry each fp32
+        operand as a hi/lo fp16 pair and multiply on the fp16 matrix pipe with fp32 accumulation -- include/orienmask_hip.h:
+        om_model_set_precision) or 'f16': fp16 activations and convolution weights, fp32 accumulation, fp32 head tensors
+        (BASELINE.json configs[4]; include/orienmask_hip.h: om_forward_f16)."""
+        if precision not in ("f32", "f32_split", "f16"):
+            raise ValueError("precision must be 'f32', 'f32_split' or 'f16', got %r" % (precision,))
         self.precision = precision
         return self
+
+    def packed_weights_split(self, device):
+        h = self._ensure_handle()
+        if self._packed_split is None or self._packed_split.device != device:
+            total = _lib.load().om_model_weight_split_words(h)
+            self.bind_packed_split(_pack.pack_state_dict_split(self.state_dict(), self._layers, total,
+                                                               self.packed_weights(device).cpu()).to(device))
+        return self._packed_split
+
+    def bind_packed_split(self, blob):
+        h = self._ensure_handle()
+        _lib.require_cuda_tensor(blob, "packed split weights", torch.float32)
+        with torch.cuda.device(blob.device):
+            _lib.check(_lib.load().om_model_load_weights_split(h, ctypes.c_void_p(blob.data_ptr()), blob.numel() * 4),
+                       "om_model_load_weights_split")
+        self._packed_split = blob
 
     def set_streams(self, n):
         """Run forward() as n independent sub-batches on n side HIP streams (batch divisible by n, else one launch).
@@ -225,6 +245,10 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         if f16:
             self.packed_weights_f16(dev)
         h = self._handle
+        split = self.precision == "f32_split"
+        if split:
+            self.packed_weights_split(dev)
+        _lib.check(L.om_model_set_precision(h, 1 if split else 0), "om_model_set_precision")
         # sub-batches: n_streams > 1 runs B / n_streams images on each of n side streams (own workspace each) and joins
         # them on the caller's stream; images are independent, so the results are bit-identical to one launch
         n_sub = self.n_streams if (self.n_streams > 1 and B % self.n_streams == 0) else 1
@@ -318,12 +342,13 @@ class OrienMaskYOLOFPNPlus(nn.Module):
                 fmt = {0: "conv_stem_kernel<f16>", 1: "conv_igemm_f16_kernel<%d,%d>", 4: "conv3x3_f16_kernel<%d,%d>"}[algo.value]
                 out.append((l["name"], fmt % (bm.value, bn.value) if algo.value else fmt))
             return out
+        _lib.check(_lib.load().om_model_set_precision(h, 1 if self.precision == "f32_split" else 0), "om_model_set_precision")
         for i, l in enumerate(self._layers):
             bm, bn, algo = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
             _lib.check(_lib.load().om_layer_tile(h, i, B, H, W, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(algo)),
                        "om_layer_tile")
             fmt = {0: "conv_stem_kernel", 1: "conv_igemm_f32_kernel<%d,%d>", 2: "wino_gemm_kernel<%d,%d>",
-                   3: "wino_fused_kernel<%d,%d>", 5: "wino24_gemm_kernel<%d,%d>"}[algo.value]
+                   3: "wino_fused_kernel<%d,%d>", 5: "wino24_gemm_kernel<%d,%d>", 6: "wino24_gemm_kernel<%d,%d,split>"}[algo.value]
             out.append((l["name"], fmt % ((bm.value, bn.value) if algo.value else ())))
         return out
 

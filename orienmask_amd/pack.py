@@ -30,7 +30,7 @@ def graph_layers(handle):
                         ksize=info.ksize, stride=info.stride, has_bn=bool(info.has_bn), leaky=bool(info.leaky),
                         w_off=info.w_off, scale_off=info.scale_off, shift_off=info.shift_off,
                         wino_off=info.wino_off, wino_planes=info.wino_planes, wino_alt_off=info.wino_alt_off,
-                        w16_off=info.w16_off))
+                        w16_off=info.w16_off, wsplit_off=info.wsplit_off, wsplit_scale_off=info.wsplit_scale_off))
     return out
 
 
@@ -124,4 +124,46 @@ def pack_state_dict_f16(state_dict, layers, total_halfs):
         w = sd[l["name"] + (".conv_block.0.weight" if l["has_bn"] else ".weight")]
         rows = conv_weights_f16(w, l["cout_pad"]).reshape(-1)
         blob[l["w16_off"]:l["w16_off"] + rows.numel()] = rows
+    return blob
+
+
+def split_f16_pairs(x):
+    """float32 tensor [..., C] (C % 16 == 0) -> float16 tensor [..., C / 16, 2, 16]: per group of 16 channels the 16 hi halfs
+    fp16(x), then the 16 lo halfs fp16(x - hi) -- the operand row layout of the split-operand Winograd GEMM
+    (orienmask_amd/csrc/conv_wino24.hip, include/orienmask_hip.h: om_layer_info.wsplit_off)."""
+    x = x.float()
+    hi = x.half()
+    lo = (x - hi.float()).half()
+    lead = x.shape[:-1]
+    g = x.shape[-1] // 16
+    return torch.stack((hi.reshape(*lead, g, 16), lo.reshape(*lead, g, 16)), dim=-2).contiguous()
+
+
+def winograd_weights_split(w, cout_pad):
+    """[cout,cin,3,3] -> (fp16 [24][cout_pad][cin/16][2][16], exponents int32 [cout_pad]): the F(2x4,3x3) weights
+    U * 2^e[cout] as hi/lo fp16 pairs.  e[cout] puts the largest |U| of the output channel into [2^13, 2^14): every element
+    down to 2^-17 of it keeps ~22 significant bits, and fp16's 65504 is never reached; the epilogue's scale carries 2^-e."""
+    u = winograd_weights(w, cout_pad, 24)                         # the fp32 U of the exact path
+    amax = u.abs().amax(dim=(0, 2))
+    e = torch.where(amax > 0, 13 - torch.floor(torch.log2(amax.double().clamp_min(1e-300))), torch.zeros_like(amax, dtype=torch.float64))
+    e = e.clamp(-100, 100)
+    us = (u.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), e).view(1, -1, 1)).float()   # exact: a power of two
+    return split_f16_pairs(us), e.to(torch.int32)
+
+
+def pack_state_dict_split(state_dict, layers, total_words, scale_blob):
+    """CPU float32-typed tensor of total_words 4-byte words: per F(2x4) layer the split weights (two fp16 per word) and
+    [cout_pad] floats scale * 2^-e.  scale_blob: the float32 blob of pack_state_dict (source of the folded BN scales)."""
+    sd = unwrap_checkpoint(state_dict)
+    blob = torch.zeros(total_words, dtype=torch.float32)
+    for l in layers:
+        if l.get("wsplit_off", -1) < 0:
+            continue
+        w = sd[l["name"] + (".conv_block.0.weight" if l["has_bn"] else ".weight")]
+        cpad, cin = l["cout_pad"], l["cin"]
+        us, e = winograd_weights_split(w, cpad)
+        n = 24 * cpad * cin
+        blob[l["wsplit_off"]:l["wsplit_off"] + n] = us.reshape(-1).view(torch.float32)
+        scale = scale_blob[l["scale_off"]:l["scale_off"] + cpad].double().cpu()
+        blob[l["wsplit_scale_off"]:l["wsplit_scale_off"] + cpad] = (scale * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e.double())).float()
     return blob

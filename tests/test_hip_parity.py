@@ -272,6 +272,55 @@ def test_winograd24_layer_matches_torch(dev, case):
     assert _rel_err(got, want) < 1e-5, case
 
 
+@pytest.mark.parametrize("case", WINO24_CASES)
+def test_winograd24_split_layer_matches_torch(dev, case):
+    """The same layers with SPLIT operands (hi/lo fp16 pairs, three fp16 MFMAs per product group, fp32 accumulate;
+    include/orienmask_hip.h: om_model_set_precision) vs float64 direct convolution: within the fp32-operand kernel's own
+    bound, and no more than 2x that kernel's error on the same inputs + 1e-6 (the hi/lo representation is ~2^-22)."""
+    from orienmask_amd.pack import winograd_weights, winograd_weights_split
+    B, H, W, cin, cout, leaky, use_res = case
+    L = omlib.load()
+    g = torch.Generator().manual_seed(sum(case) + 17)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.2
+    res = torch.randn(B, cout, H, W, generator=g) if use_res else None
+    want = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+    want = want * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if leaky:
+        want = torch.where(want > 0, want, want * 0.1)
+    if use_res:
+        want = want + res.double()
+    cpad = (cout + 63) // 64 * 64
+    sp = torch.zeros(cpad); sp[:cout] = scale
+    hp = torch.zeros(cpad); hp[:cout] = shift
+    us, e = winograd_weights_split(w, cpad)
+    sps = (sp.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e.double())).float()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None
+    scratch = torch.empty(L.om_conv2d_winograd24_scratch_bytes(B, H, W, cin), dtype=torch.uint8, device=dev)
+    errs = {}
+    for mode in ("f32", "split"):
+        out = torch.full((B, H, W, cout), float("nan"), device=dev)
+        if mode == "f32":
+            ud, sd_ = winograd_weights(w, cpad, 24).contiguous().to(dev), sp.to(dev)
+            fn = L.om_conv2d_winograd24
+        else:
+            ud, sd_ = us.to(dev), sps.to(dev)
+            fn = L.om_conv2d_winograd24_split
+        hd = hp.to(dev)
+        rc = fn(_p(xd), B, H, W, cin, cin, _p(ud), _p(sd_), _p(hd), cout, leaky, _p(rd) if use_res else None,
+                cout if use_res else 0, _p(out), cout, _p(scratch), scratch.numel(), omlib.current_stream_ptr(dev))
+        omlib.check(rc, "om_conv2d_winograd24 " + mode)
+        got = out.cpu().permute(0, 3, 1, 2).double()
+        assert torch.isfinite(got).all(), mode
+        errs[mode] = _rel_err(got, want)
+    print("winograd24 %s: fp32 operands %.2e, split operands %.2e" % (case, errs["f32"], errs["split"]))
+    assert errs["split"] < 1e-5, (case, errs)
+    assert errs["split"] <= 2 * errs["f32"] + 1e-6, (case, errs)
+
+
 def test_stem_matches_torch(dev):
     L = omlib.load()
     g = torch.Generator().manual_seed(3)
@@ -295,21 +344,23 @@ def test_stem_matches_torch(dev):
 # ------------------------------------------------------------------------------------------------
 # forward
 # ------------------------------------------------------------------------------------------------
-def _hip_model(sd, dev):
+def _hip_model(sd, dev, precision="f32"):
     from orienmask_amd.model import OrienMaskYOLOFPNPlus
-    net = OrienMaskYOLOFPNPlus(3, 80).eval()
+    net = OrienMaskYOLOFPNPlus(3, 80).eval().set_precision(precision)
     net.load_state_dict(sd, strict=True)
     return net.to(dev)
 
 
+@pytest.mark.parametrize("precision", ["f32", "f32_split"])
 @pytest.mark.parametrize("fname", golden_files("fwd_"))
-def test_forward_matches_reference_golden(dev, fname):
-    """HIP forward vs tensors the real reference produced (tests/golden/fwd_*.npz)."""
+def test_forward_matches_reference_golden(dev, fname, precision):
+    """HIP forward vs tensors the real reference produced (tests/golden/fwd_*.npz), with fp32 and with split operands in the
+    F(2x4) Winograd GEMMs (the latter only changes the batch-of-6 fixture: smaller batches run F(2x2), which has no split form)."""
     g = np.load(os.path.join(GOLDEN, fname))
     size = tuple(int(v) for v in g["size"]); batch = int(g["batch"])
     sd = synth.synth_state_dict(int(g["wseed"]), obj_bias=float(g["obj_bias"]), head_gain=float(g["head_gain"]))
     x = synth.synth_image_batch(int(g["xseed"]), batch, size[0], size[1])
-    net = _hip_model(sd, dev)
+    net = _hip_model(sd, dev, precision)
     with torch.no_grad():
         out = net(x.to(dev))
     torch.cuda.synchronize()
@@ -986,7 +1037,8 @@ def test_forward_bs6_uses_f24_and_matches_oracle(dev):
         assert _rel_err(gb.cpu(), rb) < REL_TOL and _rel_err(go.cpu(), ro) < REL_TOL
 
 
-def test_headline_bs32_forward_and_postprocess(dev):
+@pytest.mark.parametrize("precision", ["f32", "f32_split"])
+def test_headline_bs32_forward_and_postprocess(dev, precision):
     """BASELINE configs[2] at its own size: forward + postprocess of 32 x 544x544 in one call (the bench's architecture and
     input; head gains chosen so that scores do not saturate into exact ties).
     Three images of the batch (first, middle, last) against the CPU oracle: head tensors within 1e-4 of scale, detections
@@ -995,7 +1047,9 @@ def test_headline_bs32_forward_and_postprocess(dev):
     F(2x4,3x3) path; tile shapes, grid sizes and the workspace layout differ)."""
     sd = synth.synth_state_dict(3, obj_bias=-3.0, head_gain=0.7)      # unsaturated heads: no exact score ties (gen_golden.py)
     x = synth.synth_image_batch(1000, 32, 544, 544)
-    net = _hip_model(sd, dev)
+    net = _hip_model(sd, dev, precision)
+    if precision == "f32_split":
+        assert dict(net.layer_kernels(32, 544, 544))["orien_head.2"].endswith("split>")
     post = _hip_post((544, 544), dev)
     pick = [0, 15, 31]
     with torch.no_grad():

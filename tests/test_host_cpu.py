@@ -20,11 +20,11 @@ def test_library_exports_every_declared_symbol(built):
     L = omlib.load()
     for name in declared:
         assert hasattr(L, name)
-    assert L.om_version() == 120
+    assert L.om_version() == 130
 
 
 def test_struct_layouts_match_header(built):
-    assert ctypes.sizeof(omlib.LayerInfo) == 64 + 8 * 4 + 6 * 8
+    assert ctypes.sizeof(omlib.LayerInfo) == 64 + 8 * 4 + 8 * 8
     assert ctypes.sizeof(omlib.PostCfg) == 4 * (1 + 3 + 3 + 2 + 1 + 9 + 9 + 9 + 1 + 2 + 2 + 1 + 1 + 2)
 
 
@@ -292,3 +292,36 @@ def test_checkpoint_ingest_reference_format(tmp_path, built):
     assert torch.equal(a, b)
     with pytest.raises(ValueError):
         builder.build_tester(dict(postprocess={}), raw, [], device=torch.device("cpu"))
+
+
+def test_split_f16_pairs_layout_and_accuracy():
+    """pack.split_f16_pairs / winograd_weights_split: the [16 hi | 16 lo] row layout of include/orienmask_hip.h
+    (om_layer_info.wsplit_off), hi + lo reproduces the scaled fp32 weights to 2^-21 of the output channel's largest element,
+    the scaling is a power of two per output channel and keeps fp16 far from overflow; and the three-product form
+    hi*hi + hi*lo + lo*hi of a dot product is closer to the float64 answer than fp32 accumulation error."""
+    import torch
+    from orienmask_amd.pack import split_f16_pairs, winograd_weights, winograd_weights_split
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 32, generator=g) * 7
+    p = split_f16_pairs(x)
+    assert p.shape == (3, 2, 2, 16) and p.dtype == torch.float16
+    assert torch.equal(p[:, :, 0].reshape(3, 32), x.half())
+    assert torch.equal(p[:, :, 1].reshape(3, 32), (x - x.half().float()).half())
+    w = torch.randn(70, 64, 3, 3, generator=g) / 24
+    w[5] *= 1e-3; w[6] *= 300.0; w[7] = 0
+    us, e = winograd_weights_split(w, 128)
+    assert us.shape == (24, 128, 4, 2, 16) and e.shape == (128,) and int(e[7]) == 0 and int(e[100]) == 0
+    u = winograd_weights(w, 128, 24).double()
+    back = (us[..., 0, :].double() + us[..., 1, :].double()).reshape(24, 128, 64) * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e.double()).view(1, -1, 1)
+    amax = u.abs().amax(dim=(0, 2)).clamp_min(1e-30)
+    assert float(((back - u).abs().amax(dim=(0, 2)) / amax).max()) < 2.0 ** -21
+    assert float(us.float().abs().max()) < 2.0 ** 14
+    v = torch.randn(512, 64, generator=g) * 3
+    vp = split_f16_pairs(v).double()
+    vh, vl = vp[:, :, 0].reshape(512, 64), vp[:, :, 1].reshape(512, 64)
+    uh, ul = us[3, :70, :, 0].reshape(70, 64).double(), us[3, :70, :, 1].reshape(70, 64).double()
+    want = v.double() @ u[3, :70].T
+    got = (vh @ uh.T + vh @ ul.T + vl @ uh.T) * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e[:70].double()).view(1, -1)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) / scale < 2e-7
+    assert float(((v @ u[3, :70].float().T).double() - want).abs().max()) / scale > float((got - want).abs().max()) / scale
