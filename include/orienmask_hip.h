@@ -62,10 +62,14 @@ typedef struct om_layer_info {
     int64_t w16_off;            /* fp16 path: offset IN HALFS into the fp16 weight blob (om_model_load_weights_f16):
                                    [cout_pad][ksize*ksize][cin] fp16 (rows >= cout zero); -1: the stem (always fp32) */
     int64_t wsplit_off;         /* split-operand mode (om_model_set_precision(m, 1)): offset in 4-BYTE WORDS into the split blob
-                                   (om_model_load_weights_split) of the F(2x4,3x3) weights as hi/lo fp16 pairs,
-                                   [24][cout_pad][cin / 16][2][16] halfs: per row and group of 16 input channels the 16 hi
-                                   halfs, then the 16 lo halfs of  U * 2^e[cout]  (hi = fp16(x), lo = fp16(x - hi));
-                                   -1: the layer has no F(2x4) form */
+                                   (om_model_load_weights_split) of the layer's weights as hi/lo fp16 pairs of
+                                   x = weight * 2^e[cout]  (hi = fp16(x), lo = fp16(x - hi)):
+                                   wino_planes == 24: the F(2x4,3x3) planes, [24][cout_pad][cin / 16][2][16] halfs -- per row and
+                                     group of 16 input channels the 16 hi halfs, then the 16 lo halfs;
+                                   otherwise: the direct weights, [cout_pad][ksize*ksize][cin / 16][4][8] halfs -- per group of
+                                     16 input channels hi of channels {0-3, 8-11}, hi of {4-7, 12-15}, lo of {0-3, 8-11}, lo of
+                                     {4-7, 12-15} (the order in which a lane half reads fp32 activations from LDS);
+                                   -1: the stem (always fp32 operands) */
     int64_t wsplit_scale_off;   /* offset in 4-byte words into the split blob of [cout_pad] floats scale * 2^-e[cout] (the
                                    power of two is exact, so the epilogue rounds as with the unscaled weights) */
 } om_layer_info;
@@ -120,7 +124,9 @@ int om_model_load_weights(om_model* m, const void* packed_dev, size_t bytes, int
  *    dropped): 5.3x the matrix rate at the same bytes per element.  Representation error <= 2^-22 |x| (floor 2^-25
  *    absolute), i.e. ~4x an fp32 rounding; measured end to end in DESIGN.md 3.6.  Transformed inputs must stay below
  *    65504 in magnitude (activations below ~3000); weights are pre-scaled per output channel by the packer.
- *    Needs om_model_load_weights_split; activations between layers stay fp32, every other layer is unchanged. */
+ *    Needs om_model_load_weights_split; activations between layers stay fp32.  The 1x1 and stride-2 layers run the same
+ *    three-product form (conv_igemm_split.hip: activations are split in registers); the stem and forwards too small for
+ *    the F(2x4) tiling (F(2x2) kernels) keep fp32 operands. */
 size_t om_model_weight_split_words(const om_model* m);
 int om_model_load_weights_split(om_model* m, const void* packed_split_dev, size_t bytes);
 int om_model_set_precision(om_model* m, int mode);
@@ -215,6 +221,11 @@ int om_conv2d_winograd24(const float* in, int B, int H, int W, int cin, int in_p
                          const float* scale, const float* shift, int cout, int leaky, const float* res,
                          int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
                          om_stream stream);
+/* one ConvBNRelu with split operands (conv_igemm_split.hip): w_split / scale_split as om_layer_info.wsplit_off /
+ * wsplit_scale_off describe for a layer without F(2x4) form; other arguments as om_conv2d_mode. */
+int om_conv2d_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* w_split,
+                    const float* scale_split, const float* shift, int cout, int ksize, int stride, int leaky, const float* res,
+                    int res_pix_stride, float* out, int out_pix_stride, int out_mode, int up, om_stream stream);
 /* ... with split operands (om_model_set_precision mode 1): u_split as om_layer_info.wsplit_off describes, scale_split =
  * scale * 2^-e per output channel; scratch as for om_conv2d_winograd24. */
 int om_conv2d_winograd24_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* u_split,

@@ -1,0 +1,398 @@
+// Fused convolution for gfx950 with SPLIT fp32 operands (precision mode 1, include/orienmask_hip.h: om_model_set_precision):
+// fp32 activations in, fp32 activations out, but the products run on the fp16 matrix pipe.
+//
+//   out[m][n] = act( (sum_k A[m][k] * Wt[n][k]) * scale[n] + shift[n] ) (+ res[m][n])            (conv_igemm.hip's layer)
+//   A[m][k] = a_hi + a_lo,  Wt[n][k] * 2^e[n] = w_hi + w_lo   (hi = fp16(x), lo = fp16(x - hi): x to ~2^-22 |x|)
+//   A * Wt  ~=  a_hi w_hi + a_hi w_lo + a_lo w_hi             (three v_mfma_f32_32x32x16_f16 with fp32 accumulation; the
+//                                                              dropped a_lo w_lo is <= 2^-22 of the product)
+//
+// The f32-input matrix instruction (v_mfma_f32_32x32x2_f32) peaks at 157 TFLOP/s, the fp16 one at 2.5 PFLOP/s: three fp16
+// instructions per product group are 5.3x faster than the fp32 form, at fp32-level accuracy (measured against float64:
+// tools/split_error.py) -- the 1x1 and stride-2 layers stop being bound by the matrix pipe.
+//
+// Same layer as conv_igemm.hip (Conv2d -> BatchNorm2d(eval) -> LeakyReLU(0.1), residual add, nearest upsample, concat by
+// slice, NCHW orientation head: /root/reference/model/base.py:95-137, backbone/darknet.py:14-15,
+// orienmask_yolo_fpnplus.py:78-86); the ring / LDS-DMA / tile-queue structure is conv_igemm_f16.hip's, because the byte
+// rates per matrix instruction are those of the fp16 kernels:
+//   * a k-step is 16 input channels: a 64-byte row of fp32 activations (four 16-byte chunks) and a 64-byte row of packed
+//     weights [8 hi | 8 hi | 8 lo | 8 lo] halfs.  Lane half fk reads chunks fk and 2 + fk of both: for A that is channels
+//     {4 fk .. 4 fk + 3, 8 + 4 fk .. 8 + 4 fk + 3}, and the packer stores the weights' hi and lo halfs in exactly that order
+//     (orienmask_amd/pack.py: conv_weights_split), so A is split in registers (one fp16 conversion for hi, a subtraction and
+//     a second conversion for lo) and B needs no arithmetic at all;
+//   * 3-deep operand ring filled by LDS-DMA two k-steps ahead (counted vmcnt, raw s_barrier); per k-step one barrier:
+//     convert(s+1) and the LDS reads of step s+1 run under the 3 TM TN matrix instructions of step s;
+//   * fp32 epilogue through LDS one wave-row at a time, eight channels (two 16-byte stores) per thread.
+#include <cstdlib>
+
+#include "conv_f16_common.h"
+
+namespace om {
+
+struct IgemmSParams {
+    const _Float16* in;   // the fp32 activations, addressed in halfs (pixel stride and channel counts doubled)
+    const _Float16* w;    // packed hi/lo weights: [cout_pad][taps][cin / 16][4][8] halfs
+    const float* scale;   // scale * 2^-e per output channel
+    const float* shift;
+    const float* res;
+    float* out;
+    int* ticket;
+    int H, W, cin_h, in_pix_stride_h;      // in halfs (= 2 x the float counts)
+    int Ho, Wo, HoWo, cout;
+    int ks, stride, pad;
+    int M, kc, ksteps, taps;               // kc = cin / 16
+    int n_tiles, total_tiles;
+    int leaky, res_pix_stride, out_pix_stride, out_mode, up;
+    int vec_io;
+    int total_in_pixels;
+    int w_bytes;
+};
+
+template <int BM, int BN>
+constexpr int split_blocks_per_cu() { return BM * BN >= 256 * 128 ? 2 : (BM * BN >= 128 * 128 ? 3 : 4); }
+
+// fp32 epilogue of a finished BM x BN tile (accumulators in the transposed 32x32 layout: pixel = lane & 31,
+// channel = 8*(r>>2) + 4*(lane>>5) + (r&3)): one wave-row (WM pixels x BN channels) at a time through LDS.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void split_epilogue(const IgemmSParams& p, f32x4* smem, const f32x16 (&acc)[WM / 32][WN / 32],
+                                               int m0, int n0, int tid, int wm, int wn, int fi, int fk) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int CH8 = BN / 8;
+    constexpr int RP = 256 / CH8;
+    constexpr int CH = BN / 4;
+    f32x4* sC = smem;
+    const int n8 = tid % CH8, r0 = tid / CH8;
+    const int n = n0 + n8 * 8;
+    const int nvalid = p.cout - n;
+    const bool vec = p.vec_io && nvalid >= 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = p.scale[n + k]; sh[k] = p.shift[n + k]; }   // padded to cout_pad
+#pragma unroll 1
+    for (int pass = 0; pass < BM / WM; ++pass) {
+        if (wm == pass) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int ml = a * 32 + fi;
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n4 = (wn * WN + b * 32) / 4 + 2 * g + fk;
+                        f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                        sC[ml * CH + (n4 ^ (ml & 7))] = v;
+                    }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS-only barrier: the previous pass's stores keep flying
+        __builtin_amdgcn_s_barrier();
+        if (p.out_mode != 2) {
+#pragma unroll 2
+            for (int ps = 0; ps < (WM + RP - 1) / RP; ++ps) {
+                const int ml = ps * RP + r0;
+                const int m = m0 + pass * WM + ml;
+                if (ml >= WM || m >= p.M || nvalid <= 0) continue;
+                const f32x4 v0 = sC[ml * CH + ((2 * n8) ^ (ml & 7))];
+                const f32x4 v1 = sC[ml * CH + ((2 * n8 + 1) ^ (ml & 7))];
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float t = fmaf(v[k], sc[k], sh[k]);
+                    v[k] = p.leaky ? (t > 0.f ? t : t * 0.1f) : t;
+                }
+                if (p.out_mode == 0) {
+                    float* o = p.out + (size_t)m * p.out_pix_stride + n;
+                    if (p.res) {
+                        const float* rp = p.res + (size_t)m * p.res_pix_stride + n;
+                        if (vec) {
+                            const f32x4 ra = *reinterpret_cast<const f32x4*>(rp), rb = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { v[k] += ra[k]; v[4 + k] += rb[k]; }
+                        } else {
+                            for (int k = 0; k < 8 && k < nvalid; ++k) v[k] += rp[k];
+                        }
+                    }
+                    if (vec) {
+                        *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    } else {
+                        for (int k = 0; k < 8 && k < nvalid; ++k) o[k] = v[k];
+                    }
+                } else {
+                    const int bi = m / p.HoWo;
+                    const int rr = m - bi * p.HoWo;
+                    const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
+                    const int Wu = p.Wo * p.up;
+                    const size_t base = ((size_t)bi * p.Ho * p.up + (size_t)oy * p.up) * Wu + (size_t)ox * p.up;
+                    for (int dy = 0; dy < p.up; ++dy)
+                        for (int dx = 0; dx < p.up; ++dx) {
+                            float* o = p.out + (base + (size_t)dy * Wu + dx) * p.out_pix_stride + n;
+                            if (vec) {
+                                *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                                *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                            } else {
+                                for (int k = 0; k < 8 && k < nvalid; ++k) o[k] = v[k];
+                            }
+                        }
+                }
+            }
+        } else {
+            // NCHW output (orientation head): consecutive threads walk pixels of one channel
+            const float* sCf = reinterpret_cast<const float*>(smem);
+            const int nch = min(BN, p.cout - n0);
+            for (int idx = tid; idx < nch * WM; idx += 256) {
+                const int nl = idx / WM, ml = idx - nl * WM;
+                const int m = m0 + pass * WM + ml;
+                if (m >= p.M) continue;
+                const int nn = n0 + nl;
+                float t = fmaf(sCf[(ml * CH + ((nl >> 2) ^ (ml & 7))) * 4 + (nl & 3)], p.scale[nn], p.shift[nn]);
+                if (p.leaky) t = t > 0.f ? t : t * 0.1f;
+                const int bi = m / p.HoWo;
+                const int rr = m - bi * p.HoWo;
+                p.out[((size_t)bi * p.cout + nn) * p.HoWo + rr] = t;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// hi = fp16(x) (round to nearest even), lo = fp16(x - hi) for the eight channels a lane holds of one pixel
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (_Float16)x0[i];
+        hi[4 + i] = (_Float16)x1[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lo[i] = (_Float16)(x0[i] - (float)hi[i]);
+        lo[4 + i] = (_Float16)(x1[i] - (float)hi[4 + i]);
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, (split_blocks_per_cu<BM, BN>())) void conv_igemm_split_kernel(const IgemmSParams p) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NWN = BN / WN;
+    constexpr int A_CH = BM / 64, B_CH = (BN + 63) / 64, NP = A_CH + B_CH;   // 64 rows x 64 B per workgroup-wide piece
+    constexpr int NBUF = 3;
+    constexpr int STAGE = (BM + (BN < 64 ? 64 : BN)) * 4;   // f32x4 (16-byte) units per ring stage
+    static_assert((BM / WM) * (BN / WN) == 4, "four waves per workgroup");
+    static_assert(BM % 64 == 0, "A tile = whole 64-row pieces");
+    static_assert(WM * BN / 4 <= NBUF * STAGE, "one wave-row of the fp32 C tile must fit in the operand ring");
+    __shared__ f32x4 smem[NBUF * STAGE + 1];      // ONE LDS object (see conv_igemm.hip)
+    int* const s_ticket = reinterpret_cast<int*>(smem + NBUF * STAGE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int lrow = tid >> 2, lcol = tid & 3;     // loader: row within a 64-row piece, 16-byte position in the row
+    const int scol = lcol ^ ((lrow >> 2) & 3);     // logical chunk this lane fetches (the LDS image stays lane-linear)
+    const int fi = lane & 31, fk = lane >> 5;
+    const int fsw = (fi >> 2) & 3;
+
+    for (;;) {
+        if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int tile = *s_ticket;
+        if (tile >= p.total_tiles) break;
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        const int tile_n = tile % p.n_tiles;
+        const int tile_m = tile / p.n_tiles;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+        // ---- loader role (conv_igemm_f16.hip): per A row the byte offset of tap (0,0)'s chunk relative to the tile's first
+        // image and a mask whose bit t says "tap t of this row is padding / beyond M"
+        int rowoff[A_CH];
+        unsigned invmask[A_CH];
+        const int b_first = (m0 < p.M ? m0 : p.M - 1) / p.HoWo;
+#pragma unroll
+        for (int j = 0; j < A_CH; ++j) {
+            int m = m0 + lrow + 64 * j;
+            const bool mok = m < p.M;
+            if (!mok) m = p.M - 1;
+            const int b = m / p.HoWo;
+            const int rr = m - b * p.HoWo;
+            const int oy = rr / p.Wo;
+            const int ox = rr - oy * p.Wo;
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+            rowoff[j] = (((b - b_first) * p.H * p.W + iy0 * p.W + ix0) * p.in_pix_stride_h + scol * 8) * 2;
+            unsigned badrow = 0, badcol = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                badrow |= ((unsigned)(iy0 + k) < (unsigned)p.H ? 0u : 1u) << k;
+                badcol |= ((unsigned)(ix0 + k) < (unsigned)p.W ? 0u : 1u) << k;
+            }
+            unsigned inv;
+            if (p.ks == 3) {
+                inv = ((badrow & 1u) ? 0x007u : 0u) | ((badrow & 2u) ? 0x038u : 0u) | ((badrow & 4u) ? 0x1C0u : 0u) | badcol * 0x49u;
+            } else {
+                inv = (badrow | badcol) & 1u;
+            }
+            invmask[j] = mok ? inv : 0xFFFFFFFFu;
+        }
+        int rowoffB[B_CH];
+        const int row_halfs = p.taps * p.cin_h;
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) rowoffB[j] = ((n0 + lrow + 64 * j) * row_halfs + scol * 8) * 2;
+        const _Float16* in_base = p.in + (size_t)b_first * p.H * p.W * p.in_pix_stride_h;
+        const size_t in_left = ((size_t)p.total_in_pixels - (size_t)b_first * p.H * p.W) * p.in_pix_stride_h * 2;
+        const int in_bytes = in_left < 0x7FFFFFFFull ? (int)in_left : 0x7FFFFFFF;
+
+        int n_kh = 0, n_kw = 0, n_cc = 0;          // step being fetched: (tap row, tap col, 16-channel chunk)
+        auto advance = [&]() {
+            if (++n_cc == p.kc) {
+                n_cc = 0;
+                if (++n_kw == p.ks) { n_kw = 0; ++n_kh; }
+            }
+        };
+        auto issue_piece = [&](int piece, int buf, bool live) {
+            f32x4* dst = smem + buf * STAGE + wave_u * 64;
+            if (piece < A_CH) {
+                const int j = piece;
+                const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in_base), 0, live ? in_bytes : 0, 0x00020000);
+                const int tap = n_kh * p.ks + n_kw;
+                const int tap_off = ((n_kh * p.W + n_kw) * p.in_pix_stride_h + n_cc * 32) * 2;      // scalar
+                const int voff = (rowoff[j] + tap_off) | ((invmask[j] << (31 - tap)) & 0x80000000u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(dst + j * 256), 16, voff, 0, 0, 0);
+            } else {
+                const int j = piece - A_CH;
+                const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, live ? p.w_bytes : 0, 0x00020000);
+                const int koff = ((n_kh * p.ks + n_kw) * p.cin_h + n_cc * 32) * 2;                  // scalar
+                const int vo = rowoffB[j] + koff;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(dst + BM * 4 + j * 256), 16, vo, 0, 0, 0);
+            }
+        };
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+        const f32x4* fragA = smem + (wm * WM + fi) * 4;
+        const f32x4* fragB = smem + BM * 4 + (wn * WN + fi) * 4;
+        f32x4 xa0[TM], xa1[TM], nbh[TN], nbl[TN];      // raw operands of the NEXT step
+        f16x8 ah[TM], al[TM], bh[TN], bl[TN];          // operands of the current step
+        auto read_raw = [&](int buf) {
+            const int c0 = fk ^ fsw, c1 = (2 + fk) ^ fsw;
+            const int bo = buf * STAGE;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) { xa0[a] = fragA[bo + a * 32 * 4 + c0]; xa1[a] = fragA[bo + a * 32 * 4 + c1]; }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) { nbh[b] = fragB[bo + b * 32 * 4 + c0]; nbl[b] = fragB[bo + b * 32 * 4 + c1]; }
+        };
+        auto convert = [&]() {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) split8(xa0[a], xa1[a], ah[a], al[a]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) { bh[b] = __builtin_bit_cast(f16x8, nbh[b]); bl[b] = __builtin_bit_cast(f16x8, nbl[b]); }
+        };
+
+        // prologue: steps 0, 1, 2 requested; step 0 waited for and converted
+#pragma unroll
+        for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 0, true);
+        advance();
+#pragma unroll
+        for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 1, 1 < p.ksteps);
+        advance();
+#pragma unroll
+        for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 2, 2 < p.ksteps);
+        advance();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NP) : "memory");
+        __builtin_amdgcn_s_barrier();
+        read_raw(0);
+        convert();
+        int buf = 0;
+        for (int s = 0; s < p.ksteps; ++s) {
+            const int buf1 = buf == NBUF - 1 ? 0 : buf + 1;
+            // step s+1 has landed (only step s+2's NP pieces may still fly); every wave's reads of `buf` are complete (they
+            // fed its convert) -> `buf` can take step s+3
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NP) : "memory");
+            __builtin_amdgcn_s_barrier();
+            read_raw(buf1);
+            const bool live3 = s + 3 < p.ksteps;
+#pragma unroll
+            for (int piece = 0; piece < NP; ++piece) issue_piece(piece, buf, live3);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    // weights first: D[i = channel][j = pixel]
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[b], al[a], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[b], ah[a], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[b], ah[a], acc[a][b], 0, 0, 0);
+                }
+            convert();                               // operands of step s+1 (VALU under the matrix instructions above)
+            buf = buf1;
+            advance();
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        split_epilogue<BM, BN, WM, WN>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk);
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hipStream_t stream) {
+    const int m_tiles = (p.M + BM - 1) / BM;
+    p.n_tiles = cout_pad / BN;
+    const long long total = (long long)m_tiles * p.n_tiles;
+    OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "conv split: %lld tiles out of range", total);
+    p.total_tiles = (int)total;
+    const long long grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
+    hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
+void conv_tile_for_split(int M, int cout_pad, int* bm, int* bn) { conv_tile_for_f16(M, cout_pad, 0, bm, bn); }
+
+// a.w: packed hi/lo weights (include/orienmask_hip.h: om_layer_info.wsplit_off); a.scale: scale * 2^-e
+int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream) {
+    OM_REQUIRE(a.in && a.w && a.scale && a.shift && a.out, OM_EINVAL, "conv split: null pointer");
+    OM_REQUIRE(a.cin % 16 == 0 && a.cin >= 16, OM_EINVAL, "conv split: cin=%d must be a multiple of 16", a.cin);
+    OM_REQUIRE(a.ks == 1 || a.ks == 3, OM_EINVAL, "conv split: ksize=%d not supported", a.ks);
+    OM_REQUIRE(a.stride == 1 || a.stride == 2, OM_EINVAL, "conv split: stride=%d not supported", a.stride);
+    OM_REQUIRE(a.in_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(a.w) & 15) == 0,
+               OM_EINVAL, "conv split: input view / weights must be 16-byte aligned");
+    OM_REQUIRE(a.cout_pad % 32 == 0 && a.cout <= a.cout_pad, OM_EINVAL, "conv split: cout_pad=%d", a.cout_pad);
+    OM_REQUIRE((long long)a.B * a.H * a.W * a.in_pix_stride < (1ll << 40) && (long long)a.B * a.H * a.W < (1ll << 31) &&
+                   (long long)a.B * a.Ho * a.Wo < (1ll << 31),
+               OM_EINVAL, "conv split: problem too large");
+    OM_REQUIRE(!(a.res && a.out_mode != 0), OM_EINVAL, "conv split: residual only with plain NHWC output");
+    OM_REQUIRE(a.ticket, OM_EINVAL, "conv split: the tile queue needs a zeroed ticket word");
+    IgemmSParams p;
+    p.in = reinterpret_cast<const _Float16*>(a.in); p.w = reinterpret_cast<const _Float16*>(a.w);
+    p.scale = a.scale; p.shift = a.shift; p.res = a.res; p.out = a.out; p.ticket = a.ticket;
+    p.H = a.H; p.W = a.W; p.cin_h = 2 * a.cin; p.in_pix_stride_h = 2 * a.in_pix_stride;
+    p.Ho = a.Ho; p.Wo = a.Wo; p.HoWo = a.Ho * a.Wo; p.cout = a.cout;
+    p.ks = a.ks; p.stride = a.stride; p.pad = a.ks / 2;
+    p.M = a.B * a.Ho * a.Wo; p.taps = a.ks * a.ks;
+    p.kc = a.cin / 16;
+    p.ksteps = p.taps * p.kc;
+    p.leaky = a.leaky; p.res_pix_stride = a.res_pix_stride; p.out_pix_stride = a.out_pix_stride;
+    p.out_mode = a.out_mode; p.up = a.up;
+    p.n_tiles = 0; p.total_tiles = 0;
+    p.total_in_pixels = a.B * a.H * a.W;
+    p.w_bytes = a.cout_pad * p.taps * a.cin * 4;
+    p.vec_io = (a.out_mode != 2 && a.out_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+                (!a.res || (a.res_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)))
+                   ? 1 : 0;
+    int bm, bn;
+    conv_tile_for_split(p.M, a.cout_pad, &bm, &bn);
+    if (bm == 256 && bn == 128) return launch_tile_split<256, 128, 128, 64>(p, a.cout_pad, 2, stream);
+    if (bm == 128 && bn == 128) return launch_tile_split<128, 128, 64, 64>(p, a.cout_pad, 3, stream);
+    if (bm == 128 && bn == 64) return launch_tile_split<128, 64, 64, 32>(p, a.cout_pad, 4, stream);
+    if (bm == 64 && bn == 64) return launch_tile_split<64, 64, 32, 32>(p, a.cout_pad, 4, stream);
+    return launch_tile_split<128, 32, 32, 32>(p, a.cout_pad, 4, stream);
+}
+
+}  // namespace om

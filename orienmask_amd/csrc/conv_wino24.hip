@@ -21,6 +21,10 @@
 
 #include "om_common.h"
 
+#ifndef OM_ABL
+#define OM_ABL 0
+#endif
+
 namespace om {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -181,6 +185,11 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
         nseg = (x_trail != 0) + n_full + (x_lead != 0);
     }
 
+    int xcd = 0, q_hops = 0;        // whole-tile form: my XCD's queue first, then the others' in ring order
+    if constexpr (!SK) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcd));
+        xcd &= 7;
+    }
     for (int seg = 0;; ++seg) {
         int tile, xb = 0, xe = 24, mode = 0;     // mode 1: produce the head planes of a tile, 2: finish from the partner's
         if constexpr (SK) {
@@ -195,11 +204,28 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
             // __syncthreads) does not make them drain the previous tile's output stores first.  (Drawing the NEXT ticket at the
             // start of a tile hides the round trip too, but pins the last partial round of tiles to the workgroups that started
             // first: the 34 x 34 layers went from 0.33 to 0.44 ms.)
-            if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+            // EIGHT queues, one per XCD (ticket words 0..7): XCD x owns the M panels [m_tiles x / 8, m_tiles (x + 1) / 8) and its
+            // workgroups draw (panel, N tile) pairs N fastest, so the n_tiles workgroups that share a transformed-input panel run
+            // at the same time behind the SAME L2 -- with one queue for the chip they sat on different XCDs and every one of them
+            // fetched the panel from HBM (rocprofv3 PMC: 4.5 reads of V per launch).  A workgroup whose queue is empty moves
+            // on to the next XCD's (never back), so the last round still balances over the whole chip.  Placement only:
+            // results do not depend on which workgroup computes a tile.
+            if (tid == 0) {
+                const int m_tiles_all = p.total_tiles / p.n_tiles;
+                int t = -1;
+                while (q_hops < 8) {
+                    const int q = (xcd + q_hops) & 7;
+                    const int pm0 = (int)((long long)m_tiles_all * q >> 3), pm1 = (int)((long long)m_tiles_all * (q + 1) >> 3);
+                    const int v = atomicAdd(p.ticket + q, 1);
+                    if (v < (pm1 - pm0) * p.n_tiles) { t = pm0 * p.n_tiles + v; break; }
+                    ++q_hops;
+                }
+                *s_ticket = t;
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             tile = *s_ticket;
-            if (tile >= p.total_tiles) break;
+            if (tile < 0) break;
             tile = __builtin_amdgcn_readfirstlane(tile);
         }
         const int ksteps = (xe - xb) * p.kc;
@@ -300,8 +326,17 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
             if constexpr (SPLIT) {
                 // six matrix instructions per k-step: per group of 16 channels hi*lo + lo*hi + hi*hi (fp32 accumulate)
                 f32x4 a2, b2, a3, b3;
+#if OM_ABL >= 5
+                if (p.T < 0) {
+#endif
                 read_frags(a2, b2, buf, 2);
                 read_frags(a3, b3, buf, 3);
+#if OM_ABL >= 5
+                } else { a2 = ca; b2 = cb; a3 = ca1; b3 = cb1; }
+#endif
+#if OM_ABL == 2 || OM_ABL >= 3
+                if (p.T < 0)
+#endif
 #pragma unroll
                 for (int piece = 0; piece < NP; ++piece) issue_piece(piece, buf2, live2);
                 const f16x8 ah = __builtin_bit_cast(f16x8, ca), al = __builtin_bit_cast(f16x8, ca1);
@@ -317,10 +352,22 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh2, ah2, acc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 // step s+1's operands have landed (only this step's NP pieces may still fly); my reads of `buf` are done
+#if OM_ABL >= 4
+                if (p.T < 0) {
+#endif
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NP) : "memory");
                 __builtin_amdgcn_s_barrier();
+#if OM_ABL >= 4
+                }
+#endif
+#if OM_ABL >= 5
+                if (p.T < 0) {
+#endif
                 read_frags(ca, cb, buf1, 0);
                 read_frags(ca1, cb1, buf1, 1);
+#if OM_ABL >= 5
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             } else {
 #pragma unroll
@@ -394,6 +441,9 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
             }
         }
 
+#if OM_ABL == 1 || OM_ABL >= 3
+        if (SPLIT && p.T >= 0) continue;
+#endif
         // ---- epilogue: row geometry once per tile; per pass of two output positions the residual loads are issued BEFORE the
         // LDS staging (they fly during it), C tiles [position][row][channel chunk ^ (row & 7)] go through LDS and leave as 16-byte
         // rows; the barriers wait for LDS only (a __syncthreads() would also drain the stores: ~2 us of HBM write latency per

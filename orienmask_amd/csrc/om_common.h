@@ -62,6 +62,9 @@ constexpr int SYNC_WORDS = SK_FLAG_OFF + SK_SLOTS;      // ints per launch
 constexpr size_t SK_PARTIAL_BYTES = (size_t)512 * 32 * 256 * 16;   // Winograd F(2x4): 512 slots x 8 accumulators x 16 floats x 256 threads (64 MiB)
 
 int launch_conv_igemm(const ConvArgs& a, hipStream_t stream);
+// split-operand form (conv_igemm_split.hip): a.w = packed hi/lo fp16 weights, a.scale = scale * 2^-e
+int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream);
+void conv_tile_for_split(int M, int cout_pad, int* bm, int* bn);
 
 // fp16-activation path (conv_igemm_f16.hip): in / w / res are fp16, scale / shift fp32, out fp16 unless out_f32.
 struct ConvArgsH {

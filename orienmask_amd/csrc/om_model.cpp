@@ -115,9 +115,10 @@ struct om_model {
             }
         }
         L.info.wsplit_off = L.info.wsplit_scale_off = -1;
-        if (L.info.wino_planes == 24) {
+        if (!stem) {
+            // split-operand mode: the F(2x4) planes of the stride-1 3x3 layers, the direct weights of every other layer
             L.info.wsplit_off = (int64_t)split_words;
-            split_words += (size_t)24 * L.info.cout_pad * cin;
+            split_words += (size_t)(L.info.wino_planes == 24 ? 24 : ks * ks) * L.info.cout_pad * cin;
             L.info.wsplit_scale_off = (int64_t)split_words;
             split_words = om::align_up(split_words + L.info.cout_pad, 4);
         }
@@ -495,7 +496,13 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
                 }
             } else {
                 if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));     // single-kernel layer: mid == start
-                rc = om::launch_conv_igemm(a, stream);
+                if (m->precision == 1 && li.wino_planes != 24) {
+                    a.w = m->weights_split + li.wsplit_off;
+                    a.scale = m->weights_split + li.wsplit_scale_off;
+                    rc = om::launch_conv_igemm_split(a, stream);
+                } else {
+                    rc = om::launch_conv_igemm(a, stream);
+                }
             }
         }
         if (rc != OM_OK) {
@@ -591,6 +598,11 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
         return OM_OK;
     }
     const int Ho = H / L.in_div / L.info.stride, Wo = W / L.in_div / L.info.stride;
+    if (m->precision == 1 && L.info.wino_planes != 24) {
+        om::conv_tile_for_split(B * Ho * Wo, L.info.cout_pad, bm, bn);
+        *algo = 7;
+        return OM_OK;
+    }
     om::conv_tile_for(B * Ho * Wo, L.info.cout_pad, bm, bn);
     *algo = 1;
     return OM_OK;
@@ -662,6 +674,26 @@ int om_conv2d_mode(const float* in, int B, int H, int W, int cin, int in_pix_str
     if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;
     a.ticket = g_ticket;
     return om::launch_conv_igemm(a, static_cast<hipStream_t>(stream));
+}
+
+int om_conv2d_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* w_split,
+                    const float* scale_split, const float* shift, int cout, int ksize, int stride, int leaky, const float* res,
+                    int res_pix_stride, float* out, int out_pix_stride, int out_mode, int up, om_stream stream) {
+    OM_REQUIRE(B > 0 && H > 0 && W > 0 && stride >= 1 && H % stride == 0 && W % stride == 0, OM_EINVAL,
+               "om_conv2d_split: bad shape");
+    OM_REQUIRE(out_mode >= 0 && out_mode <= 2 && up >= 1 && (out_mode == 1 || up == 1), OM_EINVAL,
+               "om_conv2d_split: out_mode=%d up=%d (0 NHWC, 1 NHWC replicated up x up, 2 NCHW)", out_mode, up);
+    om::ConvArgs a;
+    a.in = in; a.w = static_cast<const float*>(w_split); a.scale = scale_split; a.shift = shift; a.res = res; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.cin = cin; a.in_pix_stride = in_pix_stride;
+    a.Ho = H / stride; a.Wo = W / stride; a.cout = cout; a.cout_pad = om::round_up(cout, 32);
+    a.ks = ksize; a.stride = stride; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
+    a.out_pix_stride = out_pix_stride; a.out_mode = out_mode; a.up = up;
+    static int* g_ticket = nullptr;      // unit-test entry only (see om_conv2d_mode)
+    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), om::SYNC_WORDS * sizeof(int)));
+    if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;
+    a.ticket = g_ticket;
+    return om::launch_conv_igemm_split(a, static_cast<hipStream_t>(stream));
 }
 
 int om_conv2d(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* w, const float* scale,

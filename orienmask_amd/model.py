@@ -348,7 +348,8 @@ class OrienMaskYOLOFPNPlus(nn.Module):
             _lib.check(_lib.load().om_layer_tile(h, i, B, H, W, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(algo)),
                        "om_layer_tile")
             fmt = {0: "conv_stem_kernel", 1: "conv_igemm_f32_kernel<%d,%d>", 2: "wino_gemm_kernel<%d,%d>",
-                   3: "wino_fused_kernel<%d,%d>", 5: "wino24_gemm_kernel<%d,%d>", 6: "wino24_gemm_kernel<%d,%d,split>"}[algo.value]
+                   3: "wino_fused_kernel<%d,%d>", 5: "wino24_gemm_kernel<%d,%d>", 6: "wino24_gemm_kernel<%d,%d,split>",
+                   7: "conv_igemm_split_kernel<%d,%d>"}[algo.value]
             out.append((l["name"], fmt % ((bm.value, bn.value) if algo.value else ())))
         return out
 

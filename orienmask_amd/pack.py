@@ -151,9 +151,36 @@ def winograd_weights_split(w, cout_pad):
     return split_f16_pairs(us), e.to(torch.int32)
 
 
+_SPLIT_PERM = [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]
+
+
+def _pow2_row_scale(rows):
+    """Exponents e[row] (float64 tensor) that put each row's largest magnitude into [2^13, 2^14); 0 for all-zero rows."""
+    amax = rows.abs().amax(dim=1).double()
+    e = torch.where(amax > 0, 13 - torch.floor(torch.log2(amax.clamp_min(1e-300))), torch.zeros_like(amax))
+    return e.clamp(-100, 100)
+
+
+def conv_weights_split(w, cout_pad):
+    """[cout,cin,k,k] -> (fp16 [cout_pad][k*k][cin/16][4][8], exponents int32 [cout_pad]): the direct weights (OHWI rows)
+    times 2^e[cout] as hi/lo fp16 pairs in the order conv_igemm_split.hip reads them -- per group of 16 input channels
+    hi{0-3,8-11}, hi{4-7,12-15}, lo{0-3,8-11}, lo{4-7,12-15} (include/orienmask_hip.h: om_layer_info.wsplit_off)."""
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    rows = torch.zeros(cout_pad, k * k * cin, dtype=torch.float32)
+    rows[:cout] = w.detach().float().cpu().permute(0, 2, 3, 1).reshape(cout, -1)
+    e = _pow2_row_scale(rows)
+    xs = (rows.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), e).view(-1, 1)).float()
+    hi = xs.half()
+    lo = (xs - hi.float()).half()
+    g = cin // 16
+    hi = hi.reshape(cout_pad, k * k, g, 16)[..., _SPLIT_PERM].reshape(cout_pad, k * k, g, 2, 8)
+    lo = lo.reshape(cout_pad, k * k, g, 16)[..., _SPLIT_PERM].reshape(cout_pad, k * k, g, 2, 8)
+    return torch.cat((hi, lo), dim=-2).contiguous(), e.to(torch.int32)
+
+
 def pack_state_dict_split(state_dict, layers, total_words, scale_blob):
-    """CPU float32-typed tensor of total_words 4-byte words: per F(2x4) layer the split weights (two fp16 per word) and
-    [cout_pad] floats scale * 2^-e.  scale_blob: the float32 blob of pack_state_dict (source of the folded BN scales)."""
+    """CPU float32-typed tensor of total_words 4-byte words: per layer (all but the stem) the split weights (two fp16 per
+    word; the F(2x4) planes of the stride-1 3x3 layers, the direct weights of the others) and [cout_pad] floats scale * 2^-e.  scale_blob: the float32 blob of pack_state_dict (source of the folded BN scales)."""
     sd = unwrap_checkpoint(state_dict)
     blob = torch.zeros(total_words, dtype=torch.float32)
     for l in layers:
@@ -161,8 +188,11 @@ def pack_state_dict_split(state_dict, layers, total_words, scale_blob):
             continue
         w = sd[l["name"] + (".conv_block.0.weight" if l["has_bn"] else ".weight")]
         cpad, cin = l["cout_pad"], l["cin"]
-        us, e = winograd_weights_split(w, cpad)
-        n = 24 * cpad * cin
+        if l.get("wino_planes", 0) == 24:
+            us, e = winograd_weights_split(w, cpad)
+        else:
+            us, e = conv_weights_split(w, cpad)
+        n = us.numel() // 2
         blob[l["wsplit_off"]:l["wsplit_off"] + n] = us.reshape(-1).view(torch.float32)
         scale = scale_blob[l["scale_off"]:l["scale_off"] + cpad].double().cpu()
         blob[l["wsplit_scale_off"]:l["wsplit_scale_off"] + cpad] = (scale * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e.double())).float()

@@ -181,6 +181,95 @@ def test_conv_upsample_epilogue_matches_torch(dev, up, cin, cout, hw, cstride, c
     assert (rest == 7.0).all()
 
 
+SPLIT_CONV_CASES = CONV_CASES + [
+    (8, 68, 68, 256, 128, 1, 1, 1, False),     # 128 x 128 tiles
+    (16, 68, 68, 128, 256, 3, 2, 1, False),    # 256 x 128 tiles, stride 2: padding on the top / left taps
+    (4, 136, 136, 64, 32, 1, 1, 1, True),      # 128 x 32 tiles, residual
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CONV_CASES)
+def test_conv_split_layer_matches_torch(dev, case):
+    """conv_igemm_split.hip (fp32 activations split into hi/lo fp16 pairs in registers, packed hi/lo weights, three fp16 MFMAs
+    per product group, fp32 accumulate) vs float64 convolution: same bound as the fp32-operand kernel."""
+    from orienmask_amd.pack import conv_weights_split
+    B, H, W, cin, cout, k, stride, leaky, use_res = case
+    L = omlib.load()
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.2
+    Ho, Wo = H // stride, W // stride
+    res = torch.randn(B, cout, Ho, Wo, generator=g) if use_res else None
+    want = torch.nn.functional.conv2d(x.double(), w.double(), None, stride, k // 2)
+    want = want * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if leaky:
+        want = torch.where(want > 0, want, want * 0.1)
+    if use_res:
+        want = want + res.double()
+    cpad = (cout + 31) // 32 * 32
+    ws, e = conv_weights_split(w, cpad)
+    sp = torch.zeros(cpad); sp[:cout] = scale
+    sp = (sp.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e.double())).float()
+    hp = torch.zeros(cpad); hp[:cout] = shift
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd, sd_, hd = ws.to(dev), sp.to(dev), hp.to(dev)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None
+    out = torch.full((B, Ho, Wo, cout), float("nan"), device=dev)
+    rc = L.om_conv2d_split(_p(xd), B, H, W, cin, cin, _p(wd), _p(sd_), _p(hd), cout, k, stride, leaky,
+                           _p(rd) if use_res else None, cout if use_res else 0, _p(out), cout, 0, 1,
+                           omlib.current_stream_ptr(dev))
+    omlib.check(rc, "om_conv2d_split")
+    got = out.cpu().permute(0, 3, 1, 2).double()
+    assert torch.isfinite(got).all()
+    err = _rel_err(got, want)
+    print("conv split %s: %.2e" % (case, err))
+    assert err < 2e-6, case
+
+
+@pytest.mark.parametrize("mode", ["upsample", "nchw"])
+def test_conv_split_output_modes(dev, mode):
+    """The split-operand kernel's other two epilogues: nearest up-sampling into a channel slice of a concat buffer, and the
+    NCHW orientation head (18 channels, no activation)."""
+    from orienmask_amd.pack import conv_weights_split
+    L = omlib.load()
+    g = torch.Generator().manual_seed(77)
+    B, H, W = 2, 6, 5
+    cin, cout, up, leaky = (256, 64, 4, 1) if mode == "upsample" else (256, 18, 1, 0)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.2
+    want = torch.nn.functional.conv2d(x.double(), w.double()) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if leaky:
+        want = torch.where(want > 0, want, want * 0.1)
+    cpad = (cout + 31) // 32 * 32
+    ws, e = conv_weights_split(w, cpad)
+    sp = torch.zeros(cpad); sp[:cout] = scale
+    sp = (sp.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e.double())).float()
+    hp = torch.zeros(cpad); hp[:cout] = shift
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd, sd_, hd = ws.to(dev), sp.to(dev), hp.to(dev)
+    if mode == "upsample":
+        want = torch.nn.functional.interpolate(want, scale_factor=float(up), mode="nearest")
+        buf = torch.full((B, H * up, W * up, 256), 7.0, device=dev)
+        view = buf[..., 128:]
+        rc = L.om_conv2d_split(_p(xd), B, H, W, cin, cin, _p(wd), _p(sd_), _p(hd), cout, 1, 1, leaky, None, 0,
+                               ctypes.c_void_p(view.data_ptr()), 256, 1, up, omlib.current_stream_ptr(dev))
+        omlib.check(rc, "om_conv2d_split")
+        got = buf[..., 128:128 + cout].cpu().permute(0, 3, 1, 2).double()
+        assert (torch.cat([buf[..., :128], buf[..., 128 + cout:]], -1) == 7.0).all()
+    else:
+        out = torch.full((B, cout, H, W), float("nan"), device=dev)
+        rc = L.om_conv2d_split(_p(xd), B, H, W, cin, cin, _p(wd), _p(sd_), _p(hd), cout, 1, 1, leaky, None, 0,
+                               _p(out), cout, 2, 1, omlib.current_stream_ptr(dev))
+        omlib.check(rc, "om_conv2d_split")
+        got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    assert _rel_err(got, want) < 2e-6
+
+
 WINO_CASES = [
     # B, H, W, cin, cout, leaky, residual
     (2, 16, 16, 32, 64, 1, True),
