@@ -174,6 +174,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (metric is quoted at 32)")
     ap.add_argument("--size", type=int, default=544)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-compare", action="store_true", help="split mode: skip the extra timed region with fp32 operands")
     ap.add_argument("--no-extras", action="store_true", help="skip the preprocess / COCO-format side measurements")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
     ap.add_argument("--heads", choices=("dense", "sparse"), default="dense",
@@ -193,9 +194,13 @@ def main():
     ap.add_argument("--lib", default=None,
                     help="path of another build of liborienmask_hip.so to load instead of the in-tree one (A/B runs of two "
                          "builds on the same GPU box: tools/ab_bench.sh)")
-    ap.add_argument("--dtype", choices=("f32", "f32_split", "f16"), default="f32",
-                    help="f32: the parity path and the headline metric (default).  f16: BASELINE configs[4], fp16 "
-                         "activations and weights with fp32 accumulation -- a separate, clearly labelled line")
+    ap.add_argument("--dtype", choices=("f32", "f32_split", "f16"), default="f32_split",
+                    help="f32_split (default): fp32 tensors and fp32 accumulation, every convolution product computed from hi/lo "
+                         "fp16 pairs of its fp32 operands on the fp16 matrix pipe (three MFMAs per product group; error against "
+                         "float64 equal to the fp32-operand kernels: profiles/r02_split_error.json) -- the headline metric, with "
+                         "the fp32-operand time reported beside it as `f32_operands`.  f32: fp32 operands on "
+                         "v_mfma_f32_32x32x2_f32 only.  f16: BASELINE configs[4], fp16 activations and weights with fp32 "
+                         "accumulation -- a separate, clearly labelled line")
     args = ap.parse_args()
     if args.in_flight is None:
         args.in_flight = 3 if args.dtype == "f16" else 2
@@ -227,6 +232,7 @@ def main():
     obj_bias = args.obj_bias if args.obj_bias is not None else (OBJ_BIAS if args.heads == "dense" else OBJ_BIAS_SPARSE)
     net = OrienMaskYOLOFPNPlus(3, 80).eval().set_precision(args.dtype)
     f16 = args.dtype == "f16"
+    split = args.dtype == "f32_split"
     sd = None
     if rank == 0:
         sd = synth.synth_state_dict(WEIGHT_SEED, obj_bias=obj_bias, head_gain=HEAD_GAIN)
@@ -315,6 +321,38 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = t.item()
+    # ---- split mode: the same K steps with fp32 operands (v_mfma_f32_32x32x2_f32 everywhere), for comparison
+    f32_operands = None
+    if split and not args.no_f32_compare:
+        net.set_precision("f32")
+        def timed(fn):
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            e_ = time.perf_counter() - t0_
+            if use_dist:
+                t_ = torch.tensor([e_], dtype=torch.float64, device=dev)
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                e_ = t_.item()
+            return e_
+        for _ in range(2):
+            step()
+        e1 = timed(lambda: [step() for _ in range(args.steps)])
+        e2 = e1
+        if args.in_flight > 1:
+            for _ in pipe.map(itertools.repeat(x, 2 * args.in_flight)):
+                pass
+            e2 = timed(lambda: [None for _ in pipe.map(itertools.repeat(x, args.steps))])
+        f32_operands = dict(value=round(world * B * args.steps / e2, 2), ms_per_step=round(e2 / args.steps * 1e3, 3),
+                            one_batch_in_flight=round(world * B * args.steps / e1, 2),
+                            note="the same K steps with precision 'f32': fp32 operands on v_mfma_f32_32x32x2_f32 (157 TFLOP/s "
+                                 "peak) in every convolution; same tensors in HBM, same postprocess")
+        net.set_precision(args.dtype)
     timed_fw //= max(args.streams, 1)                              # one om_forward per sub-batch
     dom_main_ms = sum(ms for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw      # per step, all launches
     dom_timed_ms = dom_main_ms + sum(pre for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw
@@ -330,6 +368,9 @@ def main():
         def reduction(k):
             # multiplies the matrix pipe executes per direct-convolution multiply: F(2x4,3x3) 24 per 8 outputs instead of 72,
             # F(2x2,3x3) 16 per 4 outputs instead of 36
+            # split operands: three fp16 matrix instructions per product group (F(2x4): 3 x 1/3 = the direct-convolution count)
+            if "split" in k:
+                return 1.0 if k.startswith("wino24") else 1.0 / 3.0
             return 3.0 if k.startswith("wino24") else (2.25 if k.startswith("wino") else 1.0)
 
         pre_kernel = {}
@@ -355,7 +396,8 @@ def main():
         total_bytes = sum(t["bytes"] for t in kern.values() if t["flops"] > 0)
         # ---- HBM traffic from the committed PMC passes, only if they were measured with THIS library binary
         traffic, traffic_src, conv_stack = None, None, None
-        pmc_file = os.path.join(REPO, "profiles", "r02_pmc_traffic_f16.json" if f16 else "r02_pmc_traffic.json")
+        pmc_file = os.path.join(REPO, "profiles", "r02_pmc_traffic_f16.json" if f16 else
+                                ("r02_pmc_traffic_f32_split.json" if split else "r02_pmc_traffic.json"))
         try:
             pmc = json.load(open(pmc_file))
             meta = pmc.pop("_meta", {})
@@ -401,7 +443,7 @@ def main():
             traffic_src = "no %s" % os.path.relpath(pmc_file, REPO)
         except Exception as e:      # a malformed file must not take the bench line down
             traffic_src = "could not read %s: %s" % (os.path.relpath(pmc_file, REPO), e)
-        peak_tf = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+        peak_tf = PEAK_F16_MFMA_TFLOPS if (f16 or split) else PEAK_F32_MFMA_TFLOPS
         alg_bytes_per_launch = d["bytes"] / d["launches"]      # layer-fused model: input once, output once, residual once, weights
         roofline = dict(bound="mfma", achieved=round(executed, 2), peak=peak_tf, unit="TFLOP/s",
                         frac=round(executed / peak_tf, 4), traffic=traffic, traffic_source=traffic_src,
@@ -416,6 +458,11 @@ def main():
                         achieved_without_pre_pass=round(executed_main_only, 2),
                         note=("fp16 operands, fp32 accumulate on v_mfma_f32_32x32x16_f16 (dense peak 2.5 PFLOP/s); direct "
                               "convolution, executed = algorithmic") if f16 else
+                             ("achieved = flops the fp16 matrix pipe executed (split operands: three v_mfma_f32_32x32x16_f16 per "
+                              "product group, i.e. 3 x 1/3 of the direct-convolution flops for Winograd F(2x4,3x3)) over the time of "
+                              "the GEMM kernel AND its input-transform pre-pass, against the dense fp16 peak.  The matrix pipe's "
+                              "minimum time for this kernel (executed flops / 2.5 PFLOP/s) and HBM's (algorithmic bytes / 8 TB/s) are "
+                              "within 5 % of each other; `hbm` holds the memory-side view of the same launches") if split else
                              ("achieved = flops the f32 matrix pipe executed (exact fp32 MFMA; Winograd F(2x4,3x3) runs 1/3 of the "
                               "direct-convolution multiplies) over the time of the GEMM kernel AND its input-transform pre-pass; "
                               "achieved_algorithmic counts direct-convolution flops over the same time"),
@@ -429,7 +476,20 @@ def main():
                         postprocess_occupancy=post_occupancy(B, post_config(H, W)),
                         binding=("fp16: matrix pipe and HBM are within 2x of each other (SURVEY.md 8d); forward_hbm_frac is the "
                                  "north_star's HBM-roofline figure") if f16 else
+                                ("split operands: 5.3x the fp32 matrix rate, so the forward's matrix-pipe minimum (executed flops / "
+                                 "2.5 PFLOP/s) and its HBM minimum (algorithmic bytes / 8 TB/s) are of the same size; the measured "
+                                 "HBM traffic (conv_stack_hbm_pmc) is the binding resource") if split else
                                 "fp32 FLOPs on the f32-input matrix cores; the HBM bound is several x further away")
+        if split:
+            roofline["hbm"] = dict(bound="hbm", unit="GB/s", peak=PEAK_HBM_GBS,
+                                   achieved=round(d["bytes"] / (dom_timed_ms * 1e-3) / 1e9, 1),
+                                   frac=round(d["bytes"] / (dom_timed_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                   traffic_gbs=round(traffic * d["launches"] / (dom_timed_ms * 1e-3) / 1e9, 1) if traffic else None,
+                                   traffic_frac=round(traffic * d["launches"] / (dom_timed_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if traffic else None,
+                                   note="the same launches (GEMM + pre-pass) against HBM: achieved = algorithmic bytes per launch "
+                                        "(layer input, output, residual and weights once) / time; traffic_* = the PMC bytes "
+                                        "(`traffic`) / time -- the transformed input is written and read through HBM, which is "
+                                        "what the algorithmic figure does not contain")
         if args.layers:
             for name, ms, pre in layer_ms:
                 wk = arch.layer_work(specs[name], B, H, W)
@@ -446,10 +506,13 @@ def main():
         metric = "images/sec end-to-end (544^2, bs=32) forward+postprocess"
         if f16:
             metric += " [fp16 activations, fp32 accumulate: BASELINE configs[4], NOT the headline fp32 metric]"
+        dtype_out = {"f32_split": "f32 (fp32 tensors and accumulation; products from hi/lo fp16 pairs of the fp32 operands, three "
+                                  "fp16 MFMAs per product group)",
+                     "f32": "f32 (fp32 operands on v_mfma_f32_32x32x2_f32)", "f16": "f16"}[args.dtype]
         line = dict(metric=metric, value=round(total_images / elapsed, 2),
                     unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
-                    vs_baseline=None, dtype=args.dtype, data="synthetic",
+                    vs_baseline=None, dtype=dtype_out, data="synthetic",
                     config=dict(workload="OrienMaskYOLOFPNPlus forward + OrienMaskYOLOPostProcess, %d x [3,%d,%d] per GPU "
                                          "(BASELINE configs[2]); seeded random-init weights (seed %d, obj_bias %g, head_gain %g): "
                                          "%s heads (dense: >400 candidates pass conf_thresh per image, NMS, 100 masks per image; "
@@ -474,6 +537,8 @@ def main():
             hbm_pmc_frac=round(conv_stack["bytes_per_step"] / step_s / 1e9 / PEAK_HBM_GBS, 4) if conv_stack else None,
             note="forward flops the matrix pipe executed / algorithmic forward bytes / PMC conv-stack bytes, each per step, over the "
                  "step time of the timed region behind `value` (forward + postprocess, batches_in_flight batches overlapping)")
+        if f32_operands is not None:
+            line["f32_operands"] = f32_operands
         if not args.no_extras:
             line["extras"] = measure_neighbours(dev, dets, B)
         if world == 1 and not args.no_cpu_baseline:

@@ -226,6 +226,9 @@ int om_conv2d_winograd24(const float* in, int B, int H, int W, int cin, int in_p
 int om_conv2d_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* w_split,
                     const float* scale_split, const float* shift, int cout, int ksize, int stride, int leaky, const float* res,
                     int res_pix_stride, float* out, int out_pix_stride, int out_mode, int up, om_stream stream);
+/* debugging / tile sweeps only (process-wide, not thread-safe): force the tile shape of conv_igemm_split.hip (256x128, 128x128,
+ * 128x64, 64x64, 128x32) for layers whose cout_pad it divides; 0, 0 restores the built-in choice. */
+int om_debug_split_tile(int bm, int bn);
 /* ... with split operands (om_model_set_precision mode 1): u_split as om_layer_info.wsplit_off describes, scale_split =
  * scale * 2^-e per output channel; scratch as for om_conv2d_winograd24. */
 int om_conv2d_winograd24_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* u_split,

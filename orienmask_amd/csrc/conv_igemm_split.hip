@@ -193,6 +193,9 @@ __global__ __launch_bounds__(256, (split_blocks_per_cu<BM, BN>())) void conv_ige
     const int fi = lane & 31, fk = lane >> 5;
     const int fsw = (fi >> 2) & 3;
 
+    // ONE chip-wide tile queue here: per-XCD queues as in conv_wino24.hip were measured on these layers and lost 5 % end to end
+    // (same-box A/B: forward kernels 19.6 -> 21.6 ms) -- most of them have one or two N tiles, so there is no panel to share and
+    // the static eighths only unbalance the last round.
     for (;;) {
         if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -352,7 +355,23 @@ static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hi
     return OM_OK;
 }
 
-void conv_tile_for_split(int M, int cout_pad, int* bm, int* bn) { conv_tile_for_f16(M, cout_pad, 0, bm, bn); }
+static int g_force_bm = 0, g_force_bn = 0;      // om_debug_split_tile: tile sweeps (tools/split_tile_sweep.py)
+void conv_split_force_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
+
+void conv_tile_for_split(int M, int cout_pad, int* bm, int* bn) {
+    if (g_force_bm && cout_pad % g_force_bn == 0) { *bm = g_force_bm; *bn = g_force_bn; return; }
+    // time over all tiles ~ tiles x tile area / how well the shape feeds the pipe (tools/split_tile_sweep.py on the forward's
+    // layer shapes: 128 x 128 is the fastest wherever cout allows it, 256 x 128 -- two workgroups per CU, 256 registers -- 9 %
+    // behind, then 128 x 64, 64 x 64, 128 x 32)
+    struct Cand { int bm, bn; double eff; };
+    const Cand cands[] = {{128, 128, 1.00}, {256, 128, 0.91}, {128, 64, 0.82}, {64, 64, 0.69}, {128, 32, 0.57}};
+    double best = 1e300;
+    for (const Cand& c : cands) {
+        if (cout_pad % c.bn) continue;
+        const double cost = (double)((M + c.bm - 1) / c.bm) * (cout_pad / c.bn) * c.bm * c.bn / c.eff;
+        if (cost < best) { best = cost; *bm = c.bm; *bn = c.bn; }
+    }
+}
 
 // a.w: packed hi/lo weights (include/orienmask_hip.h: om_layer_info.wsplit_off); a.scale: scale * 2^-e
 int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream) {

@@ -21,8 +21,9 @@
 
 #include "om_common.h"
 
-#ifndef OM_ABL
-#define OM_ABL 0
+#ifndef OM_W24_NBUF
+#define OM_W24_NBUF 4          // operand ring depth of the split-operand GEMM: 3 steps of LDS-DMA in flight (+2.7 % end to end
+                              // over 3 deep, same-box A/B); the fp32 form is built around 3
 #endif
 
 namespace om {
@@ -72,8 +73,13 @@ __global__ __launch_bounds__(256) void wino24_input_kernel(const float* __restri
     const int c4n = C >> 2;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int c4 = (int)(idx % c4n);
+#ifdef OM_W24_REV_PRE
+    const long long tile = (long long)T - 1 - idx / c4n;
+    if (tile < 0) return;
+#else
     const long long tile = idx / c4n;
     if (tile >= T) return;
+#endif
     const int b = (int)(tile / (TH * TW));
     const int r = (int)(tile - (long long)b * TH * TW);
     const int ty = r / TW, tx = r - ty * TW;
@@ -147,15 +153,19 @@ struct Wino24Params {
 //   3. finishes the tile whose head the PREVIOUS slot published long ago: it STARTS from those accumulators and continues
 //      with the remaining planes, so every output is the same sequence of fp32 operations as in an unsplit tile -- results do
 //      not depend on where a tile was cut (bit-identical to SK = false, batch-size invariant).
-// Slot numbers are drawn from the ticket word in start order, so a finisher never waits for a workgroup that has not started
-// (placement- and dispatch-order independent).  Needs tiles >= slots (a tile is cut at most once).
+// Slot numbers are drawn at start from eight per-XCD counters (slot = xcd + 8 k): slots s and s + slots / n_tiles walk the same
+// transformed-input panels at the same time and sit behind the same L2 (slots = 512, n_tiles a power of two; rocprofv3 PMC showed
+// 7 reads of V per launch from HBM with one chip-wide counter; +2 % end to end, same-box A/B).  All slots workgroups are resident
+// at once (grid = slots = 2 per CU), so a finisher's partner has started or starts without waiting for anyone; the wait is
+// bounded.  Needs tiles >= slots (a tile is cut at most once).
 template <bool SK, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params p) {
     constexpr int BM = 64, BN = 64, WM = 32, WN = 32;
     constexpr int NWN = BN / WN;
     constexpr int A_CH = BM / 32, B_CH = BN / 32, NP = A_CH + B_CH;
     constexpr int CH = BN / 4, RP = 256 / CH;
-    constexpr int NBUF = 3;
+    constexpr int NBUF = SPLIT ? OM_W24_NBUF : 3;
+    constexpr int PF = NBUF - 1;               // k-steps the LDS-DMA runs ahead
     __shared__ f32x4 smem[NBUF * (BM + BN) * 8 + 1];     // one LDS object (see conv_igemm.hip)
     int* const s_ticket = reinterpret_cast<int*>(smem + NBUF * (BM + BN) * 8);
 
@@ -173,7 +183,22 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
     // ---- stream-K: my slot and its unit range
     int slot = 0, t_lead = 0, x_lead = 0, t_trail = 0, x_trail = 0, t_full0 = 0, n_full = 0, nseg = 0;
     if constexpr (SK) {
-        if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+        // slot numbers congruent to the XCD id mod 8: slots s and s + slots / n_tiles (which walk the same panels at the same
+        // time) then sit behind the same L2 whenever slots / n_tiles is a multiple of 8
+        if (tid == 0) {
+            int x;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+            x &= 7;
+            // every XCD's counter hands out slots / 8 numbers; a workgroup beyond its XCD's share (placement is not promised to
+            // be even) takes one from another XCD's counter: slots numbers for slots workgroups, each drawn exactly once
+            int sl = 0;
+            for (int h = 0; h < 8; ++h) {
+                const int y = (x + h) & 7;
+                const int k = atomicAdd(p.ticket + y, 1);
+                if (k < (p.slots >> 3)) { sl = y + 8 * k; break; }
+            }
+            *s_ticket = sl;
+        }
         __syncthreads();
         slot = __builtin_amdgcn_readfirstlane(*s_ticket);
         const long long U = (long long)p.total_tiles * 24;
@@ -235,7 +260,11 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
         // n_tiles times a whole tile-time apart: +4 % on the whole set of layers).
         const int m_tiles = p.total_tiles / p.n_tiles;
         const int tile_n = SK ? tile / m_tiles : tile % p.n_tiles;
+#ifdef OM_W24_REV_GEMM
+        const int tile_m = m_tiles - 1 - (SK ? tile - tile_n * m_tiles : tile / p.n_tiles);
+#else
         const int tile_m = SK ? tile - tile_n * m_tiles : tile / p.n_tiles;
+#endif
         const int m0 = tile_m * BM, n0 = tile_n * BN;
         const int rows_valid = min(BM, p.T - m0);
 
@@ -312,7 +341,12 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
 #pragma unroll
         for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 1, 1 < ksteps);
         advance();                                          // fetch state = step 2
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NP) : "memory");   // step 0 landed, step 1 may still fly
+        if constexpr (PF > 2) {
+#pragma unroll
+            for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 2, 2 < ksteps);
+            advance();
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"((PF - 1) * NP) : "memory");   // step 0 landed, the later ones may still fly
         __builtin_amdgcn_s_barrier();
         read_frags(ca, cb, 0, 0);
         int xi = xb, cc = 0;
@@ -326,19 +360,12 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
             if constexpr (SPLIT) {
                 // six matrix instructions per k-step: per group of 16 channels hi*lo + lo*hi + hi*hi (fp32 accumulate)
                 f32x4 a2, b2, a3, b3;
-#if OM_ABL >= 5
-                if (p.T < 0) {
-#endif
                 read_frags(a2, b2, buf, 2);
                 read_frags(a3, b3, buf, 3);
-#if OM_ABL >= 5
-                } else { a2 = ca; b2 = cb; a3 = ca1; b3 = cb1; }
-#endif
-#if OM_ABL == 2 || OM_ABL >= 3
-                if (p.T < 0)
-#endif
+                const int bufp = buf + PF >= NBUF ? buf + PF - NBUF : buf + PF;      // step s+PF: last read during step s-1
+                const bool livep = s + PF < ksteps;
 #pragma unroll
-                for (int piece = 0; piece < NP; ++piece) issue_piece(piece, buf2, live2);
+                for (int piece = 0; piece < NP; ++piece) issue_piece(piece, bufp, livep);
                 const f16x8 ah = __builtin_bit_cast(f16x8, ca), al = __builtin_bit_cast(f16x8, ca1);
                 const f16x8 bh = __builtin_bit_cast(f16x8, cb), bl = __builtin_bit_cast(f16x8, cb1);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc, 0, 0, 0);
@@ -352,22 +379,10 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh2, ah2, acc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 // step s+1's operands have landed (only this step's NP pieces may still fly); my reads of `buf` are done
-#if OM_ABL >= 4
-                if (p.T < 0) {
-#endif
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NP) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"((PF - 1) * NP) : "memory");
                 __builtin_amdgcn_s_barrier();
-#if OM_ABL >= 4
-                }
-#endif
-#if OM_ABL >= 5
-                if (p.T < 0) {
-#endif
                 read_frags(ca, cb, buf1, 0);
                 read_frags(ca1, cb1, buf1, 1);
-#if OM_ABL >= 5
-                }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             } else {
 #pragma unroll
@@ -441,9 +456,6 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
             }
         }
 
-#if OM_ABL == 1 || OM_ABL >= 3
-        if (SPLIT && p.T >= 0) continue;
-#endif
         // ---- epilogue: row geometry once per tile; per pass of two output positions the residual loads are issued BEFORE the
         // LDS staging (they fly during it), C tiles [position][row][channel chunk ^ (row & 7)] go through LDS and leave as 16-byte
         // rows; the barriers wait for LDS only (a __syncthreads() would also drain the stores: ~2 us of HBM write latency per

@@ -65,6 +65,7 @@ int launch_conv_igemm(const ConvArgs& a, hipStream_t stream);
 // split-operand form (conv_igemm_split.hip): a.w = packed hi/lo fp16 weights, a.scale = scale * 2^-e
 int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream);
 void conv_tile_for_split(int M, int cout_pad, int* bm, int* bn);
+void conv_split_force_tile(int bm, int bn);
 
 // fp16-activation path (conv_igemm_f16.hip): in / w / res are fp16, scale / shift fp32, out fp16 unless out_f32.
 struct ConvArgsH {

@@ -676,6 +676,13 @@ int om_conv2d_mode(const float* in, int B, int H, int W, int cin, int in_pix_str
     return om::launch_conv_igemm(a, static_cast<hipStream_t>(stream));
 }
 
+int om_debug_split_tile(int bm, int bn) {
+    OM_REQUIRE((bm == 0 && bn == 0) || ((bm == 256 && bn == 128) || (bm == 128 && (bn == 128 || bn == 64 || bn == 32)) || (bm == 64 && bn == 64)),
+               OM_EINVAL, "om_debug_split_tile: %d x %d is not a built tile", bm, bn);
+    om::conv_split_force_tile(bm, bn);
+    return OM_OK;
+}
+
 int om_conv2d_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* w_split,
                     const float* scale_split, const float* shift, int cout, int ksize, int stride, int leaky, const float* res,
                     int res_pix_stride, float* out, int out_pix_stride, int out_mode, int up, om_stream stream) {

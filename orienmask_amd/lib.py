@@ -55,6 +55,7 @@ SIGNATURES = {
     "om_model_load_weights_split": (_i, [_vp, _vp, _sz]),
     "om_model_set_precision": (_i, [_vp, _i]),
     "om_model_get_precision": (_i, [_vp]),
+    "om_debug_split_tile": (_i, [_i, _i]),
     "om_conv2d_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "om_conv2d_winograd24_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "om_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i]),

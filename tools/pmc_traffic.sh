@@ -5,15 +5,19 @@
 # reports them).  On gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads: double it
 # (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is used as reported.
 set -e
-EXTRA=${1:-}          # e.g. "--dtype f16" (output then goes to gpurun_out/pmc_traffic_f16.json)
-TAG=$(echo "$EXTRA" | grep -q f16 && echo _f16 || echo "")
+EXTRA=${1:-}          # "" (the bench's default: split operands) -> gpurun_out/pmc_traffic_f32_split.json; "--dtype f32" ->
+                      # pmc_traffic.json; "--dtype f16" -> pmc_traffic_f16.json
+TAG=_f32_split
+echo "$EXTRA" | grep -q "dtype f32\b" && TAG=""
+echo "$EXTRA" | grep -q "dtype f32_split" && TAG=_f32_split
+echo "$EXTRA" | grep -q f16 && TAG=_f16
 R=$PWD
 export TMPDIR=/tmp
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$C
   rocprofv3 --kernel-trace --output-format csv --pmc $C -d $R/gpurun_out/pmc_$C -o pmc -- \
-    timeout 300 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 $EXTRA > /dev/null 2> $R/gpurun_out/pmc_$C.err || true
+    timeout 300 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-f32-compare --in-flight 1 $EXTRA > /dev/null 2> $R/gpurun_out/pmc_$C.err || true
 done
 cd $R
 TAG=$TAG python - <<'PY'
