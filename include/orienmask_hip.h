@@ -125,8 +125,9 @@ int om_model_load_weights(om_model* m, const void* packed_dev, size_t bytes, int
  *    absolute), i.e. ~4x an fp32 rounding; measured end to end in DESIGN.md 3.6.  Transformed inputs must stay below
  *    65504 in magnitude (activations below ~3000); weights are pre-scaled per output channel by the packer.
  *    Needs om_model_load_weights_split; activations between layers stay fp32.  The 1x1 and stride-2 layers run the same
- *    three-product form (conv_igemm_split.hip: activations are split in registers); the stem and forwards too small for
- *    the F(2x4) tiling (F(2x2) kernels) keep fp32 operands. */
+ *    three-product form (conv_igemm_split.hip: activations are split in registers); the stem keeps fp32 operands.  In this
+ *    mode the stride-1 3x3 layers run F(2x4,3x3) at EVERY size (mode 0 switches to F(2x2,3x3) below 1700 1/32-scale cells
+ *    per batch), so an image's outputs do not depend on the batch it is in. */
 size_t om_model_weight_split_words(const om_model* m);
 int om_model_load_weights_split(om_model* m, const void* packed_split_dev, size_t bytes);
 int om_model_set_precision(om_model* m, int mode);

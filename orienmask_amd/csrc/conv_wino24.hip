@@ -73,13 +73,8 @@ __global__ __launch_bounds__(256) void wino24_input_kernel(const float* __restri
     const int c4n = C >> 2;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int c4 = (int)(idx % c4n);
-#ifdef OM_W24_REV_PRE
-    const long long tile = (long long)T - 1 - idx / c4n;
-    if (tile < 0) return;
-#else
     const long long tile = idx / c4n;
     if (tile >= T) return;
-#endif
     const int b = (int)(tile / (TH * TW));
     const int r = (int)(tile - (long long)b * TH * TW);
     const int ty = r / TW, tx = r - ty * TW;
@@ -260,11 +255,7 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
         // n_tiles times a whole tile-time apart: +4 % on the whole set of layers).
         const int m_tiles = p.total_tiles / p.n_tiles;
         const int tile_n = SK ? tile / m_tiles : tile % p.n_tiles;
-#ifdef OM_W24_REV_GEMM
-        const int tile_m = m_tiles - 1 - (SK ? tile - tile_n * m_tiles : tile / p.n_tiles);
-#else
         const int tile_m = SK ? tile - tile_n * m_tiles : tile / p.n_tiles;
-#endif
         const int m0 = tile_m * BM, n0 = tile_n * BN;
         const int rows_valid = min(BM, p.T - m0);
 

@@ -226,8 +226,11 @@ struct om_model {
 
     // F(2x4,3x3) needs enough tiles to fill the chip: measured at 544^2, bs=4 is 4 % faster with F(2x2) and bs=8 is 4 % faster
     // with F(2x4); the switch is on the number of 1/32-scale cells in the batch (289 per 544^2 image).
-    static bool use_f24(int B, int H, int W) {
-        return (long long)B * (H / 32) * (W / 32) >= 1700ll;
+    // With split operands (precision 1) F(2x4) runs at every size: its matrix instructions are 5.3x cheaper than the fp32-operand
+    // F(2x2) kernel's, which outweighs idle workgroup slots at small batches -- and an image's results then do not depend on the
+    // batch it is in.
+    bool use_f24(int B, int H, int W) const {
+        return precision == 1 || (long long)B * (H / 32) * (W / 32) >= 1700ll;
     }
 
     size_t buf_floats(int i, int B, int H, int W) const {
@@ -482,7 +485,7 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             if (li.wino_off >= 0 && om::wino_enabled()) {
                 float* wino_scratch = reinterpret_cast<float*>(static_cast<char*>(workspace) + lay.scratch_off[&L - m->layers.data()]);
                 a.mid_event = ev_mid;
-                if (li.wino_planes == 24 && om_model::use_f24(B, H, W)) {
+                if (li.wino_planes == 24 && m->use_f24(B, H, W)) {
                     a.w = m->weights + li.wino_off;
                     if (m->precision == 1) {
                         a.w = m->weights_split + li.wsplit_off;
@@ -585,7 +588,7 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
     OM_REQUIRE(index >= 0 && index < (int)m->layers.size(), OM_EINVAL, "om_layer_tile: index %d", index);
     const om::LayerDef& L = m->layers[index];
     if (L.stem) { *bm = 0; *bn = 0; *algo = 0; return OM_OK; }
-    if (L.info.wino_off >= 0 && om::wino_enabled() && L.info.wino_planes == 24 && om_model::use_f24(B, H, W)) {
+    if (L.info.wino_off >= 0 && om::wino_enabled() && L.info.wino_planes == 24 && m->use_f24(B, H, W)) {
         *algo = m->precision == 1 ? 6 : 5; *bm = 64; *bn = 64;
         return OM_OK;
     }

@@ -44,12 +44,14 @@ class GraphedPipeline:
             self._launch()
         # everything the captured launches point into (see the module docstring)
         self._precision = model.precision
-        self._weights = (model._packed, model._packed16 if model.precision == "f16" else None)
+        self._weights = (model._packed, model._packed16 if model.precision == "f16" else None,
+                         model._packed_split if model.precision == "f32_split" else None)
         self._keepalive = list(model._workspace.values()) + list(postprocess._ws.values()) + [w for w in self._weights if w is not None]
 
     def _check_bindings(self):
         m = self.model
-        now = (m._packed, m._packed16 if m.precision == "f16" else None)
+        now = (m._packed, m._packed16 if m.precision == "f16" else None,
+               m._packed_split if m.precision == "f32_split" else None)
         if m.precision != self._precision or any(a is not b for a, b in zip(now, self._weights)):
             raise RuntimeError("GraphedPipeline: the model's weights or precision changed after capture; build a new "
                                "GraphedPipeline (the captured kernels read the packed blobs that were bound at capture time)")

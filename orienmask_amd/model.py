@@ -253,7 +253,7 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         # them on the caller's stream; images are independent, so the results are bit-identical to one launch
         n_sub = self.n_streams if (self.n_streams > 1 and B % self.n_streams == 0) else 1
         Bs = B // n_sub
-        key = (dev, Bs, H, W, f16, n_sub)
+        key = (dev, Bs, H, W, f16, n_sub, split)
         cache = self._workspace if self._slot == 0 else self._slot_workspaces.setdefault(self._slot, {})
         ws = cache.get(key)
         if ws is None:

@@ -62,13 +62,14 @@ def _check_detections(r, want_bbox, want_cls, want_mask, tag, exact_decode):
         assert _mask_iou(got_mask[k], want_mask[k]) >= 1 - 1e-4, (tag, k)
 
 
-def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol=5e-5, nms_post=100, mask_iou_min=0.999):
+def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol=5e-5, nms_post=100, mask_iou_min=0.999, flip_max=2):
     """HIP forward + HIP postprocess against the reference's forward + postprocess.  The two forwards differ by ~1e-6 of the
     head tensors' scale (another summation order), i.e. scores differ by up to a few 1e-5 relative, so the comparison is
     exact EXCEPT where the reference's own answer hinges on a gap smaller than that:
-      * detections are matched one to one (same class, box within 1e-4, mask IoU >= 0.999: a 1e-6 perturbation of the
-        orientation field flips a few boundary pixels of a mask of ~1e4 pixels; on identical heads the masks are identical,
-        see _check_detections) irrespective of position;
+      * detections are matched one to one (same class, box within 1e-4, mask IoU >= 0.999 or at most flip_max = 2 differing
+        pixels: a 1e-6 perturbation of the orientation field -- 1e-4 pixels where the offsets reach 100 -- flips a boundary
+        pixel in roughly one mask of ten, which is 1e-4 of a 544 x 544 mask but 2e-3 of the few-hundred-pixel masks of the
+        160 x 128 fixture; on identical heads the masks are identical, see _check_detections) irrespective of position;
       * position by position the scores agree within score_tol: detections may only trade places with near-ties;
       * when the list is cut at nms_post, a detection within score_tol of the last score may be replaced by its runner-up.
     Exact ties inside the reference's list (torch.topk / sort leave their order unspecified) are covered by the same rule."""
@@ -84,7 +85,8 @@ def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol
     unmatched = []
     for i in range(K):
         cand = np.nonzero((~used) & (got_cls == want_cls[i]) & (np.abs(got_bbox - want_bbox[i]).max(1) <= 1e-4))[0]
-        hit = [j for j in cand if _mask_iou(got_mask[j], want_mask[i]) >= mask_iou_min]
+        hit = [j for j in cand if _mask_iou(got_mask[j], want_mask[i]) >= mask_iou_min or
+               np.count_nonzero(got_mask[j].astype(bool) != want_mask[i].astype(bool)) <= flip_max]
         if hit:
             used[hit[0]] = True
         else:
@@ -528,6 +530,22 @@ def test_forward_is_batch_invariant(dev):
         assert torch.isfinite(fb).all() and torch.isfinite(fo).all()
 
 
+def test_forward_split_is_batch_invariant(dev):
+    """With split operands every size runs the same kernels (F(2x4) at any batch, one summation order per output element in
+    the implicit GEMM whatever the tile shape), so an image's head tensors are bit-identical alone, in a batch of 3 and in a
+    batch of 7 -- across the size where precision 'f32' switches from F(2x2) to F(2x4) (and is only equal to ~1e-6)."""
+    sd = synth.synth_state_dict(9, obj_bias=-16.0, head_gain=4.0)
+    x = synth.synth_image_batch(31, 7, 544, 544).to(dev)
+    net = _hip_model(sd, dev, "f32_split")
+    assert dict(net.layer_kernels(1, 544, 544))["orien_head.2"].endswith("split>")
+    with torch.no_grad():
+        full = [(b.clone(), o.clone()) for b, o in net(x)]
+        for idx in ([6], [2, 6, 4]):
+            part = net(x[idx])
+            for (fb, fo), (pb, po) in zip(full, part):
+                assert torch.equal(fb[idx], pb) and torch.equal(fo[idx], po), idx
+
+
 def test_forward_across_the_winograd_switch(dev):
     """The same image in a batch of 2 (F(2x2,3x3)) and in a batch of 7 (F(2x4,3x3)): not bit-identical, but far inside the
     parity budget, and the composed detections agree in every index."""
@@ -953,7 +971,7 @@ def test_coco_formatter_end_to_end(dev):
             i += 1
 
 
-@pytest.mark.parametrize("batch,prec", [(1, "f32"), (4, "f32"), (2, "f16")])
+@pytest.mark.parametrize("batch,prec", [(1, "f32"), (4, "f32"), (2, "f16"), (6, "f32_split")])
 def test_graphed_pipeline_matches_eager(dev, batch, prec):
     """hipGraph replay of forward + postprocess == the eager call sequence, bit for bit.  Replays run back to back
     on fresh inputs with no eager call on the same workspaces in between (an eager call re-clears the tile-queue
@@ -1206,15 +1224,16 @@ def test_forward_on_side_streams_is_bit_identical(dev, prec):
                 assert torch.equal(ga, wa) and torch.equal(gb, wb_)
 
 
-@pytest.mark.parametrize("prec,depth", [("f32", 2), ("f16", 3)])
-def test_in_flight_pipeline_matches_eager(dev, prec, depth):
+@pytest.mark.parametrize("prec,depth,bs0", [("f32", 2, 2), ("f16", 3, 2), ("f32_split", 2, 6)])
+def test_in_flight_pipeline_matches_eager(dev, prec, depth, bs0):
     """InFlightPipeline (whole batches on alternating HIP streams, own workspaces per slot) returns, in submission order,
-    exactly what the one-batch-at-a-time loop returns; different batch sizes pass through the same slots."""
+    exactly what the one-batch-at-a-time loop returns; different batch sizes pass through the same slots.  (Split operands with
+    batches of 6 / 7: the F(2x4) kernels, incl. their stream-K form with its inter-workgroup hand-off, beside another batch.)"""
     from orienmask_amd.pipeline import InFlightPipeline
     sd = synth.synth_state_dict(3, obj_bias=-16.0, head_gain=4.0)
     net, net_ref = _hip_model(sd, dev).set_precision(prec), _hip_model(sd, dev).set_precision(prec)
     post, post_ref = _hip_post((544, 544), dev), _hip_post((544, 544), dev)
-    xs = [synth.synth_image_batch(900 + i, 2 + (i % 2), 544, 544).to(dev) for i in range(7)]
+    xs = [synth.synth_image_batch(900 + i, bs0 + (i % 2), 544, 544).to(dev) for i in range(7)]
     pipe = InFlightPipeline(net, post, depth=depth)
     got = [[{k: v.clone() for k, v in d.items()} for d in dets] for dets in pipe.map(xs)]
     assert len(pipe) == 0 and len(got) == len(xs)
@@ -1239,7 +1258,7 @@ def test_in_flight_pipeline_matches_eager(dev, prec, depth):
         pipe.submit(xs[0].cpu())
 
 
-@pytest.mark.parametrize("prec,other", [("f32", "f16"), ("f32", "f32"), ("f16", "f16")])
+@pytest.mark.parametrize("prec,other", [("f32", "f16"), ("f32", "f32"), ("f16", "f16"), ("f32_split", "f32_split")])
 def test_postprocess_and_forward_are_stable_beside_other_streams(dev, prec, other):
     """Kernels of two HIP streams share compute units (InFlightPipeline relies on it).  Results must not depend on what the
     other stream runs: the postprocess of a fixed prediction and a forward of a fixed batch are repeated while a second
@@ -1250,8 +1269,9 @@ def test_postprocess_and_forward_are_stable_beside_other_streams(dev, prec, othe
     net = _hip_model(sd, dev).set_precision(prec)
     busy = _hip_model(sd, dev).set_precision(other)
     post = _hip_post((544, 544), dev)
-    x = synth.synth_image_batch(900, 2, 544, 544).to(dev)
-    y = synth.synth_image_batch(901, 1, 544, 544).to(dev)
+    split = prec == "f32_split"           # batches of 6: the F(2x4) split-operand kernels (wide-K fp16 matrix instructions everywhere)
+    x = synth.synth_image_batch(900, 6 if split else 2, 544, 544).to(dev)
+    y = synth.synth_image_batch(901, 6 if split else 1, 544, 544).to(dev)
     s0, s1 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     with torch.no_grad():
         pred = net(x)
@@ -1262,7 +1282,7 @@ def test_postprocess_and_forward_are_stable_beside_other_streams(dev, prec, othe
         torch.cuda.synchronize()
         for it in range(8):
             with torch.cuda.stream(s1):
-                for _ in range(6 if other == "f16" else 2):
+                for _ in range(6 if other == "f16" else (3 if split else 2)):
                     busy(y)
             with torch.cuda.stream(s0):
                 outs = post.launch(pred)

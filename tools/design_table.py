@@ -1,43 +1,52 @@
-"""Regenerate the table of DESIGN.md section 5.0 from the committed bench lines and rocprofv3 stats under profiles/.
-usage: python tools/design_table.py [round tag, default r02]   (rewrites DESIGN.md in place)"""
-import csv, json, os, sys
+"""Regenerate the table of DESIGN.md section 5.0 from the committed bench lines under profiles/ (between the markers
+<!-- table5.0 --> and <!-- /table5.0 -->).  usage: python tools/design_table.py [round tag, default r02]"""
+import csv
+import json
+import os
+import sys
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 P = lambda n: os.path.join(REPO, "profiles", "%s_%s" % (tag, n))
-d = json.load(open(P("bench.json"))); r = d["roofline"]; c = d["cpu_baseline"]
-h = json.load(open(P("bench_f16.json"))); sp = json.load(open(P("bench_sparse_heads.json")))
-st = r["conv_stack_hbm_pmc"]
+J = lambda n: json.loads(open(P(n)).readline())
+d, e, h, sp = J("bench.json"), J("bench_f32_operands.json"), J("bench_f16.json"), J("bench_sparse_heads.json")
+r, re_, c = d["roofline"], e["roofline"], d["cpu_baseline"]
 tot = n = 0
 for row in csv.DictReader(open(P("rocprofv3_kernel_stats.csv"))):
-    if r["kernel"].split("<")[0] in row["Name"]:
+    if "wino24_gemm_kernel" in row["Name"] and "true>" in row["Name"].split("(")[0]:      # the split instantiations <SK, true>
         tot += float(row["TotalDurationNs"]); n += int(row["Calls"])
-rp = round(tot / n / 1e6, 3)
+rp = round(tot / max(n, 1) / 1e6, 4)
+st, ste = r["conv_stack_hbm_pmc"], re_["conv_stack_hbm_pmc"]
 sw = c["thread_sweep_forward_bs1_ms"]
-step_row = ""
-if "step" in r and "step" in h["roofline"]:
-    a, b = r["step"], h["roofline"]["step"]
-    step_row = ("| whole step (`roofline.step`, over the step time behind `value`) | fp32: %s TF executed = %s of the matrix peak, PMC "
-                "conv-stack bytes %s GB/s = %s of 8 TB/s (algorithmic %s); fp16: %s TF = %s of 2.5 PF, PMC %s GB/s = %s of 8 TB/s "
-                "(algorithmic %s) |\n" % (a["executed_tflops"], a["executed_frac"], a["hbm_pmc_gbs"], a["hbm_pmc_frac"], a["hbm_algorithmic_frac"],
-                                          b["executed_tflops"], b["executed_frac"], b["hbm_pmc_gbs"], b["hbm_pmc_frac"], b["hbm_algorithmic_frac"]))
-rows = '''| end-to-end, two batches in flight (`value`) | **%s images/s** (%s ms/step); round 1: 990. Sparse heads (`--heads sparse`, ~25 detections per image, `%s_bench_sparse_heads.json`): %s |
-| end-to-end, one batch at a time (`one_batch_in_flight`) | %s images/s (%s ms/step; forward kernels %s ms, postprocess kernels %s ms) |
-| `roofline` (what the hardware did) | dominant kernel `%s`, %d launches/step incl. their input-transform pre-pass: **%s TFLOP/s executed = %s of the 157.3 TF f32-MFMA peak**; without the pre-pass %s TF (%s); the direct-convolution ("algorithmic") rate of the same layers is %s TF and is reported as `achieved_algorithmic`, no longer as `frac` (round 1 printed 1.66). Avg launch %s ms (HIP events in the timed one-at-a-time region) vs %s ms (rocprofv3, all variants weighted) |
-| algorithmic bytes per launch / PMC traffic | %.2f GB algorithmic (layer-fused model, §3) vs %s GB measured per launch (GEMM + pre-pass; `(2·FETCH_SIZE + WRITE_SIZE)·1024`, separate `--pmc` passes): the transformed input V (3× the activation) is written once and re-fetched once per 64-channel N tile. `traffic` is printed only when `profiles/%s_pmc_traffic.json` was measured with the library binary that is running (sha256 in `_meta`), else null |
-| conv stack HBM (north_star: "rocprof-reported HBM GB/s for the conv stack") | `roofline.conv_stack_hbm_pmc`: %s GB per step over %s ms of convolution kernels = **%s GB/s = %s of 8 TB/s** by PMC; algorithmic (layer-fused) %s GB/s = %s — the fp32 forward is FLOP-bound (forward overall %s TF executed = %s of the matrix peak) |
-%s| postprocess occupancy (north_star: "occupancy for NMS/mask-assembly") | §3.2 last bullet; `roofline.postprocess_occupancy` in the bench line |
-| cpu_baseline (oracle, GPU box's host, 256 hardware threads) | thread sweep on one image (forward): 8 → %.0f ms, 16 → %.0f ms, 32 → %.0f ms, 64 → %.0f ms (256 threads took 69.7 s: the sweep is capped at 64); best: %s images/s end to end on %s threads; bs=1 forward %s ms, postprocess %s ms (the oracle's decode runs single-threaded for reproducibility, §3.2); reported baseline, not a target |
-| fp16 configuration (`--dtype f16`, `%s_bench_f16.json`) | %s images/s (bs=32) with two batches in flight, %s one at a time (kernels unchanged from round 1); now also tested at its own bs=64 |
-''' % (d["value"], d["ms_per_step"], tag, sp["value"], d["one_batch_in_flight"]["value"], d["one_batch_in_flight"]["ms_per_step"],
-       r["forward_kernels_ms_per_step"], r["postprocess_ms_per_step"], r["kernel"], r["launches_per_step"],
-       r["achieved"], r["frac"], r["achieved_without_pre_pass"], round(r["achieved_without_pre_pass"] / r["peak"], 3),
-       r["achieved_algorithmic"], r["avg_launch_ms"], rp, r["algorithmic_bytes_per_launch"] / 1e9, round(r["traffic"] / 1e9, 2) if r["traffic"] else "n/a", tag,
-       round(st["bytes_per_step"] / 1e9, 1), st["kernels_ms_per_step"], st["gbs"], st["frac_of_8tbs"],
-       r["forward_hbm_algorithmic_gbs"], r["forward_hbm_frac"], r["forward_tflops_executed"], r["forward_executed_frac"], step_row,
-       sw["8"], sw["16"], sw["32"], sw["64"], c["value"], c["cores"], c["bs1"]["forward_ms"], c["bs1"]["postprocess_ms"],
+G = lambda b: round(b / 1e9, 2) if b else "n/a"
+rows = """| | value |
+|---|---|
+| end-to-end, split operands, two batches in flight (`value`) | **%s images/s** (%s ms/step); sparse heads (`--heads sparse`, ~25 detections per image): %s |
+| ... one batch at a time (`one_batch_in_flight`) | %s images/s (%s ms/step; forward kernels %s ms, postprocess kernels %s ms) |
+| the same steps with fp32 operands (`f32_operands` in the same line; `%s_bench_f32_operands.json` is `bench.py --dtype f32`) | %s / %s images/s in the default run; %s / %s in its own run (round 1: 990) |
+| `roofline`, split operands | dominant kernel `%s`, %d launches/step, charged with their input-transform pre-pass: **%s TFLOP/s executed on the fp16 pipe = %s of 2.5 PF** (without the pre-pass %s TF); avg launch %s ms by HIP events in the timed region vs %s ms by rocprofv3 (`%s_rocprofv3_kernel_stats.csv`, both split instantiations weighted). Against HBM (`roofline.hbm`): %s GB/s algorithmic = %s of 8 TB/s; PMC traffic %s GB per launch against %s GB algorithmic = %s GB/s = **%s of 8 TB/s** over the same time |
+| `roofline`, fp32 operands | `%s`: %s TFLOP/s executed = %s of the 157.3 TF f32-MFMA peak incl. the pre-pass (%s without); PMC traffic %s GB per launch |
+| conv stack HBM by PMC (north_star: "rocprof-reported HBM GB/s for the conv stack") | split: %s GB per step over %s ms of convolution kernels = **%s GB/s = %s of 8 TB/s** (algorithmic %s GB/s = %s); fp32 operands: %s GB over %s ms = %s GB/s = %s |
+| whole step (`roofline.step`, over the step time behind `value`) | split: %s TF executed = %s of 2.5 PF, PMC conv-stack bytes %s GB/s = **%s of 8 TB/s** (algorithmic %s); fp32 operands: %s TF = %s of 157.3 TF, PMC %s GB/s = %s; fp16 configuration: %s TF = %s of 2.5 PF, PMC %s GB/s = %s |
+| postprocess occupancy (north_star: "occupancy for NMS/mask-assembly") | §3.2 last bullet; `roofline.postprocess_occupancy` in the bench line |
+| cpu_baseline (oracle, GPU box's host, %s hardware threads) | thread sweep on one image (forward): %s; best: %s images/s end to end on %s threads; bs=1 forward %s ms, postprocess %s ms (the oracle's decode runs single-threaded for reproducibility, §3.2); reported baseline, not a target |
+| fp16 configuration (`--dtype f16`, `%s_bench_f16.json`) | %s images/s (bs=32) with three batches in flight, %s one at a time (kernels unchanged this round) |
+""" % (d["value"], d["ms_per_step"], sp["value"], d["one_batch_in_flight"]["value"], d["one_batch_in_flight"]["ms_per_step"],
+       r["forward_kernels_ms_per_step"], r["postprocess_ms_per_step"],
+       tag, d["f32_operands"]["value"], d["f32_operands"]["one_batch_in_flight"], e["value"], e["one_batch_in_flight"]["value"],
+       r["kernel"], r["launches_per_step"], r["achieved"], r["frac"], r["achieved_without_pre_pass"], r["avg_launch_ms"], rp, tag,
+       r["hbm"]["achieved"], r["hbm"]["frac"], G(r["traffic"]), G(r["algorithmic_bytes_per_launch"]), r["hbm"]["traffic_gbs"], r["hbm"]["traffic_frac"],
+       re_["kernel"], re_["achieved"], re_["frac"], round(re_["achieved_without_pre_pass"] / re_["peak"], 3), G(re_["traffic"]),
+       G(st["bytes_per_step"]), st["kernels_ms_per_step"], st["gbs"], st["frac_of_8tbs"], r["forward_hbm_algorithmic_gbs"], r["forward_hbm_frac"],
+       G(ste["bytes_per_step"]), ste["kernels_ms_per_step"], ste["gbs"], ste["frac_of_8tbs"],
+       r["step"]["executed_tflops"], r["step"]["executed_frac"], r["step"]["hbm_pmc_gbs"], r["step"]["hbm_pmc_frac"], r["step"]["hbm_algorithmic_frac"],
+       re_["step"]["executed_tflops"], re_["step"]["executed_frac"], re_["step"]["hbm_pmc_gbs"], re_["step"]["hbm_pmc_frac"],
+       h["roofline"]["step"]["executed_tflops"], h["roofline"]["step"]["executed_frac"], h["roofline"]["step"]["hbm_pmc_gbs"], h["roofline"]["step"]["hbm_pmc_frac"],
+       c["host_cpus"], ", ".join("%s -> %.0f ms" % (k, v) for k, v in sw.items()), c["value"], c["cores"], c["bs1"]["forward_ms"], c["bs1"]["postprocess_ms"],
        tag, h["value"], h["one_batch_in_flight"]["value"])
 path = os.path.join(REPO, "DESIGN.md")
 s = open(path).read()
-a = s.index("| end-to-end, two batches in flight (`value`)"); b = s.index("History of round 2 (same bench line)")
-open(path, "w").write(s[:a] + rows + "\n" + s[b:])
+a, b = s.index("<!-- table5.0 -->"), s.index("<!-- /table5.0 -->")
+s = s[:a] + "<!-- table5.0 -->\n" + rows + s[b:]
+open(path, "w").write(s)
 print(rows)

@@ -25,14 +25,20 @@ def rms(a, b):
 
 
 def main():
+    import numpy as np
     dev = torch.device("cuda", 0)
     out = {}
-    for tag, (wseed, bias, gain) in {"bench weights": (3, -16.0, 4.0), "unsaturated heads": (3, -3.0, 0.7)}.items():
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "fwd_f160x128_b1.npz"))
+    cases = {"bench weights, 544x544, batch of 6": (3, -16.0, 4.0, 1000, 6, 544, 544),
+             "fixture fwd_f160x128_b1 (one 160x128 image)": (int(g["wseed"]), float(g["obj_bias"]), float(g["head_gain"]), int(g["xseed"]),
+                                                            1, int(g["size"][0]), int(g["size"][1]))}
+    for tag, (wseed, bias, gain, xseed, nb, hh, ww) in cases.items():
         sd = synth.synth_state_dict(wseed, obj_bias=bias, head_gain=gain)
-        x = synth.synth_image_batch(1000, 6, 544, 544)
+        x = synth.synth_image_batch(xseed, nb, hh, ww)
         sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
-        truth = R.forward(sd64, x[:2].double())
-        ref32 = R.forward(sd, x[:2])
+        nk = min(2, nb)
+        truth = R.forward(sd64, x[:nk].double())
+        ref32 = R.forward(sd, x[:nk])
         rec = {"reference fp32 (torch CPU)": dict(max=max(max(rel(a, c), rel(b, d)) for (a, b), (c, d) in zip(ref32, truth)),
                                                    rms=max(max(rms(a, c), rms(b, d)) for (a, b), (c, d) in zip(ref32, truth)))}
         for prec in ("f32", "f32_split"):
@@ -42,8 +48,8 @@ def main():
             with torch.no_grad():
                 got = net(x.to(dev))
             torch.cuda.synchronize()
-            rec["HIP " + prec] = dict(max=max(max(rel(a[:2].cpu(), c), rel(b[:2].cpu(), d)) for (a, b), (c, d) in zip(got, truth)),
-                                      rms=max(max(rms(a[:2].cpu(), c), rms(b[:2].cpu(), d)) for (a, b), (c, d) in zip(got, truth)))
+            rec["HIP " + prec] = dict(max=max(max(rel(a[:nk].cpu(), c), rel(b[:nk].cpu(), d)) for (a, b), (c, d) in zip(got, truth)),
+                                      rms=max(max(rms(a[:nk].cpu(), c), rms(b[:nk].cpu(), d)) for (a, b), (c, d) in zip(got, truth)))
         out[tag] = rec
     print(json.dumps(out, indent=1))
 
