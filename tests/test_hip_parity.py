@@ -412,6 +412,35 @@ def test_winograd24_split_layer_matches_torch(dev, case):
     assert errs["split"] <= 2 * errs["f32"] + 1e-6, (case, errs)
 
 
+@pytest.mark.parametrize("gain,finite", [(100.0, True), (3.0e4, False)])
+def test_split_operand_range(dev, gain, finite):
+    """The documented range of split operands (include/orienmask_hip.h: om_model_set_precision): activations 100x larger than a
+    BatchNorm-ed network produces are still exact to fp32 level (the error is relative, so it does not grow with the scale),
+    and inputs whose transform exceeds fp16's 65504 give non-finite outputs -- loud, never a silently wrong number."""
+    from orienmask_amd.pack import winograd_weights_split
+    B, H, W, cin, cout = 2, 16, 20, 64, 64
+    L = omlib.load()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, cin, H, W, generator=g) * gain
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    want = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+    us, e = winograd_weights_split(w, cout)
+    sps = torch.pow(torch.tensor(2.0, dtype=torch.float64), -e.double()).float().to(dev)
+    hd = torch.zeros(cout, device=dev)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    out = torch.full((B, H, W, cout), float("nan"), device=dev)
+    scratch = torch.empty(L.om_conv2d_winograd24_scratch_bytes(B, H, W, cin), dtype=torch.uint8, device=dev)
+    rc = L.om_conv2d_winograd24_split(_p(xd), B, H, W, cin, cin, _p(us.to(dev)), _p(sps), _p(hd), cout, 0, None, 0, _p(out), cout,
+                                      _p(scratch), scratch.numel(), omlib.current_stream_ptr(dev))
+    omlib.check(rc, "om_conv2d_winograd24_split")
+    got = out.cpu().permute(0, 3, 1, 2).double()
+    if finite:
+        assert torch.isfinite(got).all()
+        assert _rel_err(got, want) < 5e-6
+    else:
+        assert not torch.isfinite(got).all()
+
+
 def test_stem_matches_torch(dev):
     L = omlib.load()
     g = torch.Generator().manual_seed(3)
