@@ -16,7 +16,7 @@ for C in "${GROUPS_[@]}"; do
   i=$((i+1))
   rm -rf $R/gpurun_out/pmcb_${TAG}_$i
   timeout 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmcb_${TAG}_$i -o p -- \
-    python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 $EXTRA > /dev/null 2> $R/gpurun_out/pmcb_${TAG}_$i.err || echo "pass $i failed"
+    python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-f32-compare --in-flight 1 $EXTRA > /dev/null 2> $R/gpurun_out/pmcb_${TAG}_$i.err || echo "pass $i failed"
 done
 cd $R
 TAG=$TAG python - <<'PY' | tee gpurun_out/pmcb_$TAG.txt
