@@ -325,3 +325,52 @@ def test_split_f16_pairs_layout_and_accuracy():
     scale = float(want.abs().max())
     assert float((got - want).abs().max()) / scale < 2e-7
     assert float(((v @ u[3, :70].float().T).double() - want).abs().max()) / scale > float((got - want).abs().max()) / scale
+
+
+def test_pack_state_dict_split_covers_every_layer(built):
+    """The split blob (om_model_load_weights_split): every layer but the stem has a slice, slices do not overlap and fill the
+    blob up to alignment, and hi + lo times the per-channel scale reproduces the fp32 blob's weights (one 1x1 layer in the
+    implicit-GEMM order, one stride-1 3x3 layer in the F(2x4) order) and folded BatchNorm scales."""
+    import torch
+    from orienmask_amd.model import OrienMaskYOLOFPNPlus
+    net = OrienMaskYOLOFPNPlus(3, 80)
+    sd = synth.synth_state_dict(4)
+    net.load_state_dict(sd, strict=True)
+    h = net._ensure_handle()
+    L = omlib.load()
+    layers = net._layers
+    total = L.om_model_weight_split_words(h)
+    blob32 = pack.pack_state_dict(sd, layers, L.om_model_weight_floats(h))
+    blob = pack.pack_state_dict_split(sd, layers, total, blob32)
+    assert blob.numel() == total and torch.isfinite(blob).all()
+    spans = []
+    for l in layers:
+        if l["name"] == "backbone.conv1":
+            assert l["wsplit_off"] == -1
+            continue
+        n = (24 if l["wino_planes"] == 24 else l["ksize"] ** 2) * l["cout_pad"] * l["cin"]
+        spans.append((l["wsplit_off"], l["wsplit_off"] + n))
+        spans.append((l["wsplit_scale_off"], l["wsplit_scale_off"] + l["cout_pad"]))
+    spans.sort()
+    assert spans[0][0] == 0 and all(a[1] <= b[0] < a[1] + 4 for a, b in zip(spans, spans[1:])) and total - spans[-1][1] < 4
+    perm = torch.tensor(pack._SPLIT_PERM)
+    for name in ("backbone.conv4.1.conv.0", "neck8.1"):
+        l = next(x for x in layers if x["name"] == name)
+        cpad, cin, cout = l["cout_pad"], l["cin"], l["cout"]
+        scale32 = blob32[l["scale_off"]:l["scale_off"] + cpad].double()
+        scale_s = blob[l["wsplit_scale_off"]:l["wsplit_scale_off"] + cpad].double()
+        ratio = (scale32[:cout] / scale_s[:cout])                      # = 2^e, exactly
+        assert torch.equal(ratio, torch.pow(torch.tensor(2.0, dtype=torch.float64), torch.round(torch.log2(ratio))))
+        if l["wino_planes"] == 24:
+            halfs = blob[l["wsplit_off"]:l["wsplit_off"] + 24 * cpad * cin].view(torch.float16).reshape(24, cpad, cin // 16, 2, 16).double()
+            back = (halfs[..., 0, :] + halfs[..., 1, :]).reshape(24, cpad, cin)[:, :cout] / ratio.view(1, -1, 1)
+            want = blob32[l["wino_off"]:l["wino_off"] + 24 * cpad * cin].reshape(24, cpad, cin)[:, :cout].double()
+        else:
+            k2 = l["ksize"] ** 2
+            halfs = blob[l["wsplit_off"]:l["wsplit_off"] + k2 * cpad * cin].view(torch.float16).reshape(cpad, k2, cin // 16, 2, 2, 8).double()
+            grp = torch.empty(cpad, k2, cin // 16, 16, dtype=torch.float64)
+            grp[..., perm] = (halfs[..., 0, :, :] + halfs[..., 1, :, :]).reshape(cpad, k2, cin // 16, 16)
+            back = grp.reshape(cpad, k2 * cin)[:cout] / ratio.view(-1, 1)
+            want = blob32[l["w_off"]:l["w_off"] + cout * k2 * cin].reshape(cout, k2 * cin).double()
+        amax = want.abs().amax()
+        assert float((back - want).abs().max() / amax) < 2.0 ** -20, name
