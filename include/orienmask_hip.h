@@ -122,7 +122,7 @@ int om_model_load_weights(om_model* m, const void* packed_dev, size_t bytes, int
  * 1: SPLIT operands.  Every fp32 operand x is carried as hi = fp16(x), lo = fp16(x - hi) and a product is
  *    hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (the lo*lo term, <= 2^-22 of the product, is
  *    dropped): 5.3x the matrix rate at the same bytes per element.  Representation error <= 2^-22 |x| (floor 2^-25
- *    absolute), i.e. ~4x an fp32 rounding; measured end to end in DESIGN.md 3.6.  Transformed inputs must stay below
+ *    absolute), i.e. ~4x an fp32 rounding; measured end to end in DESIGN.md 3.5.  Transformed inputs must stay below
  *    65504 in magnitude (activations below ~3000); weights are pre-scaled per output channel by the packer.
  *    Needs om_model_load_weights_split; activations between layers stay fp32.  The 1x1 and stride-2 layers run the same
  *    three-product form (conv_igemm_split.hip: activations are split in registers); the stem keeps fp32 operands.  In this

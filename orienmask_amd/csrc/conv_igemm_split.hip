@@ -8,7 +8,7 @@
 //
 // The f32-input matrix instruction (v_mfma_f32_32x32x2_f32) peaks at 157 TFLOP/s, the fp16 one at 2.5 PFLOP/s: three fp16
 // instructions per product group are 5.3x faster than the fp32 form, at fp32-level accuracy (measured against float64:
-// tools/split_error.py, DESIGN.md 3.6) -- the 1x1 and stride-2 layers stop being bound by the matrix pipe.
+// tools/split_error.py, DESIGN.md 3.5) -- the 1x1 and stride-2 layers stop being bound by the matrix pipe.
 //
 // Same layer as conv_igemm.hip (Conv2d -> BatchNorm2d(eval) -> LeakyReLU(0.1), residual add, nearest upsample, concat by
 // slice, NCHW orientation head: /root/reference/model/base.py:95-137, backbone/darknet.py:14-15,

@@ -36,7 +36,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// SPLIT operands (precision mode "f32_split", DESIGN.md 3.6): every fp32 operand x of the 24 GEMMs is carried as two fp16
+// SPLIT operands (precision mode "f32_split", DESIGN.md 3.5): every fp32 operand x of the 24 GEMMs is carried as two fp16
 // numbers hi = fp16(x), lo = fp16(x - hi) (x = hi + lo to ~2^-22 |x|, absolute floor 2^-25), and a product is
 // hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation: three matrix instructions of 32 cycles for
 // 16 channels instead of eight v_mfma_f32_32x32x2_f32 of 64 cycles -- 5.3x the matrix rate of the f32-input pipe at the
