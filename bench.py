@@ -42,6 +42,7 @@ ANCHOR_MASK = [[6, 7, 8], [3, 4, 5], [0, 1, 2]]
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+PROFILE_TAG = "r03"                # profiles/<tag>_pmc_traffic*.json: the PMC passes whose `traffic` this build may quote
 WEIGHT_SEED, OBJ_BIAS, HEAD_GAIN = 3, -16.0, 4.0
 OBJ_BIAS_SPARSE = -18.5     # a few tens of detections per image (-18: 67, -19: 11, -20: 3, <= -24: none)
 
@@ -175,6 +176,8 @@ def main():
     ap.add_argument("--size", type=int, default=544)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-compare", action="store_true", help="split mode: skip the extra timed region with fp32 operands")
+    ap.add_argument("--no-f16-compare", action="store_true",
+                    help="split mode: skip the extra timed region in the fp16-activation configuration (BASELINE configs[4])")
     ap.add_argument("--no-extras", action="store_true", help="skip the preprocess / COCO-format side measurements")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
     ap.add_argument("--heads", choices=("dense", "sparse"), default="dense",
@@ -194,14 +197,18 @@ def main():
     ap.add_argument("--lib", default=None,
                     help="path of another build of liborienmask_hip.so to load instead of the in-tree one (A/B runs of two "
                          "builds on the same GPU box: tools/ab_bench.sh)")
-    ap.add_argument("--dtype", choices=("f32", "f32_split", "f16"), default="f32_split",
-                    help="f32_split (default): fp32 tensors and fp32 accumulation, every convolution product computed from hi/lo "
+    ap.add_argument("--dtype", choices=("f32", "f32_split", "f16"), default=None,
+                    help="default: the plugin's own default precision (orienmask_amd.model.DEFAULT_PRECISION = f32_split), i.e. what "
+                         "build(config['model'], orienmask_amd.model) runs.  f32_split: fp32 tensors and fp32 accumulation, every convolution product computed from hi/lo "
                          "fp16 pairs of its fp32 operands on the fp16 matrix pipe (three MFMAs per product group; error against "
                          "float64 equal to the fp32-operand kernels: profiles/r02_split_error.json) -- the headline metric, with "
                          "the fp32-operand time reported beside it as `f32_operands`.  f32: fp32 operands on "
                          "v_mfma_f32_32x32x2_f32 only.  f16: BASELINE configs[4], fp16 activations and weights with fp32 "
                          "accumulation -- a separate, clearly labelled line")
     args = ap.parse_args()
+    from orienmask_amd.model import DEFAULT_PRECISION
+    if args.dtype is None:
+        args.dtype = DEFAULT_PRECISION
     if args.in_flight is None:
         args.in_flight = 3 if args.dtype == "f16" else 2
 
@@ -353,6 +360,44 @@ def main():
                             note="the same K steps with precision 'f32': fp32 operands on v_mfma_f32_32x32x2_f32 (157 TFLOP/s "
                                  "peak) in every convolution; same tensors in HBM, same postprocess")
         net.set_precision(args.dtype)
+    # ---- split mode: the same K steps in the fp16-activation configuration (BASELINE configs[4]: fp16 activations and weights,
+    # fp32 accumulate -- NARROWER arithmetic than the headline, reported beside it so that the driver's run times it too)
+    f16_config = None
+    if split and not args.no_f16_compare:
+        import itertools
+        from orienmask_amd.pipeline import InFlightPipeline
+        net.set_precision("f16")
+        broadcast_packed_weights(net, dev, src=0)                  # the fp16 weight rows (untimed)
+        pipe16 = InFlightPipeline(net, post, depth=3)
+        for _ in range(2):
+            step()
+        for _ in pipe16.map(itertools.repeat(x, 6)):
+            pass
+        def timed16(fn):
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            e_ = time.perf_counter() - t0_
+            if use_dist:
+                t_ = torch.tensor([e_], dtype=torch.float64, device=dev)
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                e_ = t_.item()
+            return e_
+        e1 = timed16(lambda: [step() for _ in range(args.steps)])
+        e3 = timed16(lambda: [None for _ in pipe16.map(itertools.repeat(x, args.steps))])
+        f16_config = dict(value=round(world * B * args.steps / e3, 2), ms_per_step=round(e3 / args.steps * 1e3, 3),
+                          batches_in_flight=3, one_batch_in_flight=round(world * B * args.steps / e1, 2),
+                          note="BASELINE configs[4] at this batch size: the same K steps with precision 'f16' (fp16 activations and "
+                               "convolution weights, fp32 accumulate, fp32 heads and postprocess; `bench.py --dtype f16` prints its own "
+                               "roofline).  Narrower arithmetic than the headline and unpinned against the reference (DESIGN.md 3.3): "
+                               "never `value`")
+        del pipe16
+        net.set_precision(args.dtype)
     timed_fw //= max(args.streams, 1)                              # one om_forward per sub-batch
     dom_main_ms = sum(ms for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw      # per step, all launches
     dom_timed_ms = dom_main_ms + sum(pre for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw
@@ -396,8 +441,8 @@ def main():
         total_bytes = sum(t["bytes"] for t in kern.values() if t["flops"] > 0)
         # ---- HBM traffic from the committed PMC passes, only if they were measured with THIS library binary
         traffic, traffic_src, conv_stack = None, None, None
-        pmc_file = os.path.join(REPO, "profiles", "r02_pmc_traffic_f16.json" if f16 else
-                                ("r02_pmc_traffic_f32_split.json" if split else "r02_pmc_traffic.json"))
+        pmc_file = os.path.join(REPO, "profiles", PROFILE_TAG + ("_pmc_traffic_f16.json" if f16 else
+                                ("_pmc_traffic_f32_split.json" if split else "_pmc_traffic.json")))
         try:
             pmc = json.load(open(pmc_file))
             meta = pmc.pop("_meta", {})
@@ -512,11 +557,14 @@ def main():
         line = dict(metric=metric, value=round(total_images / elapsed, 2),
                     unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
-                    vs_baseline=None, dtype=dtype_out, data="synthetic",
+                    vs_baseline=None, dtype=dtype_out, precision=args.dtype, plugin_default_precision=DEFAULT_PRECISION,
+                    data="synthetic",
                     config=dict(workload="OrienMaskYOLOFPNPlus forward + OrienMaskYOLOPostProcess, %d x [3,%d,%d] per GPU "
                                          "(BASELINE configs[2]); seeded random-init weights (seed %d, obj_bias %g, head_gain %g): "
                                          "%s heads (dense: >400 candidates pass conf_thresh per image, NMS, 100 masks per image; "
-                                         "sparse: a few tens of detections per image)"
+                                         "sparse: a few tens of detections per image).  Parity of exactly this workload: "
+                                         "tests/test_hip_parity.py::test_bench_workload_bs32_detections (these weights' saturated heads tie "
+                                         "hundreds of scores at exactly 1.0, so detections are compared as sets per tie group)"
                                          % (B, H, W, WEIGHT_SEED, obj_bias, HEAD_GAIN, args.heads),
                                 per_gpu_batch=B, image_size=[H, W], forward_streams=args.streams, batches_in_flight=args.in_flight, detections_per_image=round(sum(int(d_["bbox"].shape[0]) for d_ in dets) / B, 1),
                                 parallelism="batch shard x%d, one RCCL weight broadcast, no collective in the step" % world),
@@ -539,6 +587,8 @@ def main():
                  "step time of the timed region behind `value` (forward + postprocess, batches_in_flight batches overlapping)")
         if f32_operands is not None:
             line["f32_operands"] = f32_operands
+        if f16_config is not None:
+            line["f16_config"] = f16_config
         if not args.no_extras:
             line["extras"] = measure_neighbours(dev, dets, B)
         if world == 1 and not args.no_cpu_baseline:

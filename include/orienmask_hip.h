@@ -5,7 +5,8 @@
  * torch-ROCm tensor.data_ptr()); the library never allocates device memory on the hot path
  * and launches only on the stream it is handed.  All functions return 0 on success or a
  * negative OM_E* code; om_last_error() holds the message (thread-local).  No exceptions
- * cross this boundary.
+ * cross this boundary; the library has no mutable global state besides that thread-local message (the unit-test
+ * entries at the end own a hipMalloc'ed tile-queue word each).
  *
  * What each entry point replaces in the reference (/root/reference):
  *   om_model_* / om_forward        OrienMaskYOLOFPNPlus.__init__/forward
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OM_VERSION 130          /* 0.1.3: split-operand precision mode (om_layer_info.wsplit_off, om_model_set_precision, ...) */
+#define OM_VERSION 140          /* 0.1.4: forward status word (om_forward_status_offset, OM_STATUS_*), no process-wide switches */
 
 #define OM_OK 0
 #define OM_EINVAL (-1)          /* bad argument (null pointer, shape not supported) */
@@ -116,18 +117,21 @@ size_t om_model_weight_floats(const om_model* m);
  * (and unchanged) for as long as om_forward is called.  dtype: 0 = float32. */
 int om_model_load_weights(om_model* m, const void* packed_dev, size_t bytes, int dtype);
 
-/* ---- precision of om_forward's F(2x4,3x3) Winograd GEMMs (no counterpart in the reference, whose convolutions are
- * whatever cuDNN / MKLDNN run) ------------------------------------------------------------------------------------------
- * 0 (default): operands fp32 on v_mfma_f32_32x32x2_f32 (products exact, fp32 accumulate).
- * 1: SPLIT operands.  Every fp32 operand x is carried as hi = fp16(x), lo = fp16(x - hi) and a product is
- *    hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (the lo*lo term, <= 2^-22 of the product, is
- *    dropped): 5.3x the matrix rate at the same bytes per element.  Representation error <= 2^-22 |x| (floor 2^-25
- *    absolute), i.e. ~4x an fp32 rounding; measured end to end in DESIGN.md 3.5.  Transformed inputs must stay below
- *    65504 in magnitude (activations below ~3000); weights are pre-scaled per output channel by the packer.
- *    Needs om_model_load_weights_split; activations between layers stay fp32.  The 1x1 and stride-2 layers run the same
- *    three-product form (conv_igemm_split.hip: activations are split in registers); the stem keeps fp32 operands.  In this
- *    mode the stride-1 3x3 layers run F(2x4,3x3) at EVERY size (mode 0 switches to F(2x2,3x3) below 1700 1/32-scale cells
- *    per batch), so an image's outputs do not depend on the batch it is in. */
+/* ---- precision of om_forward's convolutions (no counterpart in the reference, whose convolutions are whatever cuDNN /
+ * MKLDNN run) -----------------------------------------------------------------------------------------------------------
+ * 0: operands fp32 on v_mfma_f32_32x32x2_f32 (products exact, fp32 accumulate).
+ * 1: SPLIT operands, in EVERY convolution but the stem (the F(2x4,3x3) Winograd GEMMs of the stride-1 3x3 layers,
+ *    conv_wino24.hip, and the implicit GEMM of the 1x1 / stride-2 / head layers, conv_igemm_split.hip).  Every fp32 operand x
+ *    is carried as hi = fp16(x), lo = fp16(x - hi) and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with
+ *    fp32 accumulation (the lo*lo term, <= 2^-22 of the product, is dropped): 5.3x the matrix rate at the same bytes per
+ *    element.  Representation error <= 2^-22 |x| for |x| >= 2^-14 * 2^11 and 2^-25 absolute below (measured end to end in
+ *    DESIGN.md 3.5).  Weights are pre-scaled per output channel by the packer; activations are split as they are, so a
+ *    layer input must stay below fp16's 65504 in magnitude -- for a stride-1 3x3 layer its TRANSFORMED input, up to 20x
+ *    the activation.  An operand beyond that range turns the layer's outputs into NaN, and every split-operand kernel
+ *    raises OM_STATUS_SPLIT_RANGE in the forward's status word when it stores a non-finite output (below): the caller
+ *    re-runs that batch with mode 0 (orienmask_amd/model.py does).  Needs om_model_load_weights_split; activations between
+ *    layers stay fp32.  In this mode the stride-1 3x3 layers run F(2x4,3x3) at EVERY size (mode 0 switches to F(2x2,3x3)
+ *    below 1700 1/32-scale cells per batch), so an image's outputs do not depend on the batch it is in. */
 size_t om_model_weight_split_words(const om_model* m);
 int om_model_load_weights_split(om_model* m, const void* packed_split_dev, size_t bytes);
 int om_model_set_precision(om_model* m, int mode);
@@ -140,6 +144,15 @@ size_t om_forward_workspace_bytes(const om_model* m, int B, int H, int W);
  * oriens:      [B, 6*A, H/4, W/4] float32 NCHW contiguous */
 int om_forward(om_model* m, const float* x, int B, int H, int W, float* bbox32, float* bbox16, float* bbox8,
                float* oriens, void* workspace, size_t ws_bytes, om_stream stream);
+/* The forward's STATUS WORD: one int32 inside the workspace handed to om_forward, om_forward_status_offset() bytes from its
+ * start, cleared when a forward starts and OR-ed by its kernels (om_forward_f16 has no conditions to report).  The caller reads it with whatever device-to-host copy it does anyway after the step
+ * (orienmask_amd/eval.py reads it together with the detection counts).  0 = the outputs are valid. */
+#define OM_STATUS_SPLIT_RANGE 1 /* precision mode 1: a split-operand layer stored a non-finite output -- an operand left the
+                                   fp16 range of the hi/lo representation (or the fp32 result itself is non-finite): re-run
+                                   the batch with om_model_set_precision(m, 0) */
+#define OM_STATUS_SK_TIMEOUT 2  /* a stream-K finisher gave up waiting for its partner workgroup's partial tile (bounded spin
+                                   so that a fault cannot hang the device): the outputs are invalid */
+size_t om_forward_status_offset(const om_model* m, int B, int H, int W);
 
 /* ---- fp16 activations, fp32 accumulate (BASELINE.json configs[4]; no reduced-precision path exists in the
  * reference -- the arithmetic is defined by oracle/orienmask_ref.py:forward_f16) -------------------------------
@@ -223,19 +236,20 @@ int om_conv2d_winograd24(const float* in, int B, int H, int W, int cin, int in_p
                          int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
                          om_stream stream);
 /* one ConvBNRelu with split operands (conv_igemm_split.hip): w_split / scale_split as om_layer_info.wsplit_off /
- * wsplit_scale_off describe for a layer without F(2x4) form; other arguments as om_conv2d_mode. */
+ * wsplit_scale_off describe for a layer without F(2x4) form; other arguments as om_conv2d_mode.  tile_bm x tile_bn: 0, 0 =
+ * the tile shape om_forward would pick, else one of the built shapes 256x128, 128x128, 128x64, 64x64, 128x32 with tile_bn
+ * dividing cout_pad (per call: tile sweeps and tests of every instantiation).  status_dev: optional device int32 that the
+ * kernel ORs OM_STATUS_* bits into (the caller clears it), NULL = not reported. */
 int om_conv2d_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* w_split,
                     const float* scale_split, const float* shift, int cout, int ksize, int stride, int leaky, const float* res,
-                    int res_pix_stride, float* out, int out_pix_stride, int out_mode, int up, om_stream stream);
-/* debugging / tile sweeps only (process-wide, not thread-safe): force the tile shape of conv_igemm_split.hip (256x128, 128x128,
- * 128x64, 64x64, 128x32) for layers whose cout_pad it divides; 0, 0 restores the built-in choice. */
-int om_debug_split_tile(int bm, int bn);
+                    int res_pix_stride, float* out, int out_pix_stride, int out_mode, int up, int tile_bm, int tile_bn,
+                    int32_t* status_dev, om_stream stream);
 /* ... with split operands (om_model_set_precision mode 1): u_split as om_layer_info.wsplit_off describes, scale_split =
- * scale * 2^-e per output channel; scratch as for om_conv2d_winograd24. */
+ * scale * 2^-e per output channel; scratch as for om_conv2d_winograd24; status_dev as for om_conv2d_split. */
 int om_conv2d_winograd24_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* u_split,
                                const float* scale_split, const float* shift, int cout, int leaky, const float* res,
                                int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
-                               om_stream stream);
+                               int32_t* status_dev, om_stream stream);
 /* first layer: in [B,3,H,W] NCHW -> out [B,H,W,cout] NHWC, 3x3 stride 1. */
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale,
                    const float* shift, int cout, float* out, om_stream stream);

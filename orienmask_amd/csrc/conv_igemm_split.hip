@@ -36,6 +36,7 @@ struct IgemmSParams {
     const float* res;
     float* out;
     int* ticket;
+    int* status;          // OM_STATUS_SPLIT_RANGE is OR-ed here when a tile stores a non-finite value (nullptr: not reported)
     int H, W, cin_h, in_pix_stride_h;      // in halfs (= 2 x the float counts)
     int Ho, Wo, HoWo, cout;
     int ks, stride, pad;
@@ -67,6 +68,12 @@ __device__ __forceinline__ void split_epilogue(const IgemmSParams& p, f32x4* sme
     float sc[8], sh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { sc[k] = p.scale[n + k]; sh[k] = p.shift[n + k]; }   // padded to cout_pad
+    // RANGE GUARD of the split representation (include/orienmask_hip.h: OM_STATUS_SPLIT_RANGE).  An activation beyond fp16's
+    // range converts to hi = +-inf, lo = -+inf, whose products sum to NaN in every output channel of that pixel (also against
+    // zero weights: 0 * inf), so "this tile stores a non-finite value" is exactly "an operand left the representable range, or the
+    // fp32 result itself is non-finite".  v * 0 is NaN for v = +-inf / NaN and +-0 otherwise: one multiply-add per stored value in
+    // the store-bound epilogue, nothing in the k-loop.
+    float nonfinite = 0.f;
 #pragma unroll 1
     for (int pass = 0; pass < BM / WM; ++pass) {
         if (wm == pass) {
@@ -98,6 +105,7 @@ __device__ __forceinline__ void split_epilogue(const IgemmSParams& p, f32x4* sme
                 for (int k = 0; k < 8; ++k) {
                     const float t = fmaf(v[k], sc[k], sh[k]);
                     v[k] = p.leaky ? (t > 0.f ? t : t * 0.1f) : t;
+                    nonfinite = fmaf(t, 0.f, nonfinite);
                 }
                 if (p.out_mode == 0) {
                     float* o = p.out + (size_t)m * p.out_pix_stride + n;
@@ -145,6 +153,7 @@ __device__ __forceinline__ void split_epilogue(const IgemmSParams& p, f32x4* sme
                 if (m >= p.M) continue;
                 const int nn = n0 + nl;
                 float t = fmaf(sCf[(ml * CH + ((nl >> 2) ^ (ml & 7))) * 4 + (nl & 3)], p.scale[nn], p.shift[nn]);
+                nonfinite = fmaf(t, 0.f, nonfinite);
                 if (p.leaky) t = t > 0.f ? t : t * 0.1f;
                 const int bi = m / p.HoWo;
                 const int rr = m - bi * p.HoWo;
@@ -154,6 +163,7 @@ __device__ __forceinline__ void split_epilogue(const IgemmSParams& p, f32x4* sme
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+    if (p.status && nonfinite != nonfinite) atomicOr(p.status, OM_STATUS_SPLIT_RANGE);
 }
 
 // hi = fp16(x) (round to nearest even), lo = fp16(x - hi) for the eight channels a lane holds of one pixel
@@ -355,11 +365,7 @@ static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hi
     return OM_OK;
 }
 
-static int g_force_bm = 0, g_force_bn = 0;      // om_debug_split_tile: tile sweeps (tools/split_tile_sweep.py)
-void conv_split_force_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
-
 void conv_tile_for_split(int M, int cout_pad, int* bm, int* bn) {
-    if (g_force_bm && cout_pad % g_force_bn == 0) { *bm = g_force_bm; *bn = g_force_bn; return; }
     // time over all tiles ~ tiles x tile area / how well the shape feeds the pipe (tools/split_tile_sweep.py on the forward's
     // layer shapes: 128 x 128 is the fastest wherever cout allows it, 256 x 128 -- two workgroups per CU, 256 registers -- 9 %
     // behind, then 128 x 64, 64 x 64, 128 x 32)
@@ -390,7 +396,7 @@ int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream) {
     OM_REQUIRE(a.ticket, OM_EINVAL, "conv split: the tile queue needs a zeroed ticket word");
     IgemmSParams p;
     p.in = reinterpret_cast<const _Float16*>(a.in); p.w = reinterpret_cast<const _Float16*>(a.w);
-    p.scale = a.scale; p.shift = a.shift; p.res = a.res; p.out = a.out; p.ticket = a.ticket;
+    p.scale = a.scale; p.shift = a.shift; p.res = a.res; p.out = a.out; p.ticket = a.ticket; p.status = a.status;
     p.H = a.H; p.W = a.W; p.cin_h = 2 * a.cin; p.in_pix_stride_h = 2 * a.in_pix_stride;
     p.Ho = a.Ho; p.Wo = a.Wo; p.HoWo = a.Ho * a.Wo; p.cout = a.cout;
     p.ks = a.ks; p.stride = a.stride; p.pad = a.ks / 2;
@@ -407,6 +413,13 @@ int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream) {
                    ? 1 : 0;
     int bm, bn;
     conv_tile_for_split(p.M, a.cout_pad, &bm, &bn);
+    if (a.force_bm || a.force_bn) {      // unit-test entry: this call's tile shape
+        const bool built = (a.force_bm == 256 && a.force_bn == 128) || (a.force_bm == 128 && (a.force_bn == 128 || a.force_bn == 64 || a.force_bn == 32)) ||
+                           (a.force_bm == 64 && a.force_bn == 64);
+        OM_REQUIRE(built && a.cout_pad % a.force_bn == 0, OM_EINVAL, "conv split: %d x %d is not a built tile shape for cout_pad=%d",
+                   a.force_bm, a.force_bn, a.cout_pad);
+        bm = a.force_bm; bn = a.force_bn;
+    }
     if (bm == 256 && bn == 128) return launch_tile_split<256, 128, 128, 64>(p, a.cout_pad, 2, stream);
     if (bm == 128 && bn == 128) return launch_tile_split<128, 128, 64, 64>(p, a.cout_pad, 3, stream);
     if (bm == 128 && bn == 64) return launch_tile_split<128, 64, 64, 32>(p, a.cout_pad, 4, stream);

@@ -134,6 +134,7 @@ struct Wino24Params {
     float* partial;       // [slots][32][256] f32x4: the eight raw accumulators a slot publishes for the tile it shares
     int* flags;           // [slots], zeroed before the launch: slot s has published
     int slots;
+    int* status;          // the forward's status word (OM_STATUS_*), nullptr = not reported
 };
 
 // SK = false: whole tiles from a dynamic ticket queue.
@@ -296,10 +297,17 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
             if (mode == 2) {
                 // the partner (slot - 1) published this tile's head planes as its first action
                 if (tid == 0) {
-                    // bounded (a few seconds): the partner started before this workgroup and publishes within one tile's time
-                    for (int spins = 0; spins < (1 << 22) &&
-                                        __hip_atomic_load(p.flags + slot - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spins)
+                    // The partner drew its slot number BEFORE this workgroup drew its own and publishes as its first action, within
+                    // one tile's time; with other streams' kernels on the chip (pipeline.InFlightPipeline) it may be queued behind
+                    // them, so the wait is long -- 2^24 polls, several seconds -- but bounded: a fault must not hang the device.  Giving
+                    // up is REPORTED (OM_STATUS_SK_TIMEOUT in the forward's status word; the host raises), never silent.
+                    int seen = 0;
+                    for (int spins = 0; spins < (1 << 24); ++spins) {
+                        seen = __hip_atomic_load(p.flags + slot - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (seen) break;
                         __builtin_amdgcn_s_sleep(16);
+                    }
+                    if (!seen && p.status) atomicOr(p.status, OM_STATUS_SK_TIMEOUT);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
                 __syncthreads();
@@ -442,7 +450,14 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
                     }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (tid == 0) __hip_atomic_store(p.flags + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) {
+                    // agent-scope release before the flag (MI355X_MICROARCH.md, inter-workgroup visibility): the sc1 stores above are
+                    // write-through and drained, the fence also writes back anything this L2 still holds dirty; the inline-asm wait
+                    // keeps the compiler from dropping the fence's vmcnt(0) (its scoreboard is provably empty here)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(p.flags + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 continue;
             }
         }
@@ -476,6 +491,9 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
             okb[ps] = ok;
         }
         constexpr int PPP = SK ? 1 : 2;       // output positions per pass (the stream-K form has fewer registers to spare)
+        // SPLIT: range guard of the hi/lo representation (conv_igemm_split.hip: split_epilogue) -- a transformed input beyond fp16's
+        // range makes every output of its tile row NaN; v * 0 is NaN exactly for non-finite v
+        float nonfinite = 0.f;
 #pragma unroll
         for (int pass = 0; pass < (8 + PPP - 1) / PPP; ++pass) {
             f32x4 rres[PPP][BM / RP];
@@ -521,6 +539,7 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
                     for (int k = 0; k < 4; ++k) {
                         float tv = fmaf(v[k], sc[k], sh[k]);
                         v[k] = p.leaky ? (tv > 0.f ? tv : tv * 0.1f) : tv;
+                        if constexpr (SPLIT) nonfinite = fmaf(tv, 0.f, nonfinite);
                     }
                     float* o = p.out + pix * p.out_pix_stride + n;
                     if (vec) {
@@ -534,6 +553,9 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (SPLIT) {
+            if (p.status && nonfinite != nonfinite) atomicOr(p.status, OM_STATUS_SPLIT_RANGE);
         }
     }
 }
@@ -579,7 +601,7 @@ int launch_conv_winograd24(const ConvArgs& a, float* scratch, hipStream_t stream
     OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "winograd24: %lld tiles out of range", total);
     p.total_tiles = (int)total;
     const long long grid = total < 512 ? total : 512;        // 2 workgroups per CU (register-bound)
-    p.partial = a.sk_partial; p.flags = a.ticket + SK_FLAG_OFF; p.slots = (int)grid;
+    p.partial = a.sk_partial; p.flags = a.ticket + SK_FLAG_OFF; p.slots = (int)grid; p.status = a.status;
     // Stream-K only where the last partial round hurts most (fewer than two tiles per slot: the 34 x 34 layers, 616 tiles,
     // -9 %).  A static split is only as fast as the slowest workgroup -- dealt out statically, whole layers ran 2-4 % slower
     // than from the queue -- so from two tiles per slot on the two effects cancel (68 x 68: +-0, 136 x 136: +1-2 %), and a

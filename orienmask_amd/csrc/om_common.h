@@ -54,18 +54,21 @@ struct ConvArgs {
                             // 2: NCHW contiguous [B,cout,Ho,Wo]
     int up;
     int split = 0;          // Winograd F(2x4) only: operands as hi/lo fp16 pairs (conv_wino24.hip)
+    int* status = nullptr;  // the forward's status word (include/orienmask_hip.h: OM_STATUS_*), OR-ed by the split-operand kernels
+                            // and the stream-K form; nullptr = not reported
+    int force_bm = 0, force_bn = 0;   // unit-test entries: tile shape of conv_igemm_split.hip for THIS call (0 = the chooser's)
 };
 
 constexpr int SK_SLOTS = 1024;                          // most resident workgroups of a stream-K launch (4 per CU)
 constexpr int SK_FLAG_OFF = 16;
 constexpr int SYNC_WORDS = SK_FLAG_OFF + SK_SLOTS;      // ints per launch
+constexpr int STATUS_WORDS = 16;                        // behind the last layer's sync words: [0] the forward's status word
 constexpr size_t SK_PARTIAL_BYTES = (size_t)512 * 32 * 256 * 16;   // Winograd F(2x4): 512 slots x 8 accumulators x 16 floats x 256 threads (64 MiB)
 
 int launch_conv_igemm(const ConvArgs& a, hipStream_t stream);
 // split-operand form (conv_igemm_split.hip): a.w = packed hi/lo fp16 weights, a.scale = scale * 2^-e
 int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream);
 void conv_tile_for_split(int M, int cout_pad, int* bm, int* bn);
-void conv_split_force_tile(int bm, int bn);
 
 // fp16-activation path (conv_igemm_f16.hip): in / w / res are fp16, scale / shift fp32, out fp16 unless out_f32.
 struct ConvArgsH {

@@ -302,8 +302,8 @@ struct om_model {
         out.scratch_off.resize(nl);
         for (int i = 0; i < nb; ++i) out.buf_off[i] = items[i].off;
         for (int l = 0; l < nl; ++l) out.scratch_off[l] = items[nb + l].off;
-        out.tickets_off = peak;                 // queue word + stream-K flags per layer (zeroed by every forward)
-        out.partial_off = peak + om::align_up((size_t)nl * om::SYNC_WORDS * sizeof(int), 256);
+        out.tickets_off = peak;                 // queue word + stream-K flags per layer, then the status word (zeroed by every forward)
+        out.partial_off = peak + om::align_up(((size_t)nl * om::SYNC_WORDS + om::STATUS_WORDS) * sizeof(int), 256);
         out.total = out.partial_off + (f16 ? 0 : om::SK_PARTIAL_BYTES);
         return out;
     }
@@ -387,6 +387,12 @@ static size_t forward_workspace_bytes(const om_model* m, int B, int H, int W, bo
 }
 
 size_t om_forward_workspace_bytes(const om_model* m, int B, int H, int W) { return forward_workspace_bytes(m, B, H, W, false); }
+
+size_t om_forward_status_offset(const om_model* m, int B, int H, int W) {
+    if (!m || B <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32) return 0;
+    // om_forward's workspace only: the fp16 forward (another layout) has neither split operands nor a stream-K form
+    return m->layout(B, H, W, false).tickets_off + m->layers.size() * om::SYNC_WORDS * sizeof(int);
+}
 size_t om_forward_f16_workspace_bytes(const om_model* m, int B, int H, int W) { return forward_workspace_bytes(m, B, H, W, true); }
 
 static int forward_impl(om_model* m, const float* x, int B, int H, int W, float* bbox32, float* bbox16, float* bbox8,
@@ -409,7 +415,8 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
     for (size_t i = 0; i < m->bufs.size(); ++i) base[i] = static_cast<char*>(workspace) + lay.buf_off[i];
     int* tickets = reinterpret_cast<int*>(static_cast<char*>(workspace) + lay.tickets_off);
     float* sk_partial = f16 ? nullptr : reinterpret_cast<float*>(static_cast<char*>(workspace) + lay.partial_off);
-    if (int rc = om::launch_zero_words(tickets, m->layers.size() * om::SYNC_WORDS, stream)) return rc;
+    int* status = tickets + m->layers.size() * om::SYNC_WORDS;      // om_forward_status_offset
+    if (int rc = om::launch_zero_words(tickets, m->layers.size() * om::SYNC_WORDS + om::STATUS_WORDS, stream)) return rc;
     // element pointer of a view: workspace buffers hold esz-byte elements, the four outputs are always fp32
     auto ptr_of = [&](const om::View& v) -> void* {
         switch (v.buf) {
@@ -482,6 +489,7 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             a.out_mode = L.out_mode; a.up = L.up;
             a.ticket = tickets + (&L - m->layers.data()) * om::SYNC_WORDS;
             a.sk_partial = sk_partial;
+            a.status = status;
             if (li.wino_off >= 0 && om::wino_enabled()) {
                 float* wino_scratch = reinterpret_cast<float*>(static_cast<char*>(workspace) + lay.scratch_off[&L - m->layers.data()]);
                 a.mid_event = ev_mid;
@@ -679,16 +687,10 @@ int om_conv2d_mode(const float* in, int B, int H, int W, int cin, int in_pix_str
     return om::launch_conv_igemm(a, static_cast<hipStream_t>(stream));
 }
 
-int om_debug_split_tile(int bm, int bn) {
-    OM_REQUIRE((bm == 0 && bn == 0) || ((bm == 256 && bn == 128) || (bm == 128 && (bn == 128 || bn == 64 || bn == 32)) || (bm == 64 && bn == 64)),
-               OM_EINVAL, "om_debug_split_tile: %d x %d is not a built tile", bm, bn);
-    om::conv_split_force_tile(bm, bn);
-    return OM_OK;
-}
-
 int om_conv2d_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* w_split,
                     const float* scale_split, const float* shift, int cout, int ksize, int stride, int leaky, const float* res,
-                    int res_pix_stride, float* out, int out_pix_stride, int out_mode, int up, om_stream stream) {
+                    int res_pix_stride, float* out, int out_pix_stride, int out_mode, int up, int tile_bm, int tile_bn,
+                    int32_t* status_dev, om_stream stream) {
     OM_REQUIRE(B > 0 && H > 0 && W > 0 && stride >= 1 && H % stride == 0 && W % stride == 0, OM_EINVAL,
                "om_conv2d_split: bad shape");
     OM_REQUIRE(out_mode >= 0 && out_mode <= 2 && up >= 1 && (out_mode == 1 || up == 1), OM_EINVAL,
@@ -699,6 +701,7 @@ int om_conv2d_split(const float* in, int B, int H, int W, int cin, int in_pix_st
     a.Ho = H / stride; a.Wo = W / stride; a.cout = cout; a.cout_pad = om::round_up(cout, 32);
     a.ks = ksize; a.stride = stride; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
     a.out_pix_stride = out_pix_stride; a.out_mode = out_mode; a.up = up;
+    a.force_bm = tile_bm; a.force_bn = tile_bn; a.status = status_dev;
     static int* g_ticket = nullptr;      // unit-test entry only (see om_conv2d_mode)
     if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), om::SYNC_WORDS * sizeof(int)));
     if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;
@@ -764,7 +767,7 @@ int om_conv2d_stem_f16(const float* in, int B, int H, int W, const float* w, con
 static int conv2d_winograd24_impl(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* u,
                                   const float* scale, const float* shift, int cout, int leaky, const float* res,
                                   int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
-                                  om_stream stream, int split);
+                                  om_stream stream, int split, int32_t* status_dev);
 
 size_t om_conv2d_winograd24_scratch_bytes(int B, int H, int W, int cin) {
     if (B <= 0 || H <= 0 || W <= 0 || cin <= 0) return 0;
@@ -776,13 +779,13 @@ int om_conv2d_winograd24(const float* in, int B, int H, int W, int cin, int in_p
                          int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
                          om_stream stream) {
     return conv2d_winograd24_impl(in, B, H, W, cin, in_pix_stride, u, scale, shift, cout, leaky, res, res_pix_stride, out,
-                                  out_pix_stride, scratch, scratch_bytes, stream, 0);
+                                  out_pix_stride, scratch, scratch_bytes, stream, 0, nullptr);
 }
 
 static int conv2d_winograd24_impl(const float* in, int B, int H, int W, int cin, int in_pix_stride, const float* u,
                                   const float* scale, const float* shift, int cout, int leaky, const float* res,
                                   int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
-                                  om_stream stream, int split) {
+                                  om_stream stream, int split, int32_t* status_dev) {
     OM_REQUIRE(B > 0 && H > 0 && W > 0, OM_EINVAL, "om_conv2d_winograd24: bad shape");
     OM_REQUIRE(scratch && scratch_bytes >= om_conv2d_winograd24_scratch_bytes(B, H, W, cin), OM_ENOMEM,
                "om_conv2d_winograd24: scratch too small");
@@ -791,7 +794,7 @@ static int conv2d_winograd24_impl(const float* in, int B, int H, int W, int cin,
     a.B = B; a.H = H; a.W = W; a.cin = cin; a.in_pix_stride = in_pix_stride;
     a.Ho = H; a.Wo = W; a.cout = cout; a.cout_pad = om::round_up(cout, 64);
     a.ks = 3; a.stride = 1; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
-    a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1; a.split = split;
+    a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1; a.split = split; a.status = status_dev;
     static int* g_ticket = nullptr;
     if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), om::SYNC_WORDS * sizeof(int)));
     if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;
@@ -803,9 +806,9 @@ static int conv2d_winograd24_impl(const float* in, int B, int H, int W, int cin,
 int om_conv2d_winograd24_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* u_split,
                                const float* scale_split, const float* shift, int cout, int leaky, const float* res,
                                int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
-                               om_stream stream) {
+                               int32_t* status_dev, om_stream stream) {
     return conv2d_winograd24_impl(in, B, H, W, cin, in_pix_stride, static_cast<const float*>(u_split), scale_split, shift, cout,
-                                  leaky, res, res_pix_stride, out, out_pix_stride, scratch, scratch_bytes, stream, 1);
+                                  leaky, res, res_pix_stride, out, out_pix_stride, scratch, scratch_bytes, stream, 1, status_dev);
 }
 
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale, const float* shift,

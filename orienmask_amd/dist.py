@@ -4,7 +4,7 @@ The reference has no multi-GPU inference (assert n_gpu <= 1, /root/reference/tes
 /root/reference/infer.py:69); images are independent through forward and postprocess
 (/root/reference/eval/orienmask_yolo_postprocess.py:75 loops per image), so the path shards with no
 data-path collective.  The only collective is one broadcast of rank 0's packed weight blob
-(63.67 M weights plus the Winograd transforms of the 3x3 layers: 1.16 GB) over RCCL/xGMI at start-up -- not in the timed region.  Results are merged
+(63.67 M weights plus the Winograd transforms of the 3x3 layers: 1.16 GB; in the default split-operand precision also the hi/lo fp16 form of every layer's weights) over RCCL/xGMI at start-up -- not in the timed region.  Results are merged
 on the host per rank, as the reference's validation does with its _temp_coco_eval_%d.json files
 (/root/reference/trainer/trainer.py:175-181,201-205).
 """
@@ -56,7 +56,7 @@ def broadcast_packed_weights(net, device, src=0):
         net.bind_packed_f16(broadcast_blob(b16, n16, device, src, dtype=torch.float16))
     if getattr(net, "precision", "f32") == "f32_split":     # split-operand mode: the hi/lo fp16 pairs of the F(2x4) weights
         ns = _lib.load().om_model_weight_split_words(h)
-        bs = _pack.pack_state_dict_split(net.state_dict(), net._layers, ns, blob.cpu()) if rank == src else None
+        bs = _pack.pack_state_dict_split(net.state_dict(), net._layers, ns) if rank == src else None
         net.bind_packed_split(broadcast_blob(bs, ns, device, src))
     return blob
 

@@ -6,8 +6,8 @@
                             /root/reference/eval/function.py:55-103
 
 Everything runs in liborienmask_hip.so (``om_postprocess`` / ``om_nms_ex``); the whole batch is three
-kernel launches and ONE device->host copy (the per-image detection counts), against the reference's
-per-image Python loop with four host round trips.
+kernel launches and ONE device->host copy (the per-image detection counts and, behind them, the forward's
+status word), against the reference's per-image Python loop with four host round trips.
 
 The reference dispatches on ``dets.is_cuda`` between two native backends with DIFFERENT semantics
 (/root/reference/eval/function.py:69-72,98-101):
@@ -226,7 +226,13 @@ class OrienMaskYOLOPostProcess:
         out_bbox = torch.empty((B, self.nms_post, 5), dtype=torch.float32, device=dev)
         out_cls = torch.empty((B, self.nms_post), dtype=torch.long, device=dev)
         out_mask = torch.empty((B, self.nms_post, self.image_h, self.image_w), dtype=torch.uint8, device=dev)
-        out_count = torch.empty((B,), dtype=torch.int32, device=dev)
+        # [0, B): detections per image; behind them the status word(s) of the forward that produced `predict`
+        # (model.Prediction.status), so that collect()'s one device-to-host copy brings both
+        status = getattr(predict, "status", None)
+        n_status = 0 if status is None else int(status.numel())
+        out_count = torch.empty((B + n_status,), dtype=torch.int32, device=dev)
+        if n_status:
+            out_count[B:].copy_(status)
         out_keep = torch.empty((B, self.nms_post), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             rc = L.om_postprocess(ctypes.byref(cfg), ctypes.c_void_p(bboxes[0].data_ptr()),
@@ -236,12 +242,22 @@ class OrienMaskYOLOPostProcess:
                                   ctypes.c_void_p(out_count.data_ptr()), ctypes.c_void_p(out_keep.data_ptr()),
                                   ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream_ptr(dev))
         _lib.check(rc, "om_postprocess")
-        return out_bbox, out_cls, out_mask, out_count, out_keep, (bboxes, oriens)     # keep the inputs alive
+        return out_bbox, out_cls, out_mask, out_count, out_keep, (bboxes, oriens), predict     # keep the inputs alive
 
     def collect(self, outs):
-        """The one host synchronisation of the batch: read the per-image counts, slice the outputs."""
+        """The one host synchronisation of the batch: read the per-image counts (and the forward's status word behind them),
+        slice the outputs.  A forward that left the range of the split-operand representation (OM_STATUS_SPLIT_RANGE,
+        model.resolve_status) is repeated here with fp32 operands and postprocessed again; a stream-K time-out raises."""
         out_bbox, out_cls, out_mask, out_count, out_keep = outs[:5]
-        counts = out_count.cpu().tolist()
+        B = out_bbox.shape[0]
+        host = out_count.cpu().tolist()
+        counts = host[:B]
+        flags = 0
+        for v in host[B:]:
+            flags |= int(v)
+        if flags:
+            from .model import resolve_status
+            return self.apply(resolve_status(outs[6], flags))
         mask_bool = out_mask.view(torch.bool)
         self.last_keep = [out_keep[b, :k] for b, k in enumerate(counts)]
         return [{"bbox": out_bbox[b, :k], "mask": mask_bool[b, :k], "cls": out_cls[b, :k]}

@@ -11,6 +11,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "liborienmask_hip.so")
 
 OM_MAX_SCALES = 3
 OM_MAX_ANCHORS = 9
+OM_STATUS_SPLIT_RANGE = 1      # include/orienmask_hip.h: bits of the forward's status word
+OM_STATUS_SK_TIMEOUT = 2
 
 
 class LayerInfo(ctypes.Structure):
@@ -55,10 +57,10 @@ SIGNATURES = {
     "om_model_load_weights_split": (_i, [_vp, _vp, _sz]),
     "om_model_set_precision": (_i, [_vp, _i]),
     "om_model_get_precision": (_i, [_vp]),
-    "om_debug_split_tile": (_i, [_i, _i]),
-    "om_conv2d_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
-    "om_conv2d_winograd24_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "om_conv2d_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "om_conv2d_winograd24_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp, _vp]),
     "om_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "om_forward_status_offset": (_sz, [_vp, _i, _i, _i]),
     "om_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "om_layer_tile": (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                            ctypes.POINTER(ctypes.c_int)]),

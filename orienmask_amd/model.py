@@ -9,6 +9,9 @@ state_dict, so ``build(config['model'], orienmask_amd.model)`` followed by
 
 Differences a caller can observe (documented in INTEGRATION.md):
   * inference only: forward() raises in training mode and on CPU tensors (no fallback);
+  * forward() returns a ``Prediction``: the reference's tuple ((bbox32, orien32), (bbox16, orien16), (bbox8, orien8)) -- it
+    indexes, unpacks and iterates as one -- that also carries the forward's device-side status word, which
+    ``orienmask_amd.eval.OrienMaskYOLOPostProcess`` reads together with the detection counts;
   * the three box tensors come back with the reference's SHAPE [B, A*(5+C), nH, nW] but in
     channels-last memory (NHWC, 256-float pixel stride); the orientation tensors are views of one
     contiguous [B, 6A, H/4, W/4] buffer exactly as torch.split returns them in the reference.
@@ -25,6 +28,64 @@ from . import pack as _pack
 from .arch import model_convs, state_dict_entries
 
 HEAD_PIX_STRIDE = 256
+PRECISIONS = ("f32", "f32_split", "f16")
+DEFAULT_PRECISION = "f32_split"
+
+
+class Prediction(tuple):
+    """What forward() returns: the reference's nested tuple of head tensors
+    (/root/reference/model/orienmask_yolo_fpnplus.py:88-90) plus
+      status     int32 device tensor, one word per launched sub-batch: the forward's status word(s)
+                 (include/orienmask_hip.h: OM_STATUS_*), copied out of the workspace on the launch stream; None in the fp16
+                 configuration, which has nothing to report
+      precision  the arithmetic that produced the heads ('f32', 'f32_split', 'f16')
+      rerun      callable: the same input through the fp32-operand kernels (precision 'f32') in the same workspace slot,
+                 on the current stream -- what a set OM_STATUS_SPLIT_RANGE asks for; None when precision is not 'f32_split'
+    Nothing here synchronises; check() does."""
+
+    def __new__(cls, items, status=None, precision=None, rerun=None):
+        self = super().__new__(cls, items)
+        self.status = status
+        self.precision = precision
+        self.rerun = rerun
+        return self
+
+    def flags(self):
+        """Host value of the status word(s), OR-ed (one device-to-host copy; synchronises)."""
+        if self.status is None:
+            return 0
+        out = 0
+        for v in self.status.cpu().tolist():
+            out |= int(v)
+        return out
+
+    def check(self):
+        """Synchronous form of what the postprocess does with its own host read: returns self when the status is clean, the
+        fp32-operand re-run when the split representation's range was left, raises on a stream-K time-out."""
+        return resolve_status(self, self.flags())
+
+
+_warned_range = False
+
+
+def resolve_status(pred, flags):
+    """flags: host value of pred.status.  -> the Prediction whose heads are valid."""
+    global _warned_range
+    if flags & _lib.OM_STATUS_SK_TIMEOUT:
+        raise _lib.OrienMaskHipError("om_forward: a stream-K finisher timed out waiting for its partner workgroup "
+                                     "(OM_STATUS_SK_TIMEOUT); the outputs of this batch are invalid")
+    if flags & _lib.OM_STATUS_SPLIT_RANGE:
+        if pred.rerun is None:
+            raise _lib.OrienMaskHipError("om_forward: OM_STATUS_SPLIT_RANGE is set and the prediction has no fp32 re-run")
+        if not _warned_range:
+            import warnings
+            warnings.warn("orienmask_amd: an activation left the fp16 range of the split-operand representation "
+                          "(precision 'f32_split': |layer input| < 65504, < ~3275 in front of a stride-1 3x3 layer), or the fp32 "
+                          "result itself is non-finite; this batch is re-run with fp32 operands (precision 'f32').  Set "
+                          "precision='f32' for a checkpoint that does this on every batch.")
+            _warned_range = True
+        return pred.rerun()
+    return pred
 
 
 class _Node(nn.Module):
@@ -47,7 +108,9 @@ class OrienMaskYOLOFPNPlus(nn.Module):
     VARIANT = 0          # om_model_create_variant id
 
     def __init__(self, num_anchors, num_classes, pretrained=None, freeze_backbone=False,
-                 backbone_batchnorm_eval=False):
+                 backbone_batchnorm_eval=False, precision=DEFAULT_PRECISION):
+        """The reference's arguments (model/orienmask_yolo_fpnplus.py:9-10) plus `precision`, which a config dict may carry
+        (`build(config['model'], orienmask_amd.model)` passes every key on, trainer/builder.py:61-64): see set_precision."""
         super().__init__()
         self.num_anchors = num_anchors
         self.num_classes = num_classes
@@ -81,7 +144,7 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         self._packed = None          # device blob currently bound to the handle
         self._packed16 = None        # fp16 convolution weights (precision == "f16")
         self._packed_split = None    # hi/lo fp16 pairs of the F(2x4) weights (precision == "f32_split")
-        self.precision = "f32"
+        self.set_precision(precision)
         self.n_streams = 1           # set_streams(): sub-batches on side HIP streams
         self._side_streams = {}
         self._packed_device = None
@@ -155,12 +218,16 @@ class OrienMaskYOLOFPNPlus(nn.Module):
 
     # ------------------------------------------------------------------ fp16-activation configuration
     def set_precision(self, precision):
-        """'f32' (default; the parity path), 'f32_split' (fp32 tensors everywhere; the F(2x4) Winograd GEMMs carry each fp32
-        operand as a hi/lo fp16 pair and multiply on the fp16 matrix pipe with fp32 accumulation -- include/orienmask_hip.h:
-        om_model_set_precision) or 'f16': fp16 activations and convolution weights, fp32 accumulation, fp32 head tensors
-        (BASELINE.json configs[4]; include/orienmask_hip.h: om_forward_f16)."""
-        if precision not in ("f32", "f32_split", "f16"):
-            raise ValueError("precision must be 'f32', 'f32_split' or 'f16', got %r" % (precision,))
+        """'f32_split' (the default): fp32 tensors and fp32 accumulation everywhere; every convolution but the stem carries
+        each fp32 operand as a hi/lo fp16 pair and multiplies on the fp16 matrix pipe (three matrix instructions per product
+        group; include/orienmask_hip.h: om_model_set_precision).  As close to the float64 answer as fp32 operands
+         while activations stay inside fp16's range; a forward that leaves it raises OM_STATUS_SPLIT_RANGE on
+        the device and the batch is re-run with 'f32' (Prediction.rerun; the postprocess does it with its own host read).
+        'f32': fp32 operands on v_mfma_f32_32x32x2_f32, no range condition, 1.5x slower.
+        'f16': fp16 activations and convolution weights, fp32 accumulation, fp32 head tensors (BASELINE.json configs[4];
+        include/orienmask_hip.h: om_forward_f16) -- narrower arithmetic, never a default."""
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be one of %s, got %r" % (PRECISIONS, precision))
         self.precision = precision
         return self
 
@@ -168,8 +235,7 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         h = self._ensure_handle()
         if self._packed_split is None or self._packed_split.device != device:
             total = _lib.load().om_model_weight_split_words(h)
-            self.bind_packed_split(_pack.pack_state_dict_split(self.state_dict(), self._layers, total,
-                                                               self.packed_weights(device).cpu()).to(device))
+            self.bind_packed_split(_pack.pack_state_dict_split(self.state_dict(), self._layers, total).to(device))
         return self._packed_split
 
     def bind_packed_split(self, blob):
@@ -236,16 +302,18 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         _lib.require_cuda_tensor(x, "x", torch.float32)
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
             raise ValueError("x must be [B,3,H,W] with H and W multiples of 32, got %s" % (tuple(x.shape),))
-        x = x.contiguous()
+        return self._forward(x.contiguous(), self.precision, self._slot)
+
+    def _forward(self, x, precision, slot):
         B, _, H, W = x.shape
         dev = x.device
         L = _lib.load()
         self.packed_weights(dev)
-        f16 = self.precision == "f16"
+        f16 = precision == "f16"
         if f16:
             self.packed_weights_f16(dev)
         h = self._handle
-        split = self.precision == "f32_split"
+        split = precision == "f32_split"
         if split:
             self.packed_weights_split(dev)
         _lib.check(L.om_model_set_precision(h, 1 if split else 0), "om_model_set_precision")
@@ -254,12 +322,13 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         n_sub = self.n_streams if (self.n_streams > 1 and B % self.n_streams == 0) else 1
         Bs = B // n_sub
         key = (dev, Bs, H, W, f16, n_sub, split)
-        cache = self._workspace if self._slot == 0 else self._slot_workspaces.setdefault(self._slot, {})
+        cache = self._workspace if slot == 0 else self._slot_workspaces.setdefault(slot, {})
         ws = cache.get(key)
         if ws is None:
             nbytes = (L.om_forward_f16_workspace_bytes if f16 else L.om_forward_workspace_bytes)(h, Bs, H, W)
             nbytes = (nbytes + 255) // 256 * 256
-            cache.clear()
+            for k in [k for k in cache if k[:6] != key[:6]]:      # another shape: drop; the fp32-operand re-run of a split
+                del cache[k]                                      # forward keeps its workspace next to the split one
             ws = torch.empty(nbytes * n_sub, dtype=torch.uint8, device=dev)
             cache[key] = ws
         ws_each = ws.numel() // n_sub
@@ -288,9 +357,16 @@ class OrienMaskYOLOFPNPlus(nn.Module):
                     _lib.check(launch(i, ctypes.c_void_p(side[i].cuda_stream)), "om_forward")
                 for i in range(n_sub):
                     cur.wait_stream(side[i])
+            # the status word of every launched sub-batch, copied out of the workspace (which the next forward in this slot
+            # clears) on the stream the caller's later work is ordered behind
+            status = None
+            if not f16:
+                off = L.om_forward_status_offset(h, Bs, H, W)
+                status = ws.view(n_sub, ws_each)[:, off:off + 4].clone().view(torch.int32).reshape(n_sub)
         bboxes = [t[..., :bbox_dim].permute(0, 3, 1, 2) for t in heads]
         o32, o16, o8 = torch.split(oriens, A * 2, dim=1)
-        return (bboxes[0], o32), (bboxes[1], o16), (bboxes[2], o8)
+        rerun = (lambda: self._forward(x, "f32", slot)) if split else None
+        return Prediction(((bboxes[0], o32), (bboxes[1], o16), (bboxes[2], o8)), status=status, precision=precision, rerun=rerun)
 
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, enable=True):

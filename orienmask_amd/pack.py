@@ -73,23 +73,31 @@ def winograd_weights(w, cout_pad, planes=16):
     return out
 
 
+def folded_epilogue(sd, l):
+    """(weight tensor, scale float64 [cout], shift float64 [cout]) of layer l: eval-mode BatchNorm folded in float64
+    (module docstring), or scale 1 / shift = bias for the bias-only head convolutions."""
+    name, cout = l["name"], l["cout"]
+    if l["has_bn"]:
+        w = sd[name + ".conv_block.0.weight"]
+        p = name + ".conv_block.1."
+        gamma, beta = sd[p + "weight"].double().cpu(), sd[p + "bias"].double().cpu()
+        mean, var = sd[p + "running_mean"].double().cpu(), sd[p + "running_var"].double().cpu()
+        scale = gamma / torch.sqrt(var + BN_EPS)
+        shift = beta - mean * scale
+    else:
+        w = sd[name + ".weight"]
+        scale = torch.ones(cout, dtype=torch.float64)
+        shift = sd[name + ".bias"].double().cpu()
+    return w, scale, shift
+
+
 def pack_state_dict(state_dict, layers, total_floats):
     """Returns a CPU float32 tensor of total_floats elements laid out as the graph expects."""
     sd = unwrap_checkpoint(state_dict)
     blob = torch.zeros(total_floats, dtype=torch.float32)
     for l in layers:
         name, cin, cout, cpad, k = l["name"], l["cin"], l["cout"], l["cout_pad"], l["ksize"]
-        if l["has_bn"]:
-            w = sd[name + ".conv_block.0.weight"]
-            p = name + ".conv_block.1."
-            gamma, beta = sd[p + "weight"].double().cpu(), sd[p + "bias"].double().cpu()
-            mean, var = sd[p + "running_mean"].double().cpu(), sd[p + "running_var"].double().cpu()
-            scale = gamma / torch.sqrt(var + BN_EPS)
-            shift = beta - mean * scale
-        else:
-            w = sd[name + ".weight"]
-            scale = torch.ones(cout, dtype=torch.float64)
-            shift = sd[name + ".bias"].double().cpu()
+        w, scale, shift = folded_epilogue(sd, l)
         if tuple(w.shape) != (cout, cin, k, k):
             raise _lib.OrienMaskHipError("%s: weight shape %s, expected %s" % (name, tuple(w.shape), (cout, cin, k, k)))
         ohwi = w.detach().float().cpu().permute(0, 2, 3, 1).reshape(cout, k * k * cin)
@@ -178,15 +186,17 @@ def conv_weights_split(w, cout_pad):
     return torch.cat((hi, lo), dim=-2).contiguous(), e.to(torch.int32)
 
 
-def pack_state_dict_split(state_dict, layers, total_words, scale_blob):
+def pack_state_dict_split(state_dict, layers, total_words):
     """CPU float32-typed tensor of total_words 4-byte words: per layer (all but the stem) the split weights (two fp16 per
-    word; the F(2x4) planes of the stride-1 3x3 layers, the direct weights of the others) and [cout_pad] floats scale * 2^-e.  scale_blob: the float32 blob of pack_state_dict (source of the folded BN scales)."""
+    word; the F(2x4) planes of the stride-1 3x3 layers, the direct weights of the others) and [cout_pad] floats scale * 2^-e,
+    scale being the folded BatchNorm scale ROUNDED TO FLOAT32 exactly as pack_state_dict stores it (the two precision modes
+    then differ in their products only)."""
     sd = unwrap_checkpoint(state_dict)
     blob = torch.zeros(total_words, dtype=torch.float32)
     for l in layers:
         if l.get("wsplit_off", -1) < 0:
             continue
-        w = sd[l["name"] + (".conv_block.0.weight" if l["has_bn"] else ".weight")]
+        w, scale64, _ = folded_epilogue(sd, l)
         cpad, cin = l["cout_pad"], l["cin"]
         if l.get("wino_planes", 0) == 24:
             us, e = winograd_weights_split(w, cpad)
@@ -194,6 +204,7 @@ def pack_state_dict_split(state_dict, layers, total_words, scale_blob):
             us, e = conv_weights_split(w, cpad)
         n = us.numel() // 2
         blob[l["wsplit_off"]:l["wsplit_off"] + n] = us.reshape(-1).view(torch.float32)
-        scale = scale_blob[l["scale_off"]:l["scale_off"] + cpad].double().cpu()
+        scale = torch.zeros(cpad, dtype=torch.float64)
+        scale[:l["cout"]] = scale64.float().double()
         blob[l["wsplit_scale_off"]:l["wsplit_scale_off"] + cpad] = (scale * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e.double())).float()
     return blob

@@ -9,7 +9,7 @@ unchanged (whole batches, unlike model.set_streams' sub-batches); each batch in 
 (tools/pipelined_steps.py): fp32 29.6 -> 27.4 ms per batch, fp16 9.5 -> 8.4 ms.  End to end (bench.py) a third batch in flight
 changes nothing in fp32 and adds 2.5 % in fp16, whose steps are a third as long; a fourth costs 3 %.
 
-The reference runs one batch at a time (/root/reference/infer.py:92-110, /root/reference/eval/evaluator.py: one
+The reference runs one batch at a time (/root/reference/infer.py:150-156, /root/reference/trainer/tester.py:36-44: one
 `model(image)` + `postprocess(predict)` per loader iteration, synchronising on `.cpu()` each time); its loop
 
     for image in loader:  dets = postprocess(model(image))
@@ -35,9 +35,11 @@ class InFlightPipeline:
             raise ValueError("depth must be >= 1")
         self.model = model.eval()
         self.depth = int(depth)
-        # one postprocess instance per slot: same configuration, own workspace cache
-        self._posts = [postprocess]
-        for _ in range(self.depth - 1):
+        # PRIVATE resources per batch in flight: forward workspace slots 1..depth (slot 0 stays the eager model(x) path's, which
+        # runs on the caller's stream: sharing it would race with a pending batch on a side stream) and one copy of the
+        # postprocess per slot -- same configuration, own workspace cache
+        self._posts = []
+        for _ in range(self.depth):
             p = copy.copy(postprocess)
             p._ws = {}
             self._posts.append(p)
@@ -62,7 +64,7 @@ class InFlightPipeline:
             streams.append(torch.cuda.Stream(device=dev))
         s = streams[slot]
         s.wait_stream(torch.cuda.current_stream(dev))          # the image was produced on the caller's stream
-        with torch.cuda.stream(s), torch.no_grad(), self.model.workspace_slot(slot):
+        with torch.cuda.stream(s), torch.no_grad(), self.model.workspace_slot(slot + 1):
             outs = self._posts[slot].launch(self.model(image))
             done = torch.cuda.Event()
             done.record(s)
@@ -70,7 +72,9 @@ class InFlightPipeline:
         self._pending.append((slot, outs, done, dev))
 
     def result(self):
-        """Detections of the oldest pending batch (list of dicts as OrienMaskYOLOPostProcess.apply returns them)."""
+        """Detections of the oldest pending batch (list of dicts as OrienMaskYOLOPostProcess.apply returns them).  If that
+        batch's forward reported OM_STATUS_SPLIT_RANGE, collect() re-runs it with fp32 operands on the caller's stream, in the
+        batch's own workspace slot (it is free: the batch has finished)."""
         if not self._pending:
             raise RuntimeError("InFlightPipeline: nothing in flight")
         slot, outs, done, dev = self._pending.popleft()

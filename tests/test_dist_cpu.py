@@ -36,6 +36,12 @@ def _worker(rank, world, port, q):
     b16 = pack.pack_state_dict_f16(net.state_dict(), net._layers, n16) if rank == 0 else None
     got16 = omd.broadcast_blob(b16, n16, torch.device("cpu"), src=0, dtype=torch.float16)
     ok_blob = ok_blob and bool(torch.equal(got16, pack.pack_state_dict_f16(synth.synth_state_dict(9), net._layers, n16)))
+    # ... and so does the split blob of the default precision (hi/lo fp16 pairs of every layer's weights + their scales)
+    ns = omlib.load().om_model_weight_split_words(h)
+    bs = pack.pack_state_dict_split(net.state_dict(), net._layers, ns) if rank == 0 else None
+    gots = omd.broadcast_blob(bs, ns, torch.device("cpu"), src=0)
+    ok_blob = ok_blob and ns > 0 and bool(torch.equal(gots.view(torch.int32), pack.pack_state_dict_split(
+        synth.synth_state_dict(9), net._layers, ns).view(torch.int32)))
     start, stop = omd.shard_range(67, rank, world)
     merged = omd.gather_detections([{"image": i} for i in range(start, stop)])
     q.put((rank, ok_blob, start, stop, [m["image"] for m in merged]))

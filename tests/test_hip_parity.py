@@ -62,14 +62,15 @@ def _check_detections(r, want_bbox, want_cls, want_mask, tag, exact_decode):
         assert _mask_iou(got_mask[k], want_mask[k]) >= 1 - 1e-4, (tag, k)
 
 
-def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol=5e-5, nms_post=100, mask_iou_min=0.999, flip_max=2):
+def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol=5e-5, nms_post=100):
     """HIP forward + HIP postprocess against the reference's forward + postprocess.  The two forwards differ by ~1e-6 of the
     head tensors' scale (another summation order), i.e. scores differ by up to a few 1e-5 relative, so the comparison is
     exact EXCEPT where the reference's own answer hinges on a gap smaller than that:
-      * detections are matched one to one (same class, box within 1e-4, mask IoU >= 0.999 or at most flip_max = 2 differing
-        pixels: a 1e-6 perturbation of the orientation field -- 1e-4 pixels where the offsets reach 100 -- flips a boundary
-        pixel in roughly one mask of ten, which is 1e-4 of a 544 x 544 mask but 2e-3 of the few-hundred-pixel masks of the
-        160 x 128 fixture; on identical heads the masks are identical, see _check_detections) irrespective of position;
+      * detections are matched one to one irrespective of position: same class, box within 1e-4, and mask IoU >= 1 - 1e-4
+        (north_star) on images of 200 pixels and more; below that (the 160 x 128 fixture, whose masks have a few hundred
+        pixels, so that ONE boundary pixel flipped by a 1e-6 perturbation of the orientation field is already 1e-3 of a mask)
+        IoU >= 0.999 or at most 2 differing pixels.  The observed flips are printed per image (pytest -s / -rP); on identical
+        heads the masks are identical, see _check_detections;
       * position by position the scores agree within score_tol: detections may only trade places with near-ties;
       * when the list is cut at nms_post, a detection within score_tol of the last score may be replaced by its runner-up.
     Exact ties inside the reference's list (torch.topk / sort leave their order unspecified) are covered by the same rule."""
@@ -81,16 +82,28 @@ def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol
     ws, gs = want_bbox[:, 4], got_bbox[:, 4]
     if K >= 2 and (np.diff(ws) <= 0).all():                     # score-ordered output: positions may only move among near-ties
         assert np.all(np.abs(gs - ws) <= score_tol * np.maximum(ws, 1e-3)), (tag, np.abs(gs - ws).max())
+    small = min(want_mask.shape[1:]) < 200
+    mask_iou_min, flip_max = (0.999, 2) if small else (1 - 1e-4, 0)
     used = np.zeros(K, dtype=bool)
     unmatched = []
+    flips, worst_iou = 0, 1.0
     for i in range(K):
         cand = np.nonzero((~used) & (got_cls == want_cls[i]) & (np.abs(got_bbox - want_bbox[i]).max(1) <= 1e-4))[0]
-        hit = [j for j in cand if _mask_iou(got_mask[j], want_mask[i]) >= mask_iou_min or
-               np.count_nonzero(got_mask[j].astype(bool) != want_mask[i].astype(bool)) <= flip_max]
+        hit = None
+        for j in cand:
+            iou = _mask_iou(got_mask[j], want_mask[i])
+            nflip = int(np.count_nonzero(got_mask[j].astype(bool) != want_mask[i].astype(bool)))
+            if iou >= mask_iou_min or nflip <= flip_max:
+                hit = (j, iou, nflip)
+                break
         if hit:
             used[hit[0]] = True
+            flips += hit[2]
+            worst_iou = min(worst_iou, hit[1])
         else:
             unmatched.append(i)
+    print("composed %s: %d detections, %d differing mask pixels in all, worst mask IoU %.6f, %d unmatched"
+          % (tag, K, flips, worst_iou, len(unmatched)))
     at_cut = [i for i in unmatched if K == nms_post and ws[i] <= ws.min() * (1 + score_tol)]
     assert len(unmatched) == len(at_cut) <= 1, (tag, "detections without a counterpart", unmatched, ws[unmatched])
     # a candidate-ordered list (no top-k anywhere) has no freedom at all
@@ -219,12 +232,14 @@ def test_conv_split_layer_matches_torch(dev, case):
     wd, sd_, hd = ws.to(dev), sp.to(dev), hp.to(dev)
     rd = res.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None
     out = torch.full((B, Ho, Wo, cout), float("nan"), device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
     rc = L.om_conv2d_split(_p(xd), B, H, W, cin, cin, _p(wd), _p(sd_), _p(hd), cout, k, stride, leaky,
-                           _p(rd) if use_res else None, cout if use_res else 0, _p(out), cout, 0, 1,
+                           _p(rd) if use_res else None, cout if use_res else 0, _p(out), cout, 0, 1, 0, 0, _p(status),
                            omlib.current_stream_ptr(dev))
     omlib.check(rc, "om_conv2d_split")
     got = out.cpu().permute(0, 3, 1, 2).double()
     assert torch.isfinite(got).all()
+    assert int(status.item()) == 0                      # finite outputs: the range guard stays clear
     err = _rel_err(got, want)
     print("conv split %s: %.2e" % (case, err))
     assert err < 2e-6, case
@@ -258,14 +273,14 @@ def test_conv_split_output_modes(dev, mode):
         buf = torch.full((B, H * up, W * up, 256), 7.0, device=dev)
         view = buf[..., 128:]
         rc = L.om_conv2d_split(_p(xd), B, H, W, cin, cin, _p(wd), _p(sd_), _p(hd), cout, 1, 1, leaky, None, 0,
-                               ctypes.c_void_p(view.data_ptr()), 256, 1, up, omlib.current_stream_ptr(dev))
+                               ctypes.c_void_p(view.data_ptr()), 256, 1, up, 0, 0, None, omlib.current_stream_ptr(dev))
         omlib.check(rc, "om_conv2d_split")
         got = buf[..., 128:128 + cout].cpu().permute(0, 3, 1, 2).double()
         assert (torch.cat([buf[..., :128], buf[..., 128 + cout:]], -1) == 7.0).all()
     else:
         out = torch.full((B, cout, H, W), float("nan"), device=dev)
         rc = L.om_conv2d_split(_p(xd), B, H, W, cin, cin, _p(wd), _p(sd_), _p(hd), cout, 1, 1, leaky, None, 0,
-                               _p(out), cout, 2, 1, omlib.current_stream_ptr(dev))
+                               _p(out), cout, 2, 1, 0, 0, None, omlib.current_stream_ptr(dev))
         omlib.check(rc, "om_conv2d_split")
         got = out.cpu().double()
     assert torch.isfinite(got).all()
@@ -401,8 +416,9 @@ def test_winograd24_split_layer_matches_torch(dev, case):
             ud, sd_ = us.to(dev), sps.to(dev)
             fn = L.om_conv2d_winograd24_split
         hd = hp.to(dev)
+        extra = (None,) if mode == "split" else ()          # status_dev
         rc = fn(_p(xd), B, H, W, cin, cin, _p(ud), _p(sd_), _p(hd), cout, leaky, _p(rd) if use_res else None,
-                cout if use_res else 0, _p(out), cout, _p(scratch), scratch.numel(), omlib.current_stream_ptr(dev))
+                cout if use_res else 0, _p(out), cout, _p(scratch), scratch.numel(), *extra, omlib.current_stream_ptr(dev))
         omlib.check(rc, "om_conv2d_winograd24 " + mode)
         got = out.cpu().permute(0, 3, 1, 2).double()
         assert torch.isfinite(got).all(), mode
@@ -416,7 +432,8 @@ def test_winograd24_split_layer_matches_torch(dev, case):
 def test_split_operand_range(dev, gain, finite):
     """The documented range of split operands (include/orienmask_hip.h: om_model_set_precision): activations 100x larger than a
     BatchNorm-ed network produces are still exact to fp32 level (the error is relative, so it does not grow with the scale),
-    and inputs whose transform exceeds fp16's 65504 give non-finite outputs -- loud, never a silently wrong number."""
+    and inputs whose transform exceeds fp16's 65504 give non-finite outputs AND raise OM_STATUS_SPLIT_RANGE in the status word
+    -- loud, never a silently wrong number."""
     from orienmask_amd.pack import winograd_weights_split
     B, H, W, cin, cout = 2, 16, 20, 64, 64
     L = omlib.load()
@@ -430,15 +447,31 @@ def test_split_operand_range(dev, gain, finite):
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
     out = torch.full((B, H, W, cout), float("nan"), device=dev)
     scratch = torch.empty(L.om_conv2d_winograd24_scratch_bytes(B, H, W, cin), dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
     rc = L.om_conv2d_winograd24_split(_p(xd), B, H, W, cin, cin, _p(us.to(dev)), _p(sps), _p(hd), cout, 0, None, 0, _p(out), cout,
-                                      _p(scratch), scratch.numel(), omlib.current_stream_ptr(dev))
+                                      _p(scratch), scratch.numel(), _p(status), omlib.current_stream_ptr(dev))
     omlib.check(rc, "om_conv2d_winograd24_split")
     got = out.cpu().permute(0, 3, 1, 2).double()
     if finite:
         assert torch.isfinite(got).all()
         assert _rel_err(got, want) < 5e-6
+        assert int(status.item()) == 0
     else:
         assert not torch.isfinite(got).all()
+        assert int(status.item()) == omlib.OM_STATUS_SPLIT_RANGE
+    # the 1x1 / stride-2 kernel: raw activations beyond 65504 (no transform in front of them)
+    from orienmask_amd.pack import conv_weights_split
+    w1 = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    ws, e1 = conv_weights_split(w1, cout)
+    sp1 = torch.pow(torch.tensor(2.0, dtype=torch.float64), -e1.double()).float().to(dev)
+    x1 = (x / gain * (100.0 if finite else 7.0e4)).permute(0, 2, 3, 1).contiguous().to(dev)
+    status.zero_()
+    out1 = torch.empty((B, H, W, cout), device=dev)
+    rc = L.om_conv2d_split(_p(x1), B, H, W, cin, cin, _p(ws.to(dev)), _p(sp1), _p(hd), cout, 1, 1, 0, None, 0, _p(out1), cout, 0, 1,
+                           0, 0, _p(status), omlib.current_stream_ptr(dev))
+    omlib.check(rc, "om_conv2d_split")
+    assert bool(torch.isfinite(out1).all()) == finite
+    assert int(status.item()) == (0 if finite else omlib.OM_STATUS_SPLIT_RANGE)
 
 
 def test_stem_matches_torch(dev):
@@ -474,8 +507,8 @@ def _hip_model(sd, dev, precision="f32"):
 @pytest.mark.parametrize("precision", ["f32", "f32_split"])
 @pytest.mark.parametrize("fname", golden_files("fwd_"))
 def test_forward_matches_reference_golden(dev, fname, precision):
-    """HIP forward vs tensors the real reference produced (tests/golden/fwd_*.npz), with fp32 and with split operands in the
-    F(2x4) Winograd GEMMs (the latter only changes the batch-of-6 fixture: smaller batches run F(2x2), which has no split form)."""
+    """HIP forward vs tensors the real reference produced (tests/golden/fwd_*.npz), with fp32 operands and with split operands
+    (every convolution but the stem; the stride-1 3x3 layers run F(2x4) at every batch size in that mode)."""
     g = np.load(os.path.join(GOLDEN, fname))
     size = tuple(int(v) for v in g["size"]); batch = int(g["batch"])
     sd = synth.synth_state_dict(int(g["wseed"]), obj_bias=float(g["obj_bias"]), head_gain=float(g["head_gain"]))
@@ -1409,3 +1442,85 @@ def test_end_to_end_f16_agrees_with_f32(dev, xseed):
             miou = (mi & mj).sum().item() / max((mi | mj).sum().item(), 1)
             matched += int(iou[j] > 0.9 and miou > 0.9)
         assert matched >= 0.9 * int(conf.sum()), (matched, int(conf.sum()))
+
+
+# ------------------------------------------------------------------------------------------------
+# the range guard of the default precision (include/orienmask_hip.h: OM_STATUS_SPLIT_RANGE)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("gain", [3.0e3, 1.0e5])
+def test_forward_range_guard_falls_back_to_f32(dev, gain):
+    """precision 'f32_split' is the plugin's default, so its range condition is guarded on the device: an input scaled until
+    activations leave fp16's range (gain 1e5: already in front of the first stride-2 layer; 3e3: only the TRANSFORMED input of
+    a stride-1 3x3 layer, up to 20x the activation, does) sets OM_STATUS_SPLIT_RANGE through om_forward, and what the caller
+    gets -- Prediction.check(), or simply postprocess(model(x)) -- is the fp32-operand result, bit for bit.  An ordinary input
+    leaves the status word clear."""
+    import warnings
+    from orienmask_amd import model as om_model
+    assert om_model.OrienMaskYOLOFPNPlus(3, 80).precision == "f32_split"        # the default IS the guarded mode
+    sd = synth.synth_state_dict(12, obj_bias=-3.0, head_gain=0.7)
+    x = synth.synth_image_batch(77, 2, 160, 128)
+    xs = (x * gain).to(dev)
+    net = _hip_model(sd, dev, "f32_split")
+    ref = _hip_model(sd, dev, "f32")
+    post = _hip_post((160, 128), dev)
+    with torch.no_grad():
+        clean = net(x.to(dev))
+        assert clean.precision == "f32_split" and clean.flags() == 0 and clean.check() is clean
+        pred = net(xs)
+        assert pred.flags() == omlib.OM_STATUS_SPLIT_RANGE
+        assert not all(bool(torch.isfinite(b).all()) for b, _ in pred)          # the split forward's heads are NaN, and say so
+        want = ref(xs)
+        assert want.flags() == 0 and all(bool(torch.isfinite(b).all() and torch.isfinite(o).all()) for b, o in want)
+        om_model._warned_range = False
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            fixed = pred.check()
+        assert any("re-run with fp32 operands" in str(m.message) for m in w)
+        assert fixed.precision == "f32"
+        for (gb, go), (wb, wo) in zip(fixed, want):
+            assert torch.equal(gb, wb) and torch.equal(go, wo)
+        dets, dets_want = post(pred), post(want)                                # the postprocess resolves the status itself
+    for d, dw in zip(dets, dets_want):
+        assert all(torch.equal(d[k], dw[k]) for k in ("bbox", "cls", "mask"))
+    # ... and inside the in-flight pipeline, between two ordinary batches
+    from orienmask_amd.pipeline import InFlightPipeline
+    pipe = InFlightPipeline(net, post, depth=2)
+    with torch.no_grad():
+        out = list(pipe.map([x.to(dev), xs, x.to(dev)]))
+        eager_clean = post(net(x.to(dev)))
+    for d, dw in zip(out[1], dets_want):
+        assert all(torch.equal(d[k], dw[k]) for k in ("bbox", "cls", "mask"))
+    for batch in (out[0], out[2]):
+        for d, dw in zip(batch, eager_clean):
+            assert all(torch.equal(d[k], dw[k]) for k in ("bbox", "cls", "mask"))
+
+
+def test_rccl_broadcast_of_every_blob_on_one_gpu(dev):
+    """The RCCL call path of the N > 1 bench (orienmask_amd/dist.py: broadcast_packed_weights) with world size 1 on the nccl
+    backend: the fp32 blob, the split blob of the default precision and the fp16 rows travel through dist.broadcast and the
+    bound model computes the same heads as one that packed its own weights."""
+    import socket
+    import torch.distributed as dist
+    from orienmask_amd.dist import broadcast_packed_weights
+    from orienmask_amd.model import OrienMaskYOLOFPNPlus
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        sd = synth.synth_state_dict(14, obj_bias=-16.0, head_gain=4.0)
+        x = synth.synth_image_batch(15, 2, 96, 128).to(dev)
+        for prec in ("f32_split", "f16"):
+            net = OrienMaskYOLOFPNPlus(3, 80, precision=prec).eval()
+            net.load_state_dict(sd, strict=True)
+            broadcast_packed_weights(net, dev, src=0)
+            assert net._packed is not None and (net._packed_split if prec == "f32_split" else net._packed16) is not None
+            own = _hip_model(sd, dev, prec)
+            with torch.no_grad():
+                a, b = net(x), own(x)
+            for (ab, ao), (bb, bo) in zip(a, b):
+                assert torch.equal(ab, bb) and torch.equal(ao, bo)
+    finally:
+        dist.destroy_process_group()

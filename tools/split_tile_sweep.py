@@ -1,5 +1,5 @@
 """Time every distinct 1x1 / stride-2 layer shape of the bs=32, 544x544 forward with each tile shape of conv_igemm_split.hip
-(om_debug_split_tile) -> one line per (shape, tile), best first.  Input for the tile chooser in conv_igemm_split.hip."""
+(om_conv2d_split's per-call tile_bm x tile_bn) -> one line per (shape, tile), best first.  Input for the tile chooser in conv_igemm_split.hip."""
 import ctypes
 import os
 import sys
@@ -39,10 +39,9 @@ def main():
         for bm, bn in TILES:
             if cpad % bn:
                 continue
-            omlib.check(L.om_debug_split_tile(bm, bn), "tile")
             def run():
                 omlib.check(L.om_conv2d_split(p(x), B, hw, hw, cin, cin, p(wd), p(sp), p(hp), cout, k, stride, 1, None, 0,
-                                              p(out), cpad, 0, 1, omlib.current_stream_ptr(dev)), "conv")
+                                              p(out), cpad, 0, 1, bm, bn, None, omlib.current_stream_ptr(dev)), "conv")
             for _ in range(3):
                 run()
             torch.cuda.synchronize()
@@ -53,7 +52,6 @@ def main():
             b.record()
             torch.cuda.synchronize()
             res.append((a.elapsed_time(b) / 10, bm, bn))
-        omlib.check(L.om_debug_split_tile(0, 0), "tile")
         res.sort()
         M = B * ho * ho
         print("hw=%3d cin=%4d cout=%4d k=%d s=%d M=%7d x%2d  " % (hw, cin, cout, k, stride, M, len(names)) +
