@@ -268,8 +268,16 @@ __global__ __launch_bounds__(256, 2) void wino24_gemm_kernel(const Wino24Params 
             if (++n_cc == p.kc) { n_cc = 0; ++n_xi; }
         };
         auto issue_piece = [&](int piece, int buf, bool live) {
+#ifdef OM_EXP_V_RESIDENT        // upper-bound experiment (wrong numerics): every workgroup reads the SAME M panel of V -> V stays in L2
+            const float* abase = p.V + (size_t)n_xi * v_plane;
+#else
             const float* abase = p.V + (size_t)n_xi * v_plane + (size_t)m0 * p.C;
+#endif
+#ifdef OM_EXP_U_RESIDENT        // ... and / or the same N tile of U
+            const float* bbase = p.U + (size_t)n_xi * u_plane;
+#else
             const float* bbase = p.U + (size_t)n_xi * u_plane + (size_t)n0 * p.C;
+#endif
             const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(abase), 0,
                                                                live ? rows_valid * p.C * 4 : 0, 0x00020000);
             const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bbase), 0, live ? BN * p.C * 4 : 0,

@@ -9,7 +9,7 @@ unchanged (whole batches, unlike model.set_streams' sub-batches); each batch in 
 (tools/pipelined_steps.py): fp32 29.6 -> 27.4 ms per batch, fp16 9.5 -> 8.4 ms.  End to end (bench.py) a third batch in flight
 changes nothing in fp32 and adds 2.5 % in fp16, whose steps are a third as long; a fourth costs 3 %.
 
-The reference runs one batch at a time (/root/reference/infer.py:150-156, /root/reference/trainer/tester.py:36-44: one
+The reference runs one batch at a time (/root/reference/infer.py:153-156, /root/reference/trainer/tester.py:38-44: one
 `model(image)` + `postprocess(predict)` per loader iteration, synchronising on `.cpu()` each time); its loop
 
     for image in loader:  dets = postprocess(model(image))

@@ -69,6 +69,86 @@ def synth_state_dict(seed=0, num_anchors=3, num_classes=80, obj_bias=0.0, head_g
     return sd
 
 
+def synth_state_dict_stress(seed, norms=None, num_anchors=3, num_classes=80, obj_bias=-3.0, head_gain=0.7,
+                            coord_gain=0.3, orien_gain=0.2, model="OrienMaskYOLOFPNPlus"):
+    """Heavy-tailed variant of synth_state_dict for the split-operand stress fixtures (tools/gen_golden.py: fwd_stress_*):
+
+      * folded BatchNorm scale gamma / sqrt(var + eps) LOG-UNIFORM over [1e-2, 1e2] per output channel (x 0.2 on the
+        residual tails so that the residual streams stay inside fp16's range), realised with running_var log-uniform over
+        [1e-4, 1e2] and ~5 % of the channels at running_var = 1e-6;
+      * ~2 % of the convolution rows scaled down to max |w| = 1e-20 and ~2 % exactly zero (their outputs are the BatchNorm
+        shift alone): the per-output-channel power-of-two scaling of the split weights must survive both;
+      * activations therefore span ~1e-6 ... 1e3 within one tensor.
+
+    norms: one float32 per convolution (model_convs order) multiplying its weights, so that its pre-BatchNorm output has
+    unit rms on the calibration input -- measured by tools/gen_golden.py through the reference model and STORED in the
+    fixture, so that every machine regenerates the same bytes (None: all ones, the generator's first pass)."""
+    rng = _rng(seed)
+    specs = list(model_convs(model, num_anchors, num_classes))
+    if norms is None:
+        norms = np.ones(len(specs), dtype=np.float32)
+    norms = np.asarray(norms, dtype=np.float32)
+    assert norms.shape == (len(specs),)
+    sd = {}
+    for li, spec in enumerate(specs):
+        fan_in = spec.cin * spec.ksize * spec.ksize
+        cout = spec.cout
+        w = rng.standard_normal((cout, spec.cin, spec.ksize, spec.ksize), dtype=np.float32) * np.float32(np.sqrt(1.0 / fan_in))
+        w = w * norms[li]
+        kind = rng.random(cout)
+        if spec.bn:
+            s = np.power(10.0, rng.uniform(-2.0, 2.0, cout))                     # folded scale, log-uniform
+            if is_residual_tail(spec):
+                s = s * 0.2
+            var = np.power(10.0, rng.uniform(-4.0, 2.0, cout))
+            var[rng.random(cout) < 0.05] = 1e-6
+            gamma = s * np.sqrt(var + 1e-5)
+            mean = rng.standard_normal(cout) * 0.3
+            beta = rng.standard_normal(cout) * 0.1 * s
+            tiny, zero = kind < 0.02, (kind >= 0.02) & (kind < 0.04)
+            for c in np.nonzero(tiny)[0]:
+                w[c] *= np.float32(1e-20) / np.abs(w[c]).max()
+            w[zero] = 0.0
+            p = spec.name + ".conv_block"
+            sd[p + ".0.weight"] = torch.from_numpy(np.ascontiguousarray(w))
+            sd[p + ".1.weight"] = torch.from_numpy(gamma.astype(np.float32))
+            sd[p + ".1.bias"] = torch.from_numpy(beta.astype(np.float32))
+            sd[p + ".1.running_mean"] = torch.from_numpy(mean.astype(np.float32))
+            sd[p + ".1.running_var"] = torch.from_numpy(var.astype(np.float32))
+            sd[p + ".1.num_batches_tracked"] = torch.tensor(1, dtype=torch.long)
+        else:
+            gain = np.full((cout, 1, 1, 1), orien_gain, dtype=np.float32)
+            b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+            if spec.name.startswith("bbox_head"):
+                per_anchor = 5 + num_classes
+                gain[:] = head_gain
+                for a in range(num_anchors):
+                    gain[a * per_anchor:a * per_anchor + 4] = coord_gain
+                b[4::per_anchor] += np.float32(obj_bias)
+            sd[spec.name + ".weight"] = torch.from_numpy(np.ascontiguousarray(w * gain))
+            sd[spec.name + ".bias"] = torch.from_numpy(b)
+    return sd
+
+
+def synth_image_batch_stress(seed, batch, height, width):
+    """[B,3,H,W] float32 in [0,1] with SATURATED rectangles (exactly 1.0), NEAR-ZERO rectangles (~1e-6) and a smooth ramp over
+    uniform noise: the input of the split-operand stress fixtures."""
+    rng = _rng(seed)
+    x = rng.random((batch, 3, height, width), dtype=np.float32)
+    for b in range(batch):
+        for k in range(8):
+            h = int(rng.integers(height // 8, height // 2)); w = int(rng.integers(width // 8, width // 2))
+            y0 = int(rng.integers(0, height - h)); x0 = int(rng.integers(0, width - w))
+            if k % 3 == 0:
+                x[b, :, y0:y0 + h, x0:x0 + w] = 1.0
+            elif k % 3 == 1:
+                x[b, :, y0:y0 + h, x0:x0 + w] = rng.random((3, h, w), dtype=np.float32) * np.float32(1e-6)
+            else:
+                ramp = np.linspace(0.0, 1.0, w, dtype=np.float32)[None, None, :]
+                x[b, :, y0:y0 + h, x0:x0 + w] = ramp * x[b, :, y0:y0 + h, x0:x0 + w]
+    return torch.from_numpy(x)
+
+
 def synth_image_batch(seed, batch, height=544, width=544):
     """[B,3,H,W] float32 in [0,1): what FastCOCOTransform hands the model
     (/root/reference/config/base.py:158-164, Normalize std=255)."""

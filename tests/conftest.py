@@ -36,3 +36,17 @@ def built():
 
 def golden_files(prefix):
     return sorted(f for f in os.listdir(GOLDEN) if f.startswith(prefix) and f.endswith(".npz"))
+
+
+def fixture_weights_and_input(g):
+    """(state_dict, input) of a tests/golden/fwd_*.npz fixture, regenerated from its seeds (and, for the heavy-tailed stress
+    fixtures, its stored per-layer normalisation factors) -- tools/gen_golden.py made them the same way."""
+    from orienmask_amd import synth
+    size = tuple(int(v) for v in g["size"]); batch = int(g["batch"])
+    if "stress" in g.files:
+        sd = synth.synth_state_dict_stress(int(g["wseed"]), g["norms"], obj_bias=float(g["obj_bias"]), head_gain=float(g["head_gain"]))
+        x = synth.synth_image_batch_stress(int(g["xseed"]), batch, size[0], size[1])
+    else:
+        sd = synth.synth_state_dict(int(g["wseed"]), obj_bias=float(g["obj_bias"]), head_gain=float(g["head_gain"]))
+        x = synth.synth_image_batch(int(g["xseed"]), batch, size[0], size[1])
+    return sd, x

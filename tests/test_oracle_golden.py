@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, golden_files, post_cfg
+from conftest import GOLDEN, fixture_weights_and_input, golden_files, post_cfg
 from oracle import orienmask_ref as R
 from orienmask_amd import synth
 
@@ -115,8 +115,7 @@ def test_forward_matches_reference(fname):
     size = tuple(int(v) for v in g["size"]); batch = int(g["batch"])
     if size[0] > 200 and os.environ.get("OM_FAST_TESTS"):
         pytest.skip("544x544 CPU forward skipped under OM_FAST_TESTS")
-    sd = synth.synth_state_dict(int(g["wseed"]), obj_bias=float(g["obj_bias"]), head_gain=float(g["head_gain"]))
-    x = synth.synth_image_batch(int(g["xseed"]), batch, size[0], size[1])
+    sd, x = fixture_weights_and_input(g)
     out, feats = R.forward(sd, x, return_features=True)
     tensors = dict(bbox32=out[0][0], bbox16=out[1][0], bbox8=out[2][0],
                    oriens=torch.cat([out[0][1], out[1][1], out[2][1]], 1),

@@ -177,37 +177,99 @@ def main():
     ]
     for name, wseed, size, batch, xseed, obj_bias, head_gain in fwd_cases:
         sd = synth.synth_state_dict(wseed, obj_bias=obj_bias, head_gain=head_gain)
-        missing = net.load_state_dict(sd, strict=True)       # proves the 524 keys line up
         x = synth.synth_image_batch(xseed, batch, size[0], size[1])
-        with torch.no_grad():
-            feats = {}
-            x32, x16, x8, x4 = net.backbone(x)
-            feats.update(x32=x32, x16=x16, x8=x8, x4=x4)
-            out = net(x)
         rec = dict(size=np.array(size), batch=np.int64(batch), wseed=np.int64(wseed), xseed=np.int64(xseed),
                    obj_bias=np.float32(obj_bias), head_gain=np.float32(head_gain))
-        tensors = dict(bbox32=out[0][0], bbox16=out[1][0], bbox8=out[2][0],
-                       oriens=torch.cat([out[0][1], out[1][1], out[2][1]], 1), **feats)
-        full = size[0] <= 160
-        for k, t in tensors.items():
-            s, samp, idx = digest(t)
-            rec[k + "_sum"] = s; rec[k + "_samples"] = samp; rec[k + "_idx"] = idx
-            rec[k + "_shape"] = np.array(t.shape); rec[k + "_absmax"] = np.float32(t.abs().max().item())
-            if full and k in ("bbox32", "bbox16", "bbox8", "oriens"):
-                rec[k] = t.numpy()
-        # end to end through the reference postprocess
-        pc = post_cfg(size)
-        post = reval.OrienMaskYOLOPostProcess(nms_func=functools.partial(rfunc.batched_nms, threshold=0.5), **pc)
-        with torch.no_grad(), single_thread():
-            res = post(out)
-        for b, r in enumerate(res):
-            rec["bbox_det%d" % b] = r["bbox"].numpy(); rec["cls_det%d" % b] = r["cls"].numpy()
-            rec["mask%d" % b] = pack_masks(r["mask"].numpy()); rec["maskshape%d" % b] = np.array(r["mask"].shape)
-        np.savez_compressed(os.path.join(OUT, "fwd_%s.npz" % name), **rec)
-        print(name, {k: float(rec[k + "_absmax"]) for k in ("x4", "x32", "bbox32", "bbox8", "oriens")},
-              [int(r["bbox"].shape[0]) for r in res], "exact score ties among the detections:",
-              [int(r["bbox"].shape[0] - np.unique(r["bbox"][:, 4].numpy()).size) for r in res],
-              "%.0f KB" % (os.path.getsize(os.path.join(OUT, "fwd_%s.npz" % name)) / 1024))
+        write_forward_fixture(name, net, reval, rfunc, sd, x, rec, size)
+
+
+def write_forward_fixture(name, net, reval, rfunc, sd, x, rec, size):
+    """Reference forward + reference postprocess of one (weights, input) pair -> tests/golden/fwd_<name>.npz."""
+    net.load_state_dict(sd, strict=True)       # proves the 524 keys line up
+    with torch.no_grad():
+        feats = {}
+        x32, x16, x8, x4 = net.backbone(x)
+        feats.update(x32=x32, x16=x16, x8=x8, x4=x4)
+        out = net(x)
+    tensors = dict(bbox32=out[0][0], bbox16=out[1][0], bbox8=out[2][0],
+                   oriens=torch.cat([out[0][1], out[1][1], out[2][1]], 1), **feats)
+    full = size[0] <= 160
+    for k, t in tensors.items():
+        assert torch.isfinite(t).all(), k
+        s, samp, idx = digest(t)
+        rec[k + "_sum"] = s; rec[k + "_samples"] = samp; rec[k + "_idx"] = idx
+        rec[k + "_shape"] = np.array(t.shape); rec[k + "_absmax"] = np.float32(t.abs().max().item())
+        if full and k in ("bbox32", "bbox16", "bbox8", "oriens"):
+            rec[k] = t.numpy()
+    # end to end through the reference postprocess
+    pc = post_cfg(size)
+    post = reval.OrienMaskYOLOPostProcess(nms_func=functools.partial(rfunc.batched_nms, threshold=0.5), **pc)
+    with torch.no_grad(), single_thread():
+        res = post(out)
+    for b, r in enumerate(res):
+        rec["bbox_det%d" % b] = r["bbox"].numpy(); rec["cls_det%d" % b] = r["cls"].numpy()
+        rec["mask%d" % b] = pack_masks(r["mask"].numpy()); rec["maskshape%d" % b] = np.array(r["mask"].shape)
+    np.savez_compressed(os.path.join(OUT, "fwd_%s.npz" % name), **rec)
+    print(name, {k: float(rec[k + "_absmax"]) for k in ("x4", "x32", "bbox32", "bbox8", "oriens")},
+          [int(r["bbox"].shape[0]) for r in res], "exact score ties among the detections:",
+          [int(r["bbox"].shape[0] - np.unique(r["bbox"][:, 4].numpy()).size) for r in res],
+          "%.0f KB" % (os.path.getsize(os.path.join(OUT, "fwd_%s.npz" % name)) / 1024))
+    return tensors
+
+
+def stress_golden():
+    """G9: heavy-tailed weights and inputs for the split-operand precision mode.  BatchNorm scales
+    log-uniform over four decades, running_var down to 1e-6, convolution rows of magnitude 1e-20 and exactly zero, saturated and
+    near-zero image regions (orienmask_amd/synth.py: synth_state_dict_stress, synth_image_batch_stress).  Every convolution's
+    weights carry a normalisation factor measured HERE through the reference model (pre-BatchNorm output rms 1 on the fixture's
+    own input, layer by layer in execution order) and stored in the fixture, so that the 75-layer-deep activations neither
+    vanish nor overflow and every machine regenerates identical weights."""
+    import torch.nn.functional as F
+    from orienmask_amd import arch
+    cfg, rmodel, reval, rfunc = import_reference()
+    torch.set_num_threads(8)
+    mcfg = dict(cfg.orienmask_yolo_coco_544_anchor4_fpn_plus_infer["model"])
+    mcfg.pop("type"); mcfg["pretrained"] = None
+    net = rmodel.OrienMaskYOLOFPNPlus(**mcfg).eval()
+    specs = list(arch.model_convs("OrienMaskYOLOFPNPlus"))
+    for name, wseed, size, batch, xseed in (("stress_f160x128_b1", 51, (160, 128), 1, 52), ("stress_f544_b2", 53, (544, 544), 2, 54)):
+        x = synth.synth_image_batch_stress(xseed, batch, size[0], size[1])
+        net.load_state_dict(synth.synth_state_dict_stress(wseed), strict=True)
+        norms = np.ones(len(specs), dtype=np.float32)
+        mods = dict(net.named_modules())
+        hooks = []
+        for li, spec in enumerate(specs):
+            m = mods[spec.name + (".conv_block.0" if spec.bn else "")]
+
+            def pre(mod, inp, li=li):
+                rows = mod.weight.abs().amax(dim=(1, 2, 3)) > 1e-10             # the 1e-20 and zero rows keep their magnitude
+                y = F.conv2d(inp[0], mod.weight[rows], None, mod.stride, mod.padding)
+                n = np.float32(1.0 / float(y.double().pow(2).mean().sqrt()))
+                norms[li] = n
+                mod.weight.data[rows] *= float(n)
+
+            hooks.append(m.register_forward_pre_hook(pre))
+        with torch.no_grad():
+            net(x)
+        for h in hooks:
+            h.remove()
+        sd = synth.synth_state_dict_stress(wseed, norms)
+        rec = dict(size=np.array(size), batch=np.int64(batch), wseed=np.int64(wseed), xseed=np.int64(xseed),
+                   obj_bias=np.float32(-3.0), head_gain=np.float32(0.7), stress=np.int64(1), norms=norms)
+        tensors = write_forward_fixture(name, net, reval, rfunc, sd, x, rec, size)
+        # what the fixture stresses, on the reference's own activations
+        with torch.no_grad():
+            acts = []
+            hs = [m.register_forward_hook(lambda mod, i, o: acts.append(o)) for n_, m in net.named_modules()
+                  if m.__class__.__name__ == "LeakyReLU"]
+            net(x)
+            for h in hs:
+                h.remove()
+        amax = max(float(a.abs().max()) for a in acts)
+        small = float(np.mean([float((a.abs() < 1e-4).float().mean()) for a in acts]))
+        print("  %s: %d activation tensors, largest |a| = %.1f, mean fraction of |a| < 1e-4: %.3f, norms %.3g .. %.3g"
+              % (name, len(acts), amax, small, norms.min(), norms.max()))
+        assert amax < 3000.0, "the stress fixture must stay inside the split representation's range (else it tests the fallback)"
 
 
 def check_tie_fixture(post, heads, regime, res):
@@ -352,8 +414,11 @@ if __name__ == "__main__":
         yolo_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "coco":
         coco_format_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "stress":
+        stress_golden()
     else:
         main()
         yolo_golden()
         coco_format_golden()
         preprocess_golden()
+        stress_golden()
