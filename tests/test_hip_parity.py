@@ -63,15 +63,46 @@ def _check_detections(r, want_bbox, want_cls, want_mask, tag, exact_decode):
         assert _mask_iou(got_mask[k], want_mask[k]) >= 1 - 1e-4, (tag, k)
 
 
-def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol=5e-5, nms_post=100):
+def _margin_ctx(oracle_post, heads_cpu, b):
+    """What _check_detections_composed needs to judge a differing mask pixel: the orientation field of image b (the oracle's
+    arithmetic on the heads under test) and, per detection of the oracle's postprocess ON THOSE SAME HEADS (bit-identical to the
+    HIP postprocess, _check_detections), its box and anchor."""
+    coord, score, cls, aidx, sel = oracle_post.candidates(heads_cpu, b)
+    field = oracle_post.orien_field(heads_cpu, b)
+    res = oracle_post.finish(coord, score, cls, aidx, field)
+    return dict(field=field, bbox=res["bbox"].numpy(), cls=res["cls"].numpy(), anchor=res["anchor"].numpy(),
+                grid_sizes=oracle_post.grid_sizes.numpy(), orien_thresh=oracle_post.orien_thresh)
+
+
+def _borderline_flips(got_mask, want_mask, ctx, j, tol_rel=1e-4):
+    """(number of differing pixels, the largest decision margin among them in units of the field's scale).  A pixel is inside a
+    mask iff |Px - xc| < tx and |Py - yc| < ty (postprocess.py:157-164); its decision margin is how far the field would have to
+    move to change that.  Two forwards that agree to 1e-6 of scale can only disagree on pixels whose margin is of that order."""
+    diff = np.nonzero(got_mask.astype(bool) != want_mask.astype(bool))
+    if diff[0].size == 0:
+        return 0, 0.0
+    a = int(ctx["anchor"][j]); gsx, gsy = ctx["grid_sizes"][a]
+    cx, cy, w, h = (float(v) for v in ctx["bbox"][j, :4])
+    f = ctx["field"][a].numpy()
+    mx = np.abs(f[0][diff] - gsx * cx) - ctx["orien_thresh"] * w * gsx
+    my = np.abs(f[1][diff] - gsy * cy) - ctx["orien_thresh"] * h * gsy
+    inside = (mx < 0) & (my < 0)
+    d = np.where(inside, np.minimum(-mx, -my), np.maximum(np.maximum(mx, 0), np.maximum(my, 0)))
+    scale = max(float(np.abs(f).max()), 1.0)
+    return int(diff[0].size), float(d.max() / scale)
+
+
+def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol=5e-5, nms_post=100, margin_ctx=None):
     """HIP forward + HIP postprocess against the reference's forward + postprocess.  The two forwards differ by ~1e-6 of the
     head tensors' scale (another summation order), i.e. scores differ by up to a few 1e-5 relative, so the comparison is
     exact EXCEPT where the reference's own answer hinges on a gap smaller than that:
       * detections are matched one to one irrespective of position: same class, box within 1e-4, and mask IoU >= 1 - 1e-4
-        (north_star) on images of 200 pixels and more; below that (the 160 x 128 fixture, whose masks have a few hundred
-        pixels, so that ONE boundary pixel flipped by a 1e-6 perturbation of the orientation field is already 1e-3 of a mask)
-        IoU >= 0.999 or at most 2 differing pixels.  The observed flips are printed per image (pytest -s / -rP); on identical
-        heads the masks are identical, see _check_detections;
+        (north_star) -- or, since ONE boundary pixel is already more than 1e-4 of a mask smaller than 10^4 pixels, every
+        differing pixel must be BORDERLINE: its decision margin (_borderline_flips, evaluated in the oracle's arithmetic on the
+        heads under test) at most 1e-4 of the orientation field's scale -- the same 1e-4 the head tensors are held to -- and
+        at most 0.5 % of the mask's pixels + 2 may differ.  Without margin_ctx only images under 200 pixels fall back to
+        "IoU >= 0.999 or at most 2 pixels".  The observed flips are printed per image (pytest -s) and appended to
+        gpurun_out/composed_flips.txt when that directory exists;
       * position by position the scores agree within score_tol: detections may only trade places with near-ties;
       * when the list is cut at nms_post, a detection within score_tol of the last score may be replaced by its runner-up.
     Exact ties inside the reference's list (torch.topk / sort leave their order unspecified) are covered by the same rule."""
@@ -83,30 +114,48 @@ def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol
     ws, gs = want_bbox[:, 4], got_bbox[:, 4]
     if K >= 2 and (np.diff(ws) <= 0).all():                     # score-ordered output: positions may only move among near-ties
         assert np.all(np.abs(gs - ws) <= score_tol * np.maximum(ws, 1e-3)), (tag, np.abs(gs - ws).max())
+    ctx_of = None
+    if margin_ctx is not None:       # the context's detections are the HIP postprocess's own (same heads in -> same bits out;
+        key = lambda bb, c: (np.ascontiguousarray(bb[[0, 1, 4]]).tobytes(), int(c))       # centres and score are bit-identical, w / h <= 2 ulps
+        lut = {key(margin_ctx["bbox"][k], margin_ctx["cls"][k]): k for k in range(margin_ctx["bbox"].shape[0])}   # order may differ
+        ctx_of = [lut.get(key(got_bbox[j], got_cls[j])) for j in range(K)]                                        # inside exact-tie groups)
+        assert all(k is not None for k in ctx_of), (tag, "the oracle's postprocess on the same heads found other detections")
     small = min(want_mask.shape[1:]) < 200
-    mask_iou_min, flip_max = (0.999, 2) if small else (1 - 1e-4, 0)
     used = np.zeros(K, dtype=bool)
-    unmatched = []
-    flips, worst_iou = 0, 1.0
+    unmatched, notes = [], []
+    flips, worst_iou, worst_margin = 0, 1.0, 0.0
     for i in range(K):
         cand = np.nonzero((~used) & (got_cls == want_cls[i]) & (np.abs(got_bbox - want_bbox[i]).max(1) <= 1e-4))[0]
         hit = None
         for j in cand:
             iou = _mask_iou(got_mask[j], want_mask[i])
             nflip = int(np.count_nonzero(got_mask[j].astype(bool) != want_mask[i].astype(bool)))
-            if iou >= mask_iou_min or nflip <= flip_max:
-                hit = (j, iou, nflip)
+            margin = 0.0
+            ok = iou >= 1 - 1e-4
+            if not ok and margin_ctx is not None:
+                nflip, margin = _borderline_flips(got_mask[j], want_mask[i], margin_ctx, ctx_of[j])
+                ok = margin <= 1e-4 and nflip <= 2 + 0.005 * np.count_nonzero(want_mask[i])
+            elif not ok and small:
+                ok = iou >= 0.999 or nflip <= 2
+            if ok:
+                hit = (j, iou, nflip, margin)
                 break
+            notes.append((i, int(j), round(iou, 6), nflip, margin))
         if hit:
             used[hit[0]] = True
             flips += hit[2]
             worst_iou = min(worst_iou, hit[1])
+            worst_margin = max(worst_margin, hit[3])
         else:
             unmatched.append(i)
-    print("composed %s: %d detections, %d differing mask pixels in all, worst mask IoU %.6f, %d unmatched"
-          % (tag, K, flips, worst_iou, len(unmatched)))
+    line = ("composed %s: %d detections, %d differing mask pixels in all, worst mask IoU %.6f, largest decision margin of a "
+            "differing pixel %.2e of the field's scale, %d unmatched %s" % (tag, K, flips, worst_iou, worst_margin, len(unmatched), notes[:6]))
+    print(line)
+    if os.path.isdir("gpurun_out"):
+        with open(os.path.join("gpurun_out", "composed_flips.txt"), "a") as fh:
+            fh.write(line + "\n")
     at_cut = [i for i in unmatched if K == nms_post and ws[i] <= ws.min() * (1 + score_tol)]
-    assert len(unmatched) == len(at_cut) <= 1, (tag, "detections without a counterpart", unmatched, ws[unmatched])
+    assert len(unmatched) == len(at_cut) <= 1, (tag, "detections without a counterpart", unmatched, ws[unmatched], notes[:6])
     # a candidate-ordered list (no top-k anywhere) has no freedom at all
     if not (K >= 2 and (np.diff(ws) <= 0).all()) and not unmatched:
         assert np.array_equal(got_cls, want_cls), tag
@@ -533,9 +582,14 @@ def test_forward_matches_reference_golden(dev, fname, precision):
     # (its own forward feeding its own postprocess)
     res = _hip_post(size, dev)(out)
     assert len(res) == batch
+    pc = post_cfg(size)
+    oracle_post = R.PostProcessOracle(pc["grid_size"], pc["image_size"], pc["anchors"], pc["anchor_mask"], 80,
+                                      conf_thresh=pc["conf_thresh"])
+    heads_cpu = [(b_.cpu(), o_.cpu()) for b_, o_ in out]
     for b, r in enumerate(res):
         _check_detections_composed(r, g["bbox_det%d" % b], g["cls_det%d" % b],
-                                   unpack_masks(g["mask%d" % b], g["maskshape%d" % b]), (fname, b))
+                                   unpack_masks(g["mask%d" % b], g["maskshape%d" % b]), (fname, precision, b),
+                                   margin_ctx=_margin_ctx(oracle_post, heads_cpu, b))
 
 
 def test_forward_matches_oracle_and_layouts(dev):
@@ -978,8 +1032,9 @@ def test_build_tester_from_checkpoint_file(dev, tmp_path):
     stats = tester.test(verbose=False)
     assert stats["detections"] > 0
     x = synth.synth_image_batch(700, 2, 544, 544).to(dev)
+    assert tester.model.precision == "f32_split"               # a checkpoint's config without `precision` gets the plugin default
     with torch.no_grad():
-        direct = _hip_model(sd, dev)(x)
+        direct = _hip_model(sd, dev, tester.model.precision)(x)
         via_ckpt = tester.model(x)
     assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(direct, via_ckpt))
 
@@ -1249,7 +1304,8 @@ def test_headline_bs32_forward_and_postprocess(dev, precision):
         _check_detections(d, want_same_heads[i]["bbox"].numpy(), want_same_heads[i]["cls"].numpy(),
                           want_same_heads[i]["mask"].numpy(), ("bs32 same heads", pick[i]), exact_decode=True)
         _check_detections_composed(d, want_e2e[i]["bbox"].numpy(), want_e2e[i]["cls"].numpy(), want_e2e[i]["mask"].numpy(),
-                                   ("bs32 end to end", pick[i]))
+                                   ("bs32 end to end", precision, pick[i]),
+                                   margin_ctx=_margin_ctx(oracle_post, [(b.cpu(), o.cpu()) for b, o in heads32], i))
 
 
 def _sorted_within_ties(bbox, cls, mask):
@@ -1302,7 +1358,7 @@ def test_bench_workload_bs32_detections(dev):
     want_e2e = oracle_post(ref)
     for i, b in enumerate(pick):
         _check_detections_composed(res[b], want_e2e[i]["bbox"].numpy(), want_e2e[i]["cls"].numpy(), want_e2e[i]["mask"].numpy(),
-                                   ("bench workload end to end", b))
+                                   ("bench workload end to end", b), margin_ctx=_margin_ctx(oracle_post, heads, i))
 
 
 def test_backbone_features_bs8_match_oracle(dev):

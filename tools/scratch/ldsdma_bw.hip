@@ -18,7 +18,9 @@ __global__ __launch_bounds__(256) void stream_kernel(const float* src, size_t fo
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // `shared_by` workgroups walk the same addresses (operand panels shared behind one L2 / by neighbouring CUs)
-    const size_t wg_base = (size_t)(blockIdx.x / shared_by) * 4 * iters * DEPTH;
+    // distinct phase per group of workgroups (an odd number of KiB pieces apart), so that a small footprint is walked at
+    // different places at any one time instead of every CU hitting the same lines together
+    const size_t wg_base = (size_t)(blockIdx.x / shared_by) * (4 * iters * DEPTH + 977);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -56,7 +58,7 @@ static void run(const float* src, size_t footprint, int wg_per_cu, int shared_by
     CHECK(hipEventElapsedTime(&ms, a, b));
     const double bytes = (double)grid * 4 * iters * DEPTH * 1024;
     printf("%-8s depth %2d  waves/CU %2d  shared_by %2d  footprint %8.1f MiB : %7.2f TB/s  = %5.1f B/clk/CU at 2.1 GHz\n", what, DEPTH,
-           wg_per_cu * 4, shared_by, footprint / 1048576.0, bytes / ms / 1e9, bytes / ms / 1e9 * 1e12 / 256 / 2.1e9 / 1e3);
+           wg_per_cu * 4, shared_by, footprint / 1048576.0, bytes / ms / 1e9, bytes / (ms * 1e-3) / 256 / 2.1e9);
 }
 
 int main() {
@@ -71,11 +73,13 @@ int main() {
             run<8, true>(src, fp, wg, 1, sink, "lds-dma");
             run<16, true>(src, fp, wg, 1, sink, "lds-dma");
             run<8, false>(src, fp, wg, 1, sink, "global");
+            run<16, false>(src, fp, wg, 1, sink, "global");
         }
     // operand sharing as in the GEMMs: 4 / 8 workgroups walk the same panel at the same time (HBM-sized footprint)
     for (int sh : {2, 4, 8}) {
         run<8, true>(src, big, 2, sh, sink, "lds-dma");
         run<16, true>(src, big, 2, sh, sink, "lds-dma");
+        run<16, false>(src, big, 2, sh, sink, "global");
     }
     return 0;
 }
