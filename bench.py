@@ -414,6 +414,9 @@ def main():
             # multiplies the matrix pipe executes per direct-convolution multiply: F(2x4,3x3) 24 per 8 outputs instead of 72,
             # F(2x2,3x3) 16 per 4 outputs instead of 36
             # split operands: three fp16 matrix instructions per product group (F(2x4): 3 x 1/3 = the direct-convolution count)
+            # the fused F(4,3)-along-the-rows form: 18 products per 4 outputs instead of 36, times three fp16 instructions
+            if k.startswith("wino14"):
+                return 1.0 / 1.5
             if "split" in k:
                 return 1.0 if k.startswith("wino24") else 1.0 / 3.0
             return 3.0 if k.startswith("wino24") else (2.25 if k.startswith("wino") else 1.0)

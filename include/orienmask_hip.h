@@ -250,6 +250,13 @@ int om_conv2d_winograd24_split(const float* in, int B, int H, int W, int cin, in
                                const float* scale_split, const float* shift, int cout, int leaky, const float* res,
                                int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
                                int32_t* status_dev, om_stream stream);
+/* The stride-1 3x3 layer in the fused split-operand form om_forward runs in precision mode 1 (conv_wino14.hip: Winograd F(4,3)
+ * along the rows, the input transform inside the kernel, no scratch): u14_split = the packed weights
+ * [cout_pad/64][cin/16][6][3][64][32 halfs] (orienmask_amd/pack.py: winograd14_weights_split), cout_pad = cout rounded up to 64,
+ * cin a multiple of 16; scale_split = scale * 2^-e; status_dev as for om_conv2d_split. */
+int om_conv2d_wino14_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* u14_split,
+                           const float* scale_split, const float* shift, int cout, int leaky, const float* res,
+                           int res_pix_stride, float* out, int out_pix_stride, int32_t* status_dev, om_stream stream);
 /* first layer: in [B,3,H,W] NCHW -> out [B,H,W,cout] NHWC, 3x3 stride 1. */
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale,
                    const float* shift, int cout, float* out, om_stream stream);

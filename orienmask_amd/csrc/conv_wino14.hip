@@ -1,0 +1,436 @@
+// Fused stride-1 3x3 convolution with SPLIT fp32 operands (precision mode 1): Winograd F(4,3) along the image rows, the
+// three kernel rows as part of the contraction, and the input transform computed INSIDE the workgroup -- the transformed
+// input never exists in global memory.
+//
+//   Y[oy][4 t + px] = sum_j A^T[px][j] * M_j[oy][t],      M_j[oy][t][n] = sum_ky sum_c U[ky][j][n][c] * V_j[oy + ky - 1][t][c]
+//   V_j[y][t][c]    = sum_x B^T[j][x] d[y][4 t - 1 + x][c]                (6 transform points per 4 outputs, x = 0..5)
+//   U[ky][j][n][c]  = sum_kx G[j][kx] w[n][c][ky][kx]                     (host, float64; orienmask_amd/pack.py)
+//
+// Same layer as conv_wino24.hip (Conv2d 3x3 s1 p1 -> BatchNorm2d(eval) -> LeakyReLU(0.1) (+ residual),
+// /root/reference/model/base.py:104-137, model/backbone/darknet.py:14-15) and the same F(4,3) matrices as its column transform.
+//
+// Why this form (MI355X, measured in round 3: profiles/r03_*): with the two-kernel F(2x4) form the transformed input (3x the
+// activation) is written and read through HBM -- 53 of the forward's 83 GB per step -- and the forward as a whole moves 4.6 TB/s,
+// i.e. it is bound by that traffic, not by the matrix pipe (20 % busy).  Keeping V on chip needs the accumulators of ALL planes of
+// a tile resident while the channel chunks stream by (the transform of a chunk yields every plane at once): 24 planes x 16
+// registers for F(2x4) leaves room for one 32x32 tile per SIMD; F(4,3) along the rows only has SIX planes -- 96 registers per
+// 32x32 wave tile, eight waves per workgroup, a 128 x 64 tile per CU -- at 4.5 instead of 3 matrix products per output, which the
+// idle matrix pipe has room for.  Per 16-channel chunk a workgroup
+//   * (four producer waves) loads the (R + 2) x (4 Ct + 2) input pixels of its R x Ct block of 1x4 output tiles straight into
+//     registers (one chunk ahead), applies B^T (14 vector operations per 6 planes), splits into hi/lo fp16 and writes
+//     V_j[row][t] as 64-byte LDS entries [8 hi | 8 hi | 8 lo | 8 lo];
+//   * (eight consumer waves) runs 18 (ky, j) steps of three v_mfma_f32_32x32x16_f16 per wave: the A fragment of tap ky is the SAME LDS plane read Ct
+//     entries further on (row oy + ky of the block: conv3x3_f16.hip's shared patch, one dimension up), so V is stored once for
+//     the three kernel rows; zero padding is zero ENTRIES (rows / columns outside the image are written as zeros), no masks;
+//   * streams U through a three-slot LDS-DMA ring of (j; ky = 0..2) groups, 12 KiB each, contiguous in the packed blob.
+// Tiles are blocks of the PADDED row space G = b (H + 2) + y + 1 (one zero row above and below every image), so a block may
+// span images (17 x 17 layers) and the row shift ky needs no per-lane case.  The inverse transform runs once per tile, in the
+// epilogue, position by position from the six plane accumulators.
+//
+// Numerics: V_j grows the activation by at most 10x (|4| + |5| + 1), so the split representation's range is |activation| <
+// 6550 here (3275 for F(2x4)); one-dimensional F(4,3) is better conditioned than the two-dimensional F(2x4) it replaces.
+// Every output is the same sequence of fp32 operations whatever tile it falls in (chunks outer, ky, then the three products),
+// so results do not depend on the batch size.
+#include <cstdlib>
+
+#include "conv_f16_common.h"
+
+namespace om {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((__vector_size__(4 * sizeof(unsigned))));
+
+#ifndef OM_W14_ABLATE
+#define OM_W14_ABLATE 0        // measurement builds only (wrong numerics): 2 no fragment reads, 4 no per-group barrier, 8 no weight
+#endif                         // DMA, 16 no input loads / transform, 32 no epilogue stores
+constexpr int W14_BM = 128, W14_BN = 64;
+constexpr int W14_EMAX = 160;                 // LDS entries per plane: (R + 2) * Ct <= 160
+constexpr int W14_VPLANE = W14_EMAX * 4;      // f32x4 units (16 B) per plane
+constexpr int W14_VBUF = 6 * W14_VPLANE;      // one transformed chunk: 61440 B
+constexpr int W14_UGRP = 3 * W14_BN * 4;      // one (j; ky = 0..2) weight group: 12288 B
+constexpr int W14_ITEMS = 3;                  // (entry, channel quad) items per producer thread: 3 * 256 >= 4 * W14_EMAX
+constexpr int W14_NX = 6 * W14_ITEMS;         // input loads per producer thread and chunk
+constexpr int W14_THREADS = 768;              // waves 0-7: consumers (LDS reads + matrix instructions), 8-11: producers
+
+struct Wino14Params {
+    const float* in;        // NHWC fp32 view
+    const _Float16* u;      // packed [n_tiles][cin / 16][6 j][3 ky][64 rows][32 halfs]  (pack.py: winograd14_weights_split)
+    const float* scale;     // scale * 2^-e
+    const float* shift;
+    const float* res;
+    float* out;
+    int* ticket;
+    int* status;
+    int B, H, W, in_ps, in_bytes;
+    int cout, out_ps, res_ps, leaky, vec_io;
+    int R, Ct, ncb, gtot;   // block = R padded rows x Ct tile columns; ncb column blocks per row block; gtot = B * (H + 2)
+    int n_tiles, total_tiles, nch;      // nch = cin / 16
+    int u_bytes;
+};
+
+struct Wino14Tile {
+    int g0, t0, n0, tile_n;
+};
+
+__device__ __forceinline__ bool wino14_next_tile(const Wino14Params& p, int* s_ticket, int tid, Wino14Tile& t) {
+    if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int tile = *s_ticket;
+    if (tile >= p.total_tiles) return false;
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    // N fastest: the workgroups that transform the same input block run at the same time (its pixels come from L2)
+    t.tile_n = tile % p.n_tiles;
+    const int tm = tile / p.n_tiles;
+    const int cb = tm % p.ncb, rb = tm / p.ncb;
+    t.g0 = rb * p.R; t.t0 = cb * p.Ct; t.n0 = t.tile_n * W14_BN;
+    return true;
+}
+
+// Store phase of the epilogue, all 768 threads: the four fp32 C tiles [px][entry][channel chunk ^ (entry & 7)] are in LDS;
+// scale / shift, LeakyReLU, residual, 16-byte stores.
+__device__ __forceinline__ void wino14_store(const Wino14Params& p, const f32x4* sC, const Wino14Tile& tl, int tid) {
+    const int hp2 = p.H + 2;
+    const int n4 = tid & 15, r0 = tid >> 4;                 // 48 entries per sweep, 16 channel quads each
+    const int n = tl.n0 + n4 * 4;
+    const int nvalid = p.cout - n;
+    const bool vec = p.vec_io && nvalid >= 4;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);      // padded to cout_pad
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+    float nonfinite = 0.f;          // range guard of the split representation (conv_igemm_split.hip: split_epilogue)
+#pragma unroll 1
+    for (int s = 0; s < 3; ++s) {
+        const int ml = s * 48 + r0;
+        if (ml >= W14_BM) break;
+        const int r = ml / p.Ct, t = ml - r * p.Ct;
+        const int gg = tl.g0 + r;
+        const int b = gg / hp2;
+        const int y = gg - b * hp2 - 1;
+        const bool rowok = r < p.R && gg < p.gtot && y >= 0 && y < p.H && nvalid > 0;
+        const int ox0 = 4 * (tl.t0 + t);
+        const size_t pix0 = ((size_t)b * p.H + y) * p.W + ox0;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            if (!rowok || ox0 + px >= p.W) continue;
+            f32x4 v = sC[px * (W14_BM * 16) + ml * 16 + (n4 ^ (ml & 7))];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float tv = fmaf(v[k], sc[k], sh[k]);
+                nonfinite = fmaf(tv, 0.f, nonfinite);
+                v[k] = p.leaky ? (tv > 0.f ? tv : tv * 0.1f) : tv;
+            }
+            float* o = p.out + (pix0 + px) * p.out_ps + n;
+            if ((OM_W14_ABLATE & 32) && v[0] != 123.f) continue;
+            if (vec) {
+                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (pix0 + px) * p.res_ps + n);
+                *reinterpret_cast<f32x4*>(o) = v;
+            } else {
+                const float* rp = p.res ? p.res + (pix0 + px) * p.res_ps + n : nullptr;
+                for (int k = 0; k < 4 && k < nvalid; ++k) o[k] = rp ? v[k] + rp[k] : v[k];
+            }
+        }
+    }
+    if (p.status && nonfinite != nonfinite) atomicOr(p.status, OM_STATUS_SPLIT_RANGE);
+}
+
+// Roles.  The matrix waves must never wait on global memory: with the input loads, the transform and the weight DMA in their
+// own instruction streams (round 3's first version) a 16-channel chunk cost a third more than its matrix instructions -- VMEM
+// issue stalls of 60-180 cycles per request and 250 vector instructions per chunk in front of in-order matrix instructions
+// (ablations: profiles/r03_experiments.md).  So waves 8-11 are PRODUCERS -- they request the next chunk's input pixels, apply
+// B^T, split and write V, and feed the weight ring by LDS-DMA -- and waves 0-7 are CONSUMERS: LDS fragment reads and matrix
+// instructions only.  The two roles are two separate loops over the same sequence of tiles, chunks and groups that meet at
+// one s_barrier per group (the barrier counts waves, not program counters), so the six plane accumulators are live only in
+// the consumers' code and the input registers only in the producers': 168 registers, three waves per SIMD, one workgroup per CU.
+__global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino14Params p) {
+    __shared__ f32x4 smem[2 * W14_VBUF + 3 * W14_UGRP + 1];      // ONE LDS object (conv_igemm.hip); last 16 B: the ticket
+    int* const s_ticket = reinterpret_cast<int*>(smem + 2 * W14_VBUF + 3 * W14_UGRP);
+    f32x4* const s_u = smem + 2 * W14_VBUF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ngroups = 6 * p.nch;
+    Wino14Tile tl;
+
+    if (wave >= 8) {
+        // ================================================================ producers
+        const int pid = tid - 512;
+        const int hp2 = p.H + 2;
+        const int ecount = (p.R + 2) * p.Ct;
+        // a producer's few instructions per group are on everybody's critical path (the group barrier): issue them first
+        __builtin_amdgcn_s_setprio(3);
+        const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+        while (wino14_next_tile(p, s_ticket, tid, tl)) {
+            // items: entry e = rr * Ct + t is padded row g0 - 1 + rr, tile column t0 + t; per item the byte offset of its first
+            // pixel (x = 4 t - 1) and a 6-bit "pixel exists" mask
+            int xbase[W14_ITEMS], xlds[W14_ITEMS];
+            unsigned xok[W14_ITEMS];
+#pragma unroll
+            for (int k = 0; k < W14_ITEMS; ++k) {
+                const int idx = pid + 256 * k;
+                const int e = idx >> 2, q = idx & 3;
+                const int rr = e / p.Ct, t = e - rr * p.Ct;
+                const int g = tl.g0 - 1 + rr;
+                const int b = g / hp2;
+                const int y = g - b * hp2 - 1;
+                const bool rowok = e < ecount && g >= 0 && g < p.gtot && y >= 0 && y < p.H;
+                const int x0 = 4 * (tl.t0 + t) - 1;
+                unsigned ok = 0;
+#pragma unroll
+                for (int x = 0; x < 6; ++x) ok |= (rowok && (unsigned)(x0 + x) < (unsigned)p.W ? 1u : 0u) << x;
+                xok[k] = ok;
+                xbase[k] = (((b * p.H + y) * p.W + x0) * p.in_ps + 4 * q) * 4;
+                // LDS byte address of the item's 8 hi bytes in plane 0 (lo: the chunk two further on); -1: no such entry
+                const int sw = (e >> 2) & 3;
+                xlds[k] = e < ecount ? e * 64 + (((q >> 1) ^ sw) * 16) + (q & 1) * 8 : -1;
+            }
+            f32x4 xr[W14_NX];
+            if (OM_W14_ABLATE & 128)
+                for (int i = 0; i < W14_NX; ++i) xr[i] = f32x4{(float)i, 1.f, (float)lane, 2.f};
+            auto load_item = [&](int k, int c) {
+                if (OM_W14_ABLATE & (16 | 128)) return;
+#pragma unroll
+                for (int x = 0; x < 6; ++x) {
+                    // a pixel outside the image (or a pad row) gets an offset beyond the descriptor's range: the load returns zeros
+                    int off = ((xok[k] >> x) & 1u) ? xbase[k] + x * p.in_ps * 4 + c * 64 : (int)0x80000000;
+                    if (OM_W14_ABLATE & 512) off = lane * 16 + (k * 6 + x) * 1024;      // measurement: every request hits the same 18 KiB
+                    xr[k * 6 + x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+                }
+            };
+            // B^T along the row (the column transform of conv_wino24.hip), hi/lo split, 8-byte LDS stores into V buffer vb
+            auto transform_item = [&](int k, int vb) {
+                if ((OM_W14_ABLATE & (16 | 64)) || xlds[k] < 0) return;
+                const f32x4* d = xr + k * 6;
+                const f32x4 a12 = d[1] + d[2], s12 = d[1] - d[2];
+                const f32x4 a34 = d[3] + d[4], s34 = d[4] - d[3];
+                f32x4 v[6];
+                v[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+                v[1] = a34 - 4.f * a12;
+                v[2] = 4.f * s12 + s34;
+                v[3] = (d[4] - d[2]) + 2.f * (d[3] - d[1]);
+                v[4] = (d[4] - d[2]) - 2.f * (d[3] - d[1]);
+                v[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+                char* base = reinterpret_cast<char*>(smem + vb * W14_VBUF) + xlds[k];
+                // lo lives two 16-byte chunks after hi (chunk index XOR-swizzled: + 2 flips bit 1 of the chunk)
+                const int lo_off = ((((xlds[k] >> 4) & 3) ^ 2) - ((xlds[k] >> 4) & 3)) * 16;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const f16x4 h = __builtin_convertvector(v[j], f16x4);
+                    // x - hi in one v_fma_mix_f32 per element (the fp16 operand is widened by the instruction)
+                    const f32x4 rem = {__builtin_fmaf((float)h[0], -1.f, v[j][0]), __builtin_fmaf((float)h[1], -1.f, v[j][1]),
+                                       __builtin_fmaf((float)h[2], -1.f, v[j][2]), __builtin_fmaf((float)h[3], -1.f, v[j][3])};
+                    const f16x4 l = __builtin_convertvector(rem, f16x4);
+                    if ((OM_W14_ABLATE & 256) && h[0] != (_Float16)123.f) continue;
+                    *reinterpret_cast<u32x2*>(base + j * (W14_VPLANE * 16)) = __builtin_bit_cast(u32x2, h);
+                    *reinterpret_cast<u32x2*>(base + j * (W14_VPLANE * 16) + lo_off) = __builtin_bit_cast(u32x2, l);
+                }
+            };
+            // prologue: chunk 0 transformed, chunk 1 requested
+#pragma unroll
+            for (int k = 0; k < W14_ITEMS; ++k) load_item(k, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < W14_ITEMS; ++k) transform_item(k, 0);
+            if (p.nch > 1) {
+#pragma unroll
+                for (int k = 0; k < W14_ITEMS; ++k) load_item(k, 1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (int c = 0; c < p.nch; ++c) {
+                const bool more = c + 1 < p.nch, more2 = c + 2 < p.nch;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    // Software pipeline of the input, one item per group in groups 3-5: item k of chunk c + 1 -- requested one whole
+                    // chunk of matrix work ago (the input comes from HBM for the first of the N-tile siblings: ~3 us under load) --
+                    // is transformed into the other V buffer, and its registers at once take the request for item k of chunk c + 2.
+                    // Nothing else is in this wave's memory queue (the consumers feed the weight ring) and it retires in order, so
+                    // "at most the two younger items outstanding" is exactly "item k has landed".
+                    if (j >= 3 && more) {
+                        if (more2 || j == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                        else if (j == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        transform_item(j - 3, (c & 1) ^ 1);
+                        if (more2) load_item(j - 3, c + 2);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my LDS writes are done
+                    if (!(OM_W14_ABLATE & 4)) __builtin_amdgcn_s_barrier();
+                }
+            }
+            __builtin_amdgcn_s_barrier();       // the consumers have staged the C tiles
+            wino14_store(p, smem, tl, tid);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the C tiles are dead before the next tile's operands land
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    // ==================================================================== consumers
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fi = lane & 31, fk = lane >> 5;
+    // weight-group DMA: a group's 192 rows of 64 bytes are twelve 1-KiB pieces of 16 rows; wave w requests piece w, waves 0-3
+    // also piece 8 + w
+    const int drow = lane >> 2, dcol = lane & 3;
+    int dvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 16 * (wave + 8 * i) + drow;
+        dvo[i] = row * 64 + ((dcol ^ ((row >> 2) & 3)) * 16);      // swizzle on the SOURCE chunk: the LDS image stays lane-linear
+    }
+    const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.u), 0, p.u_bytes, 0x00020000);
+    // B fragments: row 32 wn + fi of a tap's 64 rows
+    const int swB = (fi >> 2) & 3;
+    const int boff_hi = (32 * wn + fi) * 4 + (fk ^ swB);
+    const int boff_lo = (32 * wn + fi) * 4 + ((2 + fk) ^ swB);
+    while (wino14_next_tile(p, s_ticket, tid, tl)) {
+        // A entries of this lane for the three kernel rows: entry m + ky Ct of the plane
+        int aoff_hi[3], aoff_lo[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int e = 32 * wm + fi + ky * p.Ct;
+            const int sw = (e >> 2) & 3;
+            aoff_hi[ky] = e * 4 + (fk ^ sw);
+            aoff_lo[ky] = e * 4 + ((2 + fk) ^ sw);
+        }
+        // weight group g = 6 c + j: 12 KiB at ((tile_n * nch + c) * 6 + j) * 12288 bytes of the packed blob
+        const int ubase = tl.tile_n * p.nch * 6 * (W14_UGRP * 16);
+        auto issue_group = [&](int g) {
+            if (!(OM_W14_ABLATE & 8) && g < ngroups) {
+                const int slot = g % 3;
+                const int soff = ubase + g * (W14_UGRP * 16);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14_UGRP + wave * 64), 16, dvo[0], soff, 0, 0);
+                if (wave < 4)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14_UGRP + (wave + 8) * 64), 16, dvo[1], soff, 0, 0);
+            }
+        };
+        f32x16 acc[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        issue_group(0);
+        issue_group(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();           // prologue: chunk 0 (producers) and weight groups 0, 1 are in LDS
+        int g = 0;
+        for (int c = 0; c < p.nch; ++c) {
+            const f32x4* sV = smem + (c & 1) * W14_VBUF;
+#pragma unroll
+            for (int j = 0; j < 6; ++j, ++g) {
+                const f32x4* sU = s_u + (g % 3) * W14_UGRP;
+                // groups g and g + 1 are in LDS; every wave has left group g - 1: its slot takes group g + 2
+                issue_group(g + 2);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    f16x8 ah, al, bh, bl;
+                    if constexpr (OM_W14_ABLATE & 2) {
+                        const f32x4 k = {(float)(g + ky), 1.f, 2.f, (float)lane};
+                        ah = al = bh = bl = __builtin_bit_cast(f16x8, k);
+                    } else {
+                        ah = __builtin_bit_cast(f16x8, sV[j * W14_VPLANE + aoff_hi[ky]]);
+                        al = __builtin_bit_cast(f16x8, sV[j * W14_VPLANE + aoff_lo[ky]]);
+                        bh = __builtin_bit_cast(f16x8, sU[ky * (W14_BN * 4) + boff_hi]);
+                        bl = __builtin_bit_cast(f16x8, sU[ky * (W14_BN * 4) + boff_lo]);
+                    }
+                    // weights first: D[i = channel][j = entry]
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[j], 0, 0, 0);
+                }
+                // my pieces of weight group g + 1 (requested two groups ago) have landed -- only the one or two pieces of group g + 2
+                // requested at the top of this group may still fly -- and my reads of this group's slot and plane are done
+                if (g + 2 >= ngroups) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else if (wave < 4) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+                if (!(OM_W14_ABLATE & 4)) __builtin_amdgcn_s_barrier();
+            }
+        }
+        // ---- inverse transform position by position (A^T rows (1,1,1,1,1,0), (0,1,-1,2,-2,0), (0,1,1,4,4,0), (0,1,-1,8,-8,1))
+        // into four fp32 C tiles in LDS (128 KiB of the 156; every operand is dead: the last group's barrier has passed)
+        {
+            f32x4* sC = smem;
+            const int ml = 32 * wm + fi;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                f32x16 yv;
+                if (px == 0) yv = acc[0] + acc[1] + acc[2] + acc[3] + acc[4];
+                else if (px == 1) yv = (acc[1] - acc[2]) + 2.f * (acc[3] - acc[4]);
+                else if (px == 2) yv = (acc[1] + acc[2]) + 4.f * (acc[3] + acc[4]);
+                else yv = (acc[1] - acc[2]) + 8.f * (acc[3] - acc[4]) + acc[5];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int n4 = (32 * wn) / 4 + 2 * gq + fk;
+                    const f32x4 v = {yv[4 * gq], yv[4 * gq + 1], yv[4 * gq + 2], yv[4 * gq + 3]};
+                    sC[px * (W14_BM * 16) + ml * 16 + (n4 ^ (ml & 7))] = v;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        wino14_store(p, smem, tl, tid);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// Block shape for a layer: Ct tile columns (a divisor-like split of ceil(W / 4)) x R padded rows with R * Ct <= 128 and
+// (R + 2) * Ct <= 160, picked for the largest share of useful rows in the 128-row matrix tile.
+void wino14_geometry(int B, int H, int W, int* R, int* Ct, int* ncb, int* nrb) {
+    const int TW = (W + 3) / 4;
+    const long long gtot = (long long)B * (H + 2);
+    double best = -1.0;
+    for (int split = 1; split <= 8; ++split) {
+        const int ct = (TW + split - 1) / split;
+        if (ct > 64 || ct < 1) continue;
+        int r = W14_BM / ct;
+        while (r > 1 && (r + 2) * ct > W14_EMAX) --r;
+        if (r < 1 || (r + 2) * ct > W14_EMAX) continue;
+        if (r > gtot) r = (int)gtot;
+        const int cbs = (TW + ct - 1) / ct;
+        const long long rbs = (gtot + r - 1) / r;
+        const double useful = (double)B * H * TW;
+        const double util = useful / ((double)rbs * cbs * W14_BM);
+        if (util > best) { best = util; *R = r; *Ct = ct; *ncb = cbs; *nrb = (int)rbs; }
+    }
+}
+
+size_t wino14_weight_halfs(int cout_pad, int cin) { return (size_t)18 * cout_pad * cin * 2; }
+
+// a.w: the packed F(4,3) weights (include/orienmask_hip.h: om_layer_info.wsplit_off for wino layers); a.scale: scale * 2^-e
+int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream) {
+    OM_REQUIRE(a.in && a.w && a.scale && a.shift && a.out && a.ticket, OM_EINVAL, "wino14: null pointer");
+    OM_REQUIRE(a.ks == 3 && a.stride == 1 && a.out_mode == 0, OM_EINVAL, "wino14: 3x3 stride-1 NHWC layers only");
+    OM_REQUIRE(a.cin % 16 == 0 && a.cin >= 16 && a.cout_pad % 64 == 0, OM_EINVAL, "wino14: cin=%d cout_pad=%d", a.cin, a.cout_pad);
+    OM_REQUIRE(a.in_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(a.w) & 15) == 0,
+               OM_EINVAL, "wino14: operands must be 16-byte aligned");
+    const long long in_bytes = ((long long)a.B * a.H * a.W - 1) * a.in_pix_stride * 4 + (long long)a.cin * 4;
+    OM_REQUIRE(in_bytes < 0x7FFFFFF0ll, OM_EINVAL, "wino14: input view of %lld bytes exceeds a buffer descriptor", in_bytes);
+    Wino14Params p;
+    p.in = a.in; p.u = reinterpret_cast<const _Float16*>(a.w); p.scale = a.scale; p.shift = a.shift; p.res = a.res; p.out = a.out;
+    p.ticket = a.ticket; p.status = a.status;
+    p.B = a.B; p.H = a.H; p.W = a.W; p.in_ps = a.in_pix_stride; p.in_bytes = (int)in_bytes;
+    p.cout = a.cout; p.out_ps = a.out_pix_stride; p.res_ps = a.res_pix_stride; p.leaky = a.leaky;
+    p.vec_io = (a.out_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+                (!a.res || (a.res_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)))
+                   ? 1 : 0;
+    int R = 0, Ct = 0, ncb = 0, nrb = 0;
+    wino14_geometry(a.B, a.H, a.W, &R, &Ct, &ncb, &nrb);
+    OM_REQUIRE(R >= 1 && Ct >= 1, OM_EINVAL, "wino14: no block shape for %d x %d", a.H, a.W);
+    p.R = R; p.Ct = Ct; p.ncb = ncb; p.gtot = a.B * (a.H + 2);
+    p.n_tiles = a.cout_pad / W14_BN;
+    p.nch = a.cin / 16;
+    const long long total = (long long)nrb * ncb * p.n_tiles;
+    OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "wino14: %lld tiles out of range", total);
+    p.total_tiles = (int)total;
+    const size_t ub = wino14_weight_halfs(a.cout_pad, a.cin) * 2;
+    OM_REQUIRE(ub < 0x7FFFFFF0ull, OM_EINVAL, "wino14: weights exceed a buffer descriptor");
+    p.u_bytes = (int)ub;
+    const long long grid = total < 256 ? total : 256;        // one 768-thread workgroup per CU (156 KiB of LDS)
+    hipLaunchKernelGGL(wino14_split_kernel, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
+}  // namespace om

@@ -106,6 +106,10 @@ size_t wino_scratch_floats(int B, int H, int W, int C);
 // Winograd F(2x4,3x3) path (conv_wino24.hip): a.w = U [24][cout_pad][cin]
 int launch_conv_winograd24(const ConvArgs& a, float* scratch, hipStream_t stream);
 size_t wino24_scratch_floats(int B, int H, int W, int C);
+// fused F(4,3)-along-the-rows form with split operands (conv_wino14.hip): a.w = packed hi/lo weights [n_tiles][cin/16][6][3][64][32]
+int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream);
+size_t wino14_weight_halfs(int cout_pad, int cin);
+void wino14_geometry(int B, int H, int W, int* R, int* Ct, int* ncb, int* nrb);
 bool wino_enabled();
 int wino_bn(long long T, int cout_pad);   // N tile of the (unfused) Winograd GEMM at this size
 bool wino_fused_for(int cin);     // true: the input transform is fused into the GEMM's loader   // tile shape launch_conv_igemm picks

@@ -116,9 +116,10 @@ struct om_model {
         }
         L.info.wsplit_off = L.info.wsplit_scale_off = -1;
         if (!stem) {
-            // split-operand mode: the F(2x4) planes of the stride-1 3x3 layers, the direct weights of every other layer
+            // split-operand mode: the fused F(4,3) form of the stride-1 3x3 layers (conv_wino14.hip: 3 kernel rows x 6 transform
+            // points = 18 planes), the direct weights of every other layer
             L.info.wsplit_off = (int64_t)split_words;
-            split_words += (size_t)(L.info.wino_planes == 24 ? 24 : ks * ks) * L.info.cout_pad * cin;
+            split_words += (size_t)(L.info.wino_planes == 24 ? 18 : ks * ks) * L.info.cout_pad * cin;
             L.info.wsplit_scale_off = (int64_t)split_words;
             split_words = om::align_up(split_words + L.info.cout_pad, 4);
         }
@@ -252,6 +253,7 @@ struct om_model {
 
     size_t layer_scratch_floats(const om::LayerDef& L, int B, int H, int W) const {
         if (L.info.wino_off < 0) return 0;
+        if (precision == 1 && L.info.wino_planes == 24) return 0;      // conv_wino14.hip transforms its input on chip
         return (L.info.wino_planes == 24 && use_f24(B, H, W)) ? om::wino24_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin)
                                                                : om::wino_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin);
     }
@@ -493,13 +495,15 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             if (li.wino_off >= 0 && om::wino_enabled()) {
                 float* wino_scratch = reinterpret_cast<float*>(static_cast<char*>(workspace) + lay.scratch_off[&L - m->layers.data()]);
                 a.mid_event = ev_mid;
-                if (li.wino_planes == 24 && m->use_f24(B, H, W)) {
+                if (li.wino_planes == 24 && m->precision == 1) {
+                    // split operands: the fused F(4,3) form, one kernel, no transformed input in memory
+                    a.w = m->weights_split + li.wsplit_off;
+                    a.scale = m->weights_split + li.wsplit_scale_off;
+                    a.split = 1;
+                    if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
+                    rc = om::launch_conv_wino14_split(a, stream);
+                } else if (li.wino_planes == 24 && m->use_f24(B, H, W)) {
                     a.w = m->weights + li.wino_off;
-                    if (m->precision == 1) {
-                        a.w = m->weights_split + li.wsplit_off;
-                        a.scale = m->weights_split + li.wsplit_scale_off;
-                        a.split = 1;
-                    }
                     rc = om::launch_conv_winograd24(a, wino_scratch, stream);
                 } else {
                     a.w = m->weights + (li.wino_planes == 24 ? li.wino_alt_off : li.wino_off);
@@ -596,8 +600,12 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
     OM_REQUIRE(index >= 0 && index < (int)m->layers.size(), OM_EINVAL, "om_layer_tile: index %d", index);
     const om::LayerDef& L = m->layers[index];
     if (L.stem) { *bm = 0; *bn = 0; *algo = 0; return OM_OK; }
+    if (L.info.wino_off >= 0 && om::wino_enabled() && L.info.wino_planes == 24 && m->precision == 1) {
+        *algo = 8; *bm = 128; *bn = 64;
+        return OM_OK;
+    }
     if (L.info.wino_off >= 0 && om::wino_enabled() && L.info.wino_planes == 24 && m->use_f24(B, H, W)) {
-        *algo = m->precision == 1 ? 6 : 5; *bm = 64; *bn = 64;
+        *algo = 5; *bm = 64; *bn = 64;
         return OM_OK;
     }
     if (L.info.wino_off >= 0 && om::wino_enabled()) {
@@ -809,6 +817,23 @@ int om_conv2d_winograd24_split(const float* in, int B, int H, int W, int cin, in
                                int32_t* status_dev, om_stream stream) {
     return conv2d_winograd24_impl(in, B, H, W, cin, in_pix_stride, static_cast<const float*>(u_split), scale_split, shift, cout,
                                   leaky, res, res_pix_stride, out, out_pix_stride, scratch, scratch_bytes, stream, 1, status_dev);
+}
+
+int om_conv2d_wino14_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* u14_split,
+                           const float* scale_split, const float* shift, int cout, int leaky, const float* res,
+                           int res_pix_stride, float* out, int out_pix_stride, int32_t* status_dev, om_stream stream) {
+    OM_REQUIRE(B > 0 && H > 0 && W > 0, OM_EINVAL, "om_conv2d_wino14_split: bad shape");
+    om::ConvArgs a;
+    a.in = in; a.w = static_cast<const float*>(u14_split); a.scale = scale_split; a.shift = shift; a.res = res; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.cin = cin; a.in_pix_stride = in_pix_stride;
+    a.Ho = H; a.Wo = W; a.cout = cout; a.cout_pad = om::round_up(cout, 64);
+    a.ks = 3; a.stride = 1; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
+    a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1; a.split = 1; a.status = status_dev;
+    static int* g_ticket = nullptr;      // unit-test entry only (see om_conv2d_mode)
+    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), om::SYNC_WORDS * sizeof(int)));
+    if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;
+    a.ticket = g_ticket;
+    return om::launch_conv_wino14_split(a, static_cast<hipStream_t>(stream));
 }
 
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale, const float* shift,

@@ -59,6 +59,7 @@ SIGNATURES = {
     "om_model_get_precision": (_i, [_vp]),
     "om_conv2d_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "om_conv2d_winograd24_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp, _vp]),
+    "om_conv2d_wino14_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "om_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "om_forward_status_offset": (_sz, [_vp, _i, _i, _i]),
     "om_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -425,7 +425,7 @@ class OrienMaskYOLOFPNPlus(nn.Module):
                        "om_layer_tile")
             fmt = {0: "conv_stem_kernel", 1: "conv_igemm_f32_kernel<%d,%d>", 2: "wino_gemm_kernel<%d,%d>",
                    3: "wino_fused_kernel<%d,%d>", 5: "wino24_gemm_kernel<%d,%d>", 6: "wino24_gemm_kernel<%d,%d,split>",
-                   7: "conv_igemm_split_kernel<%d,%d>"}[algo.value]
+                   7: "conv_igemm_split_kernel<%d,%d>", 8: "wino14_split_kernel<%d,%d>"}[algo.value]
             out.append((l["name"], fmt % ((bm.value, bn.value) if algo.value else ())))
         return out
 

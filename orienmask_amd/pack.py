@@ -159,6 +159,29 @@ def winograd_weights_split(w, cout_pad):
     return split_f16_pairs(us), e.to(torch.int32)
 
 
+def winograd14_weights_split(w, cout_pad):
+    """[cout,cin,3,3] -> (fp16 [cout_pad/64][cin/16][6][3][64][4][8], exponents int32 [cout_pad]): the weights of the fused
+    F(4,3)-along-the-rows form (orienmask_amd/csrc/conv_wino14.hip), U[ky][j][n][c] = sum_kx G6[j][kx] w[n][c][ky][kx] computed in
+    float64 and rounded to float32 once, times 2^e[n] (largest |U| of the output channel in [2^13, 2^14), as for the other split
+    weights), as hi/lo fp16 pairs.  Layout: per 64-channel N tile, 16-channel chunk and transform point j the three kernel rows'
+    64 x 64-byte rows [8 hi | 8 hi | 8 lo | 8 lo] -- 12 KiB that one weight group of the kernel's LDS-DMA ring fetches contiguously."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert cout_pad % 64 == 0 and cin % 16 == 0
+    u = torch.zeros(3, 6, cout_pad, cin, dtype=torch.float32)
+    u[:, :, :cout] = torch.einsum("js,ncrs->rjnc", _WINO_G6, w.detach().double().cpu()).float()
+    amax = u.abs().amax(dim=(0, 1, 3))
+    e = torch.where(amax > 0, 13 - torch.floor(torch.log2(amax.double().clamp_min(1e-300))), torch.zeros_like(amax, dtype=torch.float64))
+    e = e.clamp(-100, 100)
+    us = (u.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), e).view(1, 1, -1, 1)).float()      # exact: a power of two
+    hi = us.half()
+    lo = (us - hi.float()).half()
+
+    def tiles(x):       # [3][6][cpad][cin] -> [cpad/64][cin/16][6][3][64][2][8]
+        return x.reshape(3, 6, cout_pad // 64, 64, cin // 16, 2, 8).permute(2, 4, 1, 0, 3, 5, 6)
+
+    return torch.cat((tiles(hi), tiles(lo)), dim=-2).contiguous(), e.to(torch.int32)
+
+
 _SPLIT_PERM = [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]
 
 
@@ -199,7 +222,7 @@ def pack_state_dict_split(state_dict, layers, total_words):
         w, scale64, _ = folded_epilogue(sd, l)
         cpad, cin = l["cout_pad"], l["cin"]
         if l.get("wino_planes", 0) == 24:
-            us, e = winograd_weights_split(w, cpad)
+            us, e = winograd14_weights_split(w, cpad)       # the fused F(4,3) form om_forward runs for these layers
         else:
             us, e = conv_weights_split(w, cpad)
         n = us.numel() // 2

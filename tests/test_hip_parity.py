@@ -478,6 +478,62 @@ def test_winograd24_split_layer_matches_torch(dev, case):
     assert errs["split"] <= 2 * errs["f32"] + 1e-6, (case, errs)
 
 
+WINO14_CASES = WINO24_CASES + [
+    (1, 17, 17, 512, 128, 1, True),      # blocks spanning... one image, many channel chunks
+    (4, 17, 17, 64, 64, 1, False),       # 5 tile columns, 25-row blocks across image boundaries (pad rows inside a block)
+    (2, 34, 34, 32, 192, 1, True),       # 9 tile columns (36 > 34 pixels), three N tiles
+    (1, 40, 136, 16, 64, 0, False),      # two column blocks of 17, one chunk
+    (3, 7, 9, 48, 70, 1, True),          # cout not a multiple of 64 (scalar stores on the last quad), tiny image
+]
+
+
+@pytest.mark.parametrize("case", WINO14_CASES)
+def test_wino14_split_layer_matches_torch(dev, case):
+    """conv_wino14.hip -- the fused F(4,3)-along-the-rows form with split operands that om_forward runs for the stride-1 3x3
+    layers in precision mode 1 (input transform inside the kernel, no transformed input in memory) -- vs float64 direct
+    convolution: within the F(2x4) kernels' bound, and no worse than the fp32-operand F(2x4) kernel on the same inputs."""
+    from orienmask_amd.pack import winograd14_weights_split
+    B, H, W, cin, cout, leaky, use_res = case
+    L = omlib.load()
+    g = torch.Generator().manual_seed(sum(case) + 23)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.2
+    res = torch.randn(B, cout, H, W, generator=g) if use_res else None
+    want = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+    want = want * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if leaky:
+        want = torch.where(want > 0, want, want * 0.1)
+    if use_res:
+        want = want + res.double()
+    cpad = (cout + 63) // 64 * 64
+    us, e = winograd14_weights_split(w, cpad)
+    sp = torch.zeros(cpad); sp[:cout] = scale
+    sps = (sp.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e.double())).float().to(dev)
+    hp = torch.zeros(cpad); hp[:cout] = shift
+    hd = hp.to(dev)
+    # the input as a channel slice of a wider buffer (concat views), the output with a pixel stride of its own
+    xbuf = torch.full((B, H, W, cin + 16), 9.0, device=dev)
+    xbuf[..., 8:8 + cin] = x.permute(0, 2, 3, 1).to(dev)
+    xv = xbuf[..., 8:]
+    rd = res.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None
+    ostride = cout + (4 - cout % 4) % 4 + 4
+    out = torch.full((B, H, W, ostride), float("nan"), device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    ud = us.to(dev)
+    rc = L.om_conv2d_wino14_split(ctypes.c_void_p(xv.data_ptr()), B, H, W, cin, cin + 16, _p(ud), _p(sps), _p(hd), cout, leaky,
+                                  _p(rd) if use_res else None, cout if use_res else 0, _p(out), ostride, _p(status),
+                                  omlib.current_stream_ptr(dev))
+    omlib.check(rc, "om_conv2d_wino14_split")
+    got = out[..., :cout].cpu().permute(0, 3, 1, 2).double()
+    assert torch.isfinite(got).all() and int(status.item()) == 0
+    assert torch.isnan(out[..., cout:]).all()                       # nothing written beyond the layer's channels
+    err = _rel_err(got, want)
+    print("wino14 split %s: %.2e" % (case, err))
+    assert err < 5e-6, (case, err)
+
+
 @pytest.mark.parametrize("gain,finite", [(100.0, True), (3.0e4, False)])
 def test_split_operand_range(dev, gain, finite):
     """The documented range of split operands (include/orienmask_hip.h: om_model_set_precision): activations 100x larger than a
@@ -1274,7 +1330,7 @@ def test_headline_bs32_forward_and_postprocess(dev, precision):
     x = synth.synth_image_batch(1000, 32, 544, 544)
     net = _hip_model(sd, dev, precision)
     if precision == "f32_split":
-        assert dict(net.layer_kernels(32, 544, 544))["orien_head.2"].endswith("split>")
+        assert dict(net.layer_kernels(32, 544, 544))["orien_head.2"].startswith("wino14_split_kernel")
     post = _hip_post((544, 544), dev)
     pick = [0, 15, 31]
     with torch.no_grad():

@@ -349,7 +349,7 @@ def test_pack_state_dict_split_covers_every_layer(built):
         if l["name"] == "backbone.conv1":
             assert l["wsplit_off"] == -1
             continue
-        n = (24 if l["wino_planes"] == 24 else l["ksize"] ** 2) * l["cout_pad"] * l["cin"]
+        n = (18 if l["wino_planes"] == 24 else l["ksize"] ** 2) * l["cout_pad"] * l["cin"]
         spans.append((l["wsplit_off"], l["wsplit_off"] + n))
         spans.append((l["wsplit_scale_off"], l["wsplit_scale_off"] + l["cout_pad"]))
     spans.sort()
@@ -363,9 +363,11 @@ def test_pack_state_dict_split_covers_every_layer(built):
         ratio = (scale32[:cout] / scale_s[:cout])                      # = 2^e, exactly
         assert torch.equal(ratio, torch.pow(torch.tensor(2.0, dtype=torch.float64), torch.round(torch.log2(ratio))))
         if l["wino_planes"] == 24:
-            halfs = blob[l["wsplit_off"]:l["wsplit_off"] + 24 * cpad * cin].view(torch.float16).reshape(24, cpad, cin // 16, 2, 16).double()
-            back = (halfs[..., 0, :] + halfs[..., 1, :]).reshape(24, cpad, cin)[:, :cout] / ratio.view(1, -1, 1)
-            want = blob32[l["wino_off"]:l["wino_off"] + 24 * cpad * cin].reshape(24, cpad, cin)[:, :cout].double()
+            # the fused F(4,3) form: [cout_pad/64][cin/16][6 j][3 ky][64][hi 8 | hi 8 | lo 8 | lo 8] (conv_wino14.hip)
+            halfs = blob[l["wsplit_off"]:l["wsplit_off"] + 18 * cpad * cin].view(torch.float16).reshape(cpad // 64, cin // 16, 6, 3, 64, 2, 16).double()
+            back = (halfs[..., 0, :] + halfs[..., 1, :]).permute(3, 2, 0, 4, 1, 5).reshape(3, 6, cpad, cin)[:, :, :cout] / ratio.view(1, 1, -1, 1)
+            w4 = sd[name + ".conv_block.0.weight"].double()
+            want = torch.einsum("js,ncrs->rjnc", pack._WINO_G6, w4)
         else:
             k2 = l["ksize"] ** 2
             halfs = blob[l["wsplit_off"]:l["wsplit_off"] + k2 * cpad * cin].view(torch.float16).reshape(cpad, k2, cin // 16, 2, 2, 8).double()

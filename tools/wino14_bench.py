@@ -1,0 +1,62 @@
+"""Time conv_wino14.hip (the fused F(4,3) split-operand form) on the forward's stride-1 3x3 layer shapes at bs=32, 544x544, next to
+the two-kernel F(2x4) split form on the same shapes:   gpurun -- 'python tools/wino14_bench.py'"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch  # noqa: E402
+from orienmask_amd import lib as omlib  # noqa: E402
+from orienmask_amd.pack import winograd14_weights_split, winograd_weights_split  # noqa: E402
+
+SHAPES = [(272, 32, 64, 1), (136, 64, 128, 2), (68, 128, 256, 11), (34, 256, 512, 11), (17, 512, 1024, 7), (136, 128, 256, 5)]
+
+
+def main():
+    if os.environ.get("OM_LIB"):
+        omlib.LIB_PATH = os.path.abspath(os.environ["OM_LIB"])
+    L = omlib.load()
+    dev = torch.device("cuda:0")
+    B = 32
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    tot14 = tot24 = 0.0
+    for hw, cin, cout, n in SHAPES:
+        x = torch.randn(B, hw, hw, cin, device=dev)
+        w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+        out = torch.empty(B, hw, hw, cout, device=dev)
+        hd = torch.zeros(cout, device=dev)
+        u14, e14 = winograd14_weights_split(w, cout)
+        u24, e24 = winograd_weights_split(w, cout)
+        s14 = torch.pow(torch.tensor(2.0), -e14.float()).to(dev)
+        s24 = torch.pow(torch.tensor(2.0), -e24.float()).to(dev)
+        u14, u24 = u14.to(dev), u24.to(dev)
+        scratch = torch.empty(L.om_conv2d_winograd24_scratch_bytes(B, hw, hw, cin), dtype=torch.uint8, device=dev)
+        st = omlib.current_stream_ptr(dev)
+
+        def run14():
+            omlib.check(L.om_conv2d_wino14_split(p(x), B, hw, hw, cin, cin, p(u14), p(s14), p(hd), cout, 1, None, 0, p(out), cout, None, st), "w14")
+
+        def run24():
+            omlib.check(L.om_conv2d_winograd24_split(p(x), B, hw, hw, cin, cin, p(u24), p(s24), p(hd), cout, 1, None, 0, p(out), cout,
+                                                     p(scratch), scratch.numel(), None, st), "w24")
+        res = []
+        for fn in (run14, run24):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(10):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            res.append(a.elapsed_time(b) / 10)
+        fl = 2.0 * B * hw * hw * cin * cout * 9
+        print("%3dx%-3d %4d->%-4d x%2d  fused F(4,3) %.3f ms (%.0f TF alg, %.0f TF executed)   F(2x4) two kernels %.3f ms" % (
+            hw, hw, cin, cout, n, res[0], fl / res[0] / 1e9, 1.5 * fl / res[0] / 1e9, res[1]), flush=True)
+        tot14 += n * res[0]; tot24 += n * res[1]
+    print("all 37 layers: fused %.2f ms, two-kernel %.2f ms" % (tot14, tot24))
+
+
+if __name__ == "__main__":
+    main()
