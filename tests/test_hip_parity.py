@@ -704,13 +704,14 @@ def test_forward_is_batch_invariant(dev):
 
 
 def test_forward_split_is_batch_invariant(dev):
-    """With split operands every size runs the same kernels (F(2x4) at any batch, one summation order per output element in
-    the implicit GEMM whatever the tile shape), so an image's head tensors are bit-identical alone, in a batch of 3 and in a
-    batch of 7 -- across the size where precision 'f32' switches from F(2x2) to F(2x4) (and is only equal to ~1e-6)."""
+    """With split operands every size runs the same kernels (the fused F(4,3) form at any batch -- whose blocks of padded rows
+    fall differently across the images of another batch -- and one summation order per output element in the implicit GEMM
+    whatever the tile shape), so an image's head tensors are bit-identical alone, in a batch of 3 and in a batch of 7 -- across
+    the size where precision 'f32' switches from F(2x2) to F(2x4) (and is only equal to ~1e-6)."""
     sd = synth.synth_state_dict(9, obj_bias=-16.0, head_gain=4.0)
     x = synth.synth_image_batch(31, 7, 544, 544).to(dev)
     net = _hip_model(sd, dev, "f32_split")
-    assert dict(net.layer_kernels(1, 544, 544))["orien_head.2"].endswith("split>")
+    assert dict(net.layer_kernels(1, 544, 544))["orien_head.2"].startswith("wino14_split_kernel")
     with torch.no_grad():
         full = [(b.clone(), o.clone()) for b, o in net(x)]
         for idx in ([6], [2, 6, 4]):
