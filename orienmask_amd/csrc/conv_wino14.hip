@@ -242,17 +242,18 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
                 const bool more = c + 1 < p.nch, more2 = c + 2 < p.nch;
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    // Software pipeline of the input, one item per group in groups 3-5: item k of chunk c + 1 -- requested one whole
+                    // Software pipeline of the input, one item per group in groups 2-4 (the next chunk's V is complete one group before
+                    // the consumers prefetch its first fragments): item k of chunk c + 1 -- requested one whole
                     // chunk of matrix work ago (the input comes from HBM for the first of the N-tile siblings: ~3 us under load) --
                     // is transformed into the other V buffer, and its registers at once take the request for item k of chunk c + 2.
                     // Nothing else is in this wave's memory queue (the consumers feed the weight ring) and it retires in order, so
                     // "at most the two younger items outstanding" is exactly "item k has landed".
-                    if (j >= 3 && more) {
-                        if (more2 || j == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                        else if (j == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    if (j >= 2 && j < 5 && more) {
+                        if (more2 || j == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                        else if (j == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        transform_item(j - 3, (c & 1) ^ 1);
-                        if (more2) load_item(j - 3, c + 2);
+                        transform_item(j - 2, (c & 1) ^ 1);
+                        if (more2) load_item(j - 2, c + 2);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my LDS writes are done
                     if (!(OM_W14_ABLATE & 4)) __builtin_amdgcn_s_barrier();
@@ -313,36 +314,47 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
         issue_group(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();           // prologue: chunk 0 (producers) and weight groups 0, 1 are in LDS
+        // fragments are read one step ahead, across the group barrier too: weight group g + 1 -- requested at the top of group g - 1
+        // -- is waited for at the END of group g - 1 (one group of matrix work for 12 KiB from L2), and the next chunk's V is
+        // published by the barrier that ends group 4
+        f32x4 ca[4], na[4];        // A hi, A lo, B hi, B lo of the current / next step
+        auto read_frags = [&](f32x4(&f)[4], const f32x4* sV, int j, int ky, int slot) {
+            if constexpr (OM_W14_ABLATE & 2) {
+                f[0] = f[1] = f[2] = f[3] = f32x4{(float)(j + ky), 1.f, 2.f, (float)lane};
+            } else {
+                f[0] = sV[j * W14_VPLANE + aoff_hi[ky]];
+                f[1] = sV[j * W14_VPLANE + aoff_lo[ky]];
+                f[2] = s_u[slot * W14_UGRP + ky * (W14_BN * 4) + boff_hi];
+                f[3] = s_u[slot * W14_UGRP + ky * (W14_BN * 4) + boff_lo];
+            }
+        };
+        read_frags(ca, smem, 0, 0, 0);
         int g = 0;
         for (int c = 0; c < p.nch; ++c) {
             const f32x4* sV = smem + (c & 1) * W14_VBUF;
+            const f32x4* sVn = smem + ((c & 1) ^ 1) * W14_VBUF;
 #pragma unroll
             for (int j = 0; j < 6; ++j, ++g) {
-                const f32x4* sU = s_u + (g % 3) * W14_UGRP;
-                // groups g and g + 1 are in LDS; every wave has left group g - 1: its slot takes group g + 2
+                const int slot = g % 3, slot1 = slot == 2 ? 0 : slot + 1;
+                // groups g and g + 1 are in LDS; every wave has left group g - 1: its slot takes group g + 2, which has to land
+                // by the end of this group
                 issue_group(g + 2);
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    f16x8 ah, al, bh, bl;
-                    if constexpr (OM_W14_ABLATE & 2) {
-                        const f32x4 k = {(float)(g + ky), 1.f, 2.f, (float)lane};
-                        ah = al = bh = bl = __builtin_bit_cast(f16x8, k);
-                    } else {
-                        ah = __builtin_bit_cast(f16x8, sV[j * W14_VPLANE + aoff_hi[ky]]);
-                        al = __builtin_bit_cast(f16x8, sV[j * W14_VPLANE + aoff_lo[ky]]);
-                        bh = __builtin_bit_cast(f16x8, sU[ky * (W14_BN * 4) + boff_hi]);
-                        bl = __builtin_bit_cast(f16x8, sU[ky * (W14_BN * 4) + boff_lo]);
-                    }
+                    if (ky < 2) read_frags(na, sV, j, ky + 1, slot);
+                    else if (j < 5) read_frags(na, sV, j + 1, 0, slot1);
+                    else if (c + 1 < p.nch) read_frags(na, sVn, 0, 0, slot1);
+                    const f16x8 ah = __builtin_bit_cast(f16x8, ca[0]), al = __builtin_bit_cast(f16x8, ca[1]);
+                    const f16x8 bh = __builtin_bit_cast(f16x8, ca[2]), bl = __builtin_bit_cast(f16x8, ca[3]);
                     // weights first: D[i = channel][j = entry]
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ca[i] = na[i];
                 }
-                // my pieces of weight group g + 1 (requested two groups ago) have landed -- only the one or two pieces of group g + 2
-                // requested at the top of this group may still fly -- and my reads of this group's slot and plane are done
-                if (g + 2 >= ngroups) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                else if (wave < 4) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+                // my pieces of weight group g + 2 have landed; my reads of this group's slot and plane are done
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 if (!(OM_W14_ABLATE & 4)) __builtin_amdgcn_s_barrier();
             }
         }
