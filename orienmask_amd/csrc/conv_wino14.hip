@@ -32,6 +32,7 @@
 // Every output is the same sequence of fp32 operations whatever tile it falls in (chunks outer, ky, then the three products),
 // so results do not depend on the batch size.
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv_f16_common.h"
 
@@ -43,7 +44,10 @@ typedef unsigned u32x4v __attribute__((__vector_size__(4 * sizeof(unsigned))));
 
 #ifndef OM_W14_ABLATE
 #define OM_W14_ABLATE 0        // measurement builds only (wrong numerics): 2 no fragment reads, 4 no per-group barrier, 8 no weight
-#endif                         // DMA, 16 no input loads / transform, 32 no epilogue stores
+#endif                         // DMA, 16 no input loads / transform, 32 no epilogue stores, 1024 no matrix instructions
+#ifndef OM_W14_TRACE
+#define OM_W14_TRACE 0         // measurement builds only: s_memtime stamps of one tile's groups (tools/wino14_trace.py)
+#endif
 constexpr int W14_BM = 128, W14_BN = 64;
 constexpr int W14_EMAX = 160;                 // LDS entries per plane: (R + 2) * Ct <= 160
 constexpr int W14_VPLANE = W14_EMAX * 4;      // f32x4 units (16 B) per plane
@@ -51,6 +55,9 @@ constexpr int W14_VBUF = 6 * W14_VPLANE;      // one transformed chunk: 61440 B
 constexpr int W14_UGRP = 3 * W14_BN * 4;      // one (j; ky = 0..2) weight group: 12288 B
 constexpr int W14_ITEMS = 3;                  // (entry, channel quad) items per producer thread: 3 * 256 >= 4 * W14_EMAX
 constexpr int W14_NX = 6 * W14_ITEMS;         // input loads per producer thread and chunk
+#ifndef W14_DMA_AFTER
+#define W14_DMA_AFTER 0        // the weight request follows the matrix instructions of this kernel row of the group
+#endif
 constexpr int W14_THREADS = 768;              // waves 0-7: consumers (LDS reads + matrix instructions), 8-11: producers
 
 struct Wino14Params {
@@ -67,67 +74,113 @@ struct Wino14Params {
     int R, Ct, ncb, gtot;   // block = R padded rows x Ct tile columns; ncb column blocks per row block; gtot = B * (H + 2)
     int n_tiles, total_tiles, nch;      // nch = cin / 16
     int u_bytes;
+#if OM_W14_TRACE
+    unsigned long long* trace;
+#endif
 };
+
+#if OM_W14_TRACE
+// Time stamps without disturbing the LDS queue: s_memtime is issued where the event happens and its result is only read behind
+// a wait the kernel has anyway.  [block][wave 0 / 4 / 8][group 0..63][4 stamps]
+static unsigned long long* g_w14_trace = nullptr;
+extern "C" void om_debug_w14_trace(void* buf) { g_w14_trace = static_cast<unsigned long long*>(buf); }
+#define W14_STAMP(x) asm volatile("s_memtime %0" : "=s"(x)::"memory")
+#define W14_SETTLE(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d)::"memory")
+__device__ __forceinline__ void w14_trace_put(const Wino14Params& p, int slot, int g, unsigned long long a, unsigned long long b,
+                                              unsigned long long c, unsigned long long d) {
+    if (blockIdx.x < 8 && g < 64 && (threadIdx.x & 63) == 0) {
+        unsigned long long* t = p.trace + ((blockIdx.x * 3 + slot) * 64 + g) * 4;
+        t[0] = a; t[1] = b; t[2] = c; t[3] = d;
+    }
+}
+#endif
 
 struct Wino14Tile {
     int g0, t0, n0, tile_n;
 };
 
-__device__ __forceinline__ bool wino14_next_tile(const Wino14Params& p, int* s_ticket, int tid, Wino14Tile& t) {
-    if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int tile = *s_ticket;
-    if (tile >= p.total_tiles) return false;
-    tile = __builtin_amdgcn_readfirstlane(tile);
+__device__ __forceinline__ void wino14_decode(const Wino14Params& p, int tile, Wino14Tile& t) {
     // N fastest: the workgroups that transform the same input block run at the same time (its pixels come from L2)
     t.tile_n = tile % p.n_tiles;
     const int tm = tile / p.n_tiles;
     const int cb = tm % p.ncb, rb = tm / p.ncb;
     t.g0 = rb * p.R; t.t0 = cb * p.Ct; t.n0 = t.tile_n * W14_BN;
-    return true;
 }
 
-// Store phase of the epilogue, all 768 threads: the four fp32 C tiles [px][entry][channel chunk ^ (entry & 7)] are in LDS;
-// scale / shift, LeakyReLU, residual, 16-byte stores.
-__device__ __forceinline__ void wino14_store(const Wino14Params& p, const f32x4* sC, const Wino14Tile& tl, int tid) {
+// unaligned views or a last channel quad beyond cout: one element at a time (a call, so that the sixteen store sites stay small)
+__device__ __noinline__ void wino14_store_scalar(float* o, const float* rp, f32x4 v, int nvalid) {
+    for (int k = 0; k < 4 && k < nvalid; ++k) o[k] = rp ? v[k] + rp[k] : v[k];
+}
+
+// Epilogue of a consumer wave, from its six plane accumulators, with no workgroup barrier: the inverse transform position by
+// position (A^T rows (1,1,1,1,1,0), (0,1,-1,2,-2,0), (0,1,1,4,4,0), (0,1,-1,8,-8,1)), a transpose of the wave's 32 entries x 32
+// channels through 4 KiB of LDS of its own, then scale / shift, LeakyReLU, residual and 16-byte stores.  In the accumulators a
+// lane holds ONE entry (lane & 31) and four runs of four channels (8 q + 4 (lane >> 5)): stored from there, an instruction writes
+// 32-byte pieces (measured: 20 000 cycles per tile).  After the transpose lane L holds channels 4 (L & 7).. of entries 8 r + (L >> 3),
+// r = 0..3 -- eight lanes complete a 128-byte line -- and needs one scale / shift quad for the whole tile.
+// (The first version staged four fp32 C tiles of the whole workgroup in LDS: two barriers and a store phase of all 768 threads.)
+// sT: this wave's 256 f32x4 of the V buffer that the next tile does not write before its prologue barrier (buffer 1).
+__device__ __forceinline__ void wino14_epilogue(const Wino14Params& p, const f32x16 (&acc)[6], const Wino14Tile& tl, f32x4* sT, int wm,
+                                                int wn, int lane) {
+    const int fi = lane & 31, fk = lane >> 5;
     const int hp2 = p.H + 2;
-    const int n4 = tid & 15, r0 = tid >> 4;                 // 48 entries per sweep, 16 channel quads each
-    const int n = tl.n0 + n4 * 4;
-    const int nvalid = p.cout - n;
-    const bool vec = p.vec_io && nvalid >= 4;
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);      // padded to cout_pad
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-    float nonfinite = 0.f;          // range guard of the split representation (conv_igemm_split.hip: split_epilogue)
-#pragma unroll 1
-    for (int s = 0; s < 3; ++s) {
-        const int ml = s * 48 + r0;
-        if (ml >= W14_BM) break;
+    const int c8 = lane & 7;
+    const int nb = tl.n0 + 32 * wn + 4 * c8;
+    const int nvalid = p.cout - nb;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + nb);      // padded to cout_pad
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + nb);
+    // the four entries this lane stores
+    long long pix0[4];
+    int oxe[4];         // first pixel column of the entry; >= W: nothing to store
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+        const int ml = 32 * wm + 8 * rd + (lane >> 3);
         const int r = ml / p.Ct, t = ml - r * p.Ct;
         const int gg = tl.g0 + r;
         const int b = gg / hp2;
         const int y = gg - b * hp2 - 1;
-        const bool rowok = r < p.R && gg < p.gtot && y >= 0 && y < p.H && nvalid > 0;
-        const int ox0 = 4 * (tl.t0 + t);
-        const size_t pix0 = ((size_t)b * p.H + y) * p.W + ox0;
+        const bool rowok = r < p.R && gg < p.gtot && y >= 0 && y < p.H;
+        oxe[rd] = rowok ? 4 * (tl.t0 + t) : p.W;
+        pix0[rd] = ((long long)b * p.H + y) * p.W + 4 * (tl.t0 + t);
+    }
+    float nonfinite = 0.f;          // range guard of the split representation (conv_igemm_split.hip: split_epilogue)
 #pragma unroll
-        for (int px = 0; px < 4; ++px) {
-            if (!rowok || ox0 + px >= p.W) continue;
-            f32x4 v = sC[px * (W14_BM * 16) + ml * 16 + (n4 ^ (ml & 7))];
+    for (int px = 0; px < 4; ++px) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = 4 * gq + k;
+                if (px == 0) v[k] = acc[0][i] + acc[1][i] + acc[2][i] + acc[3][i] + acc[4][i];
+                else if (px == 1) v[k] = (acc[1][i] - acc[2][i]) + 2.f * (acc[3][i] - acc[4][i]);
+                else if (px == 2) v[k] = (acc[1][i] + acc[2][i]) + 4.f * (acc[3][i] + acc[4][i]);
+                else v[k] = (acc[1][i] - acc[2][i]) + 8.f * (acc[3][i] - acc[4][i]) + acc[5][i];
+            }
+            sT[fi * 8 + ((2 * gq + fk) ^ (fi & 7))] = v;        // row = entry, 16-byte chunk = channel quad, XOR-swizzled
+        }
+        // the wave's own LDS operations complete in order: no wait between its writes and its reads, nor before the next
+        // position's writes
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) {
+            const int e = 8 * rd + (lane >> 3);
+            f32x4 v = sT[e * 8 + (c8 ^ (e & 7))];
+            // entries beyond the block's R rows multiplied whatever the LDS held: they are neither stored nor range-checked
+            if (oxe[rd] + px >= p.W || nvalid <= 0) continue;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float tv = fmaf(v[k], sc[k], sh[k]);
                 nonfinite = fmaf(tv, 0.f, nonfinite);
                 v[k] = p.leaky ? (tv > 0.f ? tv : tv * 0.1f) : tv;
             }
-            float* o = p.out + (pix0 + px) * p.out_ps + n;
             if ((OM_W14_ABLATE & 32) && v[0] != 123.f) continue;
-            if (vec) {
-                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (pix0 + px) * p.res_ps + n);
+            float* o = p.out + (pix0[rd] + px) * p.out_ps + nb;
+            const float* rp = p.res ? p.res + (pix0[rd] + px) * p.res_ps + nb : nullptr;
+            if (p.vec_io && nvalid >= 4) {
+                if (rp) v += *reinterpret_cast<const f32x4*>(rp);
                 *reinterpret_cast<f32x4*>(o) = v;
             } else {
-                const float* rp = p.res ? p.res + (pix0 + px) * p.res_ps + n : nullptr;
-                for (int k = 0; k < 4 && k < nvalid; ++k) o[k] = rp ? v[k] + rp[k] : v[k];
+                wino14_store_scalar(o, rp, v, nvalid);
             }
         }
     }
@@ -136,14 +189,20 @@ __device__ __forceinline__ void wino14_store(const Wino14Params& p, const f32x4*
 
 // Roles.  The matrix waves must never wait on global memory: with the input loads, the transform and the weight DMA in their
 // own instruction streams (round 3's first version) a 16-channel chunk cost a third more than its matrix instructions -- VMEM
-// issue stalls of 60-180 cycles per request and 250 vector instructions per chunk in front of in-order matrix instructions
-// (ablations: profiles/r03_experiments.md).  So waves 8-11 are PRODUCERS -- they request the next chunk's input pixels, apply
-// B^T, split and write V, and feed the weight ring by LDS-DMA -- and waves 0-7 are CONSUMERS: LDS fragment reads and matrix
-// instructions only.  The two roles are two separate loops over the same sequence of tiles, chunks and groups that meet at
-// one s_barrier per group (the barrier counts waves, not program counters), so the six plane accumulators are live only in
-// the consumers' code and the input registers only in the producers': 168 registers, three waves per SIMD, one workgroup per CU.
+// issue stalls of 60-180 cycles per request and 250 vector instructions per chunk in front of in-order matrix instructions.
+// So waves 8-11 are PRODUCERS -- they request the next chunk's input pixels, apply B^T, split and write V -- and waves 0-7 are
+// CONSUMERS: the weight ring's LDS-DMA requests, LDS fragment reads, matrix instructions, and the epilogue from registers.
+// The two roles are two separate loops over the same sequence of tiles, chunks and groups that meet at one s_barrier per group
+// (the barrier counts waves, not program counters), so the six plane accumulators are live only in the consumers' code and the
+// input registers only in the producers': 168 registers, three waves per SIMD, one workgroup per CU.
+//
+// Tiles overlap at their ends (profiles/r03_w14_trace_tile_phases.txt: prologue + epilogue were 21 000 of a cin = 128 tile's
+// 80 000 cycles): the ticket of tile i + 1 is taken during the prologue of tile i (two LDS words, published by the prologue
+// barrier), so no barrier separates two tiles; the producers request the next tile's first chunk during the LAST chunk of this
+// one (their input registers are free then) and transform it while the consumers -- who first request the next tile's first
+// two weight groups -- run their epilogue.
 __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino14Params p) {
-    __shared__ f32x4 smem[2 * W14_VBUF + 3 * W14_UGRP + 1];      // ONE LDS object (conv_igemm.hip); last 16 B: the ticket
+    __shared__ f32x4 smem[2 * W14_VBUF + 3 * W14_UGRP + 1];      // ONE LDS object (conv_igemm.hip); last 16 B: two ticket words
     int* const s_ticket = reinterpret_cast<int*>(smem + 2 * W14_VBUF + 3 * W14_UGRP);
     f32x4* const s_u = smem + 2 * W14_VBUF;
 
@@ -151,7 +210,15 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ngroups = 6 * p.nch;
-    Wino14Tile tl;
+
+    if (tid == 0) s_ticket[0] = atomicAdd(p.ticket, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int tile = __builtin_amdgcn_readfirstlane(s_ticket[0]);
+    int tslot = 0;                      // s_ticket[tslot] is this tile's ticket, s_ticket[tslot ^ 1] takes the next one
+#if OM_W14_TRACE
+    bool first_tile = true;
+#endif
 
     if (wave >= 8) {
         // ================================================================ producers
@@ -159,13 +226,16 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
         const int hp2 = p.H + 2;
         const int ecount = (p.R + 2) * p.Ct;
         // a producer's few instructions per group are on everybody's critical path (the group barrier): issue them first
-        __builtin_amdgcn_s_setprio(3);
+        if (!(OM_W14_ABLATE & 4096)) __builtin_amdgcn_s_setprio(3);
         const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
-        while (wino14_next_tile(p, s_ticket, tid, tl)) {
-            // items: entry e = rr * Ct + t is padded row g0 - 1 + rr, tile column t0 + t; per item the byte offset of its first
-            // pixel (x = 4 t - 1) and a 6-bit "pixel exists" mask
-            int xbase[W14_ITEMS], xlds[W14_ITEMS];
-            unsigned xok[W14_ITEMS];
+
+        // items: entry e = rr * Ct + t is padded row g0 - 1 + rr, tile column t0 + t; per item the byte offset of its first
+        // pixel (x = 4 t - 1) and a 6-bit "pixel exists" mask
+        int xbase[W14_ITEMS], xlds[W14_ITEMS];
+        unsigned xok[W14_ITEMS];
+        auto setup_items = [&](int tile_id) {
+            Wino14Tile tl;
+            wino14_decode(p, tile_id, tl);
 #pragma unroll
             for (int k = 0; k < W14_ITEMS; ++k) {
                 const int idx = pid + 256 * k;
@@ -185,84 +255,142 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
                 const int sw = (e >> 2) & 3;
                 xlds[k] = e < ecount ? e * 64 + (((q >> 1) ^ sw) * 16) + (q & 1) * 8 : -1;
             }
-            f32x4 xr[W14_NX];
-            if (OM_W14_ABLATE & 128)
-                for (int i = 0; i < W14_NX; ++i) xr[i] = f32x4{(float)i, 1.f, (float)lane, 2.f};
-            auto load_item = [&](int k, int c) {
-                if (OM_W14_ABLATE & (16 | 128)) return;
+        };
+        f32x4 xr[W14_NX];
+        if (OM_W14_ABLATE & 128)
+            for (int i = 0; i < W14_NX; ++i) xr[i] = f32x4{(float)i, 1.f, (float)lane, 2.f};
+        auto load_item = [&](int k, int c) {
+            if (OM_W14_ABLATE & (16 | 128)) return;
 #pragma unroll
-                for (int x = 0; x < 6; ++x) {
-                    // a pixel outside the image (or a pad row) gets an offset beyond the descriptor's range: the load returns zeros
-                    int off = ((xok[k] >> x) & 1u) ? xbase[k] + x * p.in_ps * 4 + c * 64 : (int)0x80000000;
-                    if (OM_W14_ABLATE & 512) off = lane * 16 + (k * 6 + x) * 1024;      // measurement: every request hits the same 18 KiB
-                    xr[k * 6 + x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
-                }
-            };
-            // B^T along the row (the column transform of conv_wino24.hip), hi/lo split, 8-byte LDS stores into V buffer vb
-            auto transform_item = [&](int k, int vb) {
-                if ((OM_W14_ABLATE & (16 | 64)) || xlds[k] < 0) return;
-                const f32x4* d = xr + k * 6;
+            for (int x = 0; x < 6; ++x) {
+                // a pixel outside the image (or a pad row) gets an offset beyond the descriptor's range: the load returns zeros
+                int off = ((xok[k] >> x) & 1u) ? xbase[k] + x * p.in_ps * 4 + c * 64 : (int)0x80000000;
+                if (OM_W14_ABLATE & 512) off = lane * 16 + (k * 6 + x) * 1024;      // measurement: every request hits the same 18 KiB
+                xr[k * 6 + x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+            }
+        };
+        // B^T along the row (the column transform of conv_wino24.hip), hi/lo split, 8-byte LDS stores into V buffer vb.  An item
+        // is transformed in two halves -- planes 0-2 (pixels 0..4), planes 3-5 (pixels 1..5) -- so that every group carries the
+        // same producer work
+        auto transform_half = [&](int k, int vb, int half) {
+            if ((OM_W14_ABLATE & (16 | 64)) || xlds[k] < 0) return;
+            const f32x4* d = xr + k * 6;
+            f32x4 v[3];
+            if (half == 0) {
                 const f32x4 a12 = d[1] + d[2], s12 = d[1] - d[2];
                 const f32x4 a34 = d[3] + d[4], s34 = d[4] - d[3];
-                f32x4 v[6];
                 v[0] = 4.f * d[0] - 5.f * d[2] + d[4];
                 v[1] = a34 - 4.f * a12;
                 v[2] = 4.f * s12 + s34;
-                v[3] = (d[4] - d[2]) + 2.f * (d[3] - d[1]);
-                v[4] = (d[4] - d[2]) - 2.f * (d[3] - d[1]);
-                v[5] = 4.f * d[1] - 5.f * d[3] + d[5];
-                char* base = reinterpret_cast<char*>(smem + vb * W14_VBUF) + xlds[k];
-                // lo lives two 16-byte chunks after hi (chunk index XOR-swizzled: + 2 flips bit 1 of the chunk)
-                const int lo_off = ((((xlds[k] >> 4) & 3) ^ 2) - ((xlds[k] >> 4) & 3)) * 16;
+            } else {
+                v[0] = (d[4] - d[2]) + 2.f * (d[3] - d[1]);
+                v[1] = (d[4] - d[2]) - 2.f * (d[3] - d[1]);
+                v[2] = 4.f * d[1] - 5.f * d[3] + d[5];
+            }
+            char* base = reinterpret_cast<char*>(smem + vb * W14_VBUF) + xlds[k] + half * (3 * W14_VPLANE * 16);
+            // lo lives two 16-byte chunks after hi (chunk index XOR-swizzled: + 2 flips bit 1 of the chunk)
+            const int lo_off = ((((xlds[k] >> 4) & 3) ^ 2) - ((xlds[k] >> 4) & 3)) * 16;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const f16x4 h = __builtin_convertvector(v[j], f16x4);
-                    // x - hi in one v_fma_mix_f32 per element (the fp16 operand is widened by the instruction)
-                    const f32x4 rem = {__builtin_fmaf((float)h[0], -1.f, v[j][0]), __builtin_fmaf((float)h[1], -1.f, v[j][1]),
-                                       __builtin_fmaf((float)h[2], -1.f, v[j][2]), __builtin_fmaf((float)h[3], -1.f, v[j][3])};
-                    const f16x4 l = __builtin_convertvector(rem, f16x4);
-                    if ((OM_W14_ABLATE & 256) && h[0] != (_Float16)123.f) continue;
-                    *reinterpret_cast<u32x2*>(base + j * (W14_VPLANE * 16)) = __builtin_bit_cast(u32x2, h);
-                    *reinterpret_cast<u32x2*>(base + j * (W14_VPLANE * 16) + lo_off) = __builtin_bit_cast(u32x2, l);
-                }
-            };
-            // prologue: chunk 0 transformed, chunk 1 requested
+            for (int j = 0; j < 3; ++j) {
+                const f16x4 h = __builtin_convertvector(v[j], f16x4);
+                const u32x2 hb = __builtin_bit_cast(u32x2, h);
+                // x - hi in one v_fma_mix_f32 per element (the fp16 operand is widened by the instruction; exact)
+                f32x4 rem;
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rem[0]) : "v"(hb[0]), "v"(v[j][0]));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rem[1]) : "v"(hb[0]), "v"(v[j][1]));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rem[2]) : "v"(hb[1]), "v"(v[j][2]));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rem[3]) : "v"(hb[1]), "v"(v[j][3]));
+                const f16x4 l = __builtin_convertvector(rem, f16x4);
+                if ((OM_W14_ABLATE & 256) && h[0] != (_Float16)123.f) continue;
+                *reinterpret_cast<u32x2*>(base + j * (W14_VPLANE * 16)) = hb;
+                *reinterpret_cast<u32x2*>(base + j * (W14_VPLANE * 16) + lo_off) = __builtin_bit_cast(u32x2, l);
+            }
+        };
+
+        // the first tile's first chunk; every later tile's is requested during the tile before it
+        if (tile < p.total_tiles) {
+            setup_items(tile);
 #pragma unroll
             for (int k = 0; k < W14_ITEMS; ++k) load_item(k, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        while (tile < p.total_tiles) {
+#if OM_W14_TRACE
+            unsigned long long pp0, pp1, pp2 = 0, pp3 = 0;
+            W14_STAMP(pp0);
+#endif
+            // prologue: the next ticket requested, chunk 0 transformed, chunk 1 requested
+            int next_ticket = 0;
+            if (pid == 0) next_ticket = atomicAdd(p.ticket, 1);
 #pragma unroll
-            for (int k = 0; k < W14_ITEMS; ++k) transform_item(k, 0);
+            for (int k = 0; k < W14_ITEMS; ++k) { transform_half(k, 0, 0); transform_half(k, 0, 1); }
+            if (pid == 0) s_ticket[tslot ^ 1] = next_ticket;
             if (p.nch > 1) {
 #pragma unroll
                 for (int k = 0; k < W14_ITEMS; ++k) load_item(k, 1);
             }
+#if OM_W14_TRACE
+            W14_STAMP(pp1);
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            for (int c = 0; c < p.nch; ++c) {
-                const bool more = c + 1 < p.nch, more2 = c + 2 < p.nch;
+            const int next_tile = __builtin_amdgcn_readfirstlane(s_ticket[tslot ^ 1]);
+            // One chunk of matrix work = six groups; the producers' share of group j, in one of three straight-line forms:
+            //   0  (chunks 0 .. nch - 3)  half of item j / 2 of chunk c + 1 is transformed into the other V buffer (planes 0-2 in
+            //                             group 2 k, planes 3-5 in group 2 k + 1), then its registers take the request for item k
+            //                             of chunk c + 2 -- requested one whole chunk of matrix work before it is needed (the
+            //                             input comes from HBM for the first of the N-tile siblings: ~3 us under load);
+            //   1  (chunk nch - 2)        the transform only;
+            //   2  (chunk nch - 1)        nothing left to transform and every request of this tile has landed: the registers
+            //                             take the first chunk of the NEXT tile, one item per other group.
+            // The forms are separate code, without a branch around any request, because the compiler's wait for "item k has
+            // landed" counts the requests issued after it on the worst path: with `if (c + 2 < nch)` around each request it
+            // waited for all but the three youngest -- two groups' worth of HBM latency in every group.  Planes 0-2 of the
+            // last item are complete at the barrier that ends group 4: the consumers read the next chunk's first fragments
+            // (plane 0) during group 5.
+            auto chunk = [&](int c, auto form) {
+                constexpr int FORM = decltype(form)::value;
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    // Software pipeline of the input, one item per group in groups 2-4 (the next chunk's V is complete one group before
-                    // the consumers prefetch its first fragments): item k of chunk c + 1 -- requested one whole
-                    // chunk of matrix work ago (the input comes from HBM for the first of the N-tile siblings: ~3 us under load) --
-                    // is transformed into the other V buffer, and its registers at once take the request for item k of chunk c + 2.
-                    // Nothing else is in this wave's memory queue (the consumers feed the weight ring) and it retires in order, so
-                    // "at most the two younger items outstanding" is exactly "item k has landed".
-                    if (j >= 2 && j < 5 && more) {
-                        if (more2 || j == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                        else if (j == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        transform_item(j - 2, (c & 1) ^ 1);
-                        if (more2) load_item(j - 2, c + 2);
+#if OM_W14_TRACE
+                    unsigned long long ta, tb, tc, td;
+                    W14_STAMP(ta);
+                    W14_STAMP(tb);
+#endif
+                    if constexpr (FORM < 2) {
+                        transform_half(j >> 1, (c & 1) ^ 1, j & 1);
+                        if constexpr (FORM == 0) {
+                            if (j & 1) load_item(j >> 1, c + 2);
+                        }
+                    } else {
+                        if (next_tile < p.total_tiles) {
+                            if (j == 0) setup_items(next_tile);
+                            if ((j & 1) == 0) load_item(j >> 1, 0);
+                        }
                     }
+#if OM_W14_TRACE
+                    W14_STAMP(tc);
+#endif
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my LDS writes are done
+#if OM_W14_TRACE
+                    W14_STAMP(td);
+#endif
                     if (!(OM_W14_ABLATE & 4)) __builtin_amdgcn_s_barrier();
+#if OM_W14_TRACE
+                    W14_SETTLE(ta, tb, tc, td);
+                    if (wave == 8 && first_tile) w14_trace_put(p, 2, c * 6 + j, ta, tb, tc, td);
+#endif
                 }
-            }
-            __builtin_amdgcn_s_barrier();       // the consumers have staged the C tiles
-            wino14_store(p, smem, tl, tid);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the C tiles are dead before the next tile's operands land
-            __builtin_amdgcn_s_barrier();
+            };
+            for (int c = 0; c + 2 < p.nch; ++c) chunk(c, std::integral_constant<int, 0>{});
+            if (p.nch > 1) chunk(p.nch - 2, std::integral_constant<int, 1>{});
+            chunk(p.nch - 1, std::integral_constant<int, 2>{});
+#if OM_W14_TRACE
+            W14_SETTLE(pp0, pp1, pp2, pp3);
+            if (wave == 8 && !first_tile && pp3 == 0) w14_trace_put(p, 2, 62, pp0, pp1, pp2, pp3);      // a steady-state prologue
+            first_tile = false;
+#endif
+            tile = next_tile;
+            tslot ^= 1;
         }
         return;
     }
@@ -284,37 +412,47 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
     const int swB = (fi >> 2) & 3;
     const int boff_hi = (32 * wn + fi) * 4 + (fk ^ swB);
     const int boff_lo = (32 * wn + fi) * 4 + ((2 + fk) ^ swB);
-    while (wino14_next_tile(p, s_ticket, tid, tl)) {
-        // A entries of this lane for the three kernel rows: entry m + ky Ct of the plane
-        int aoff_hi[3], aoff_lo[3];
+    // A entries of this lane for the three kernel rows: entry m + ky Ct of the plane
+    int aoff_hi[3], aoff_lo[3];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int e = 32 * wm + fi + ky * p.Ct;
-            const int sw = (e >> 2) & 3;
-            aoff_hi[ky] = e * 4 + (fk ^ sw);
-            aoff_lo[ky] = e * 4 + ((2 + fk) ^ sw);
+    for (int ky = 0; ky < 3; ++ky) {
+        const int e = 32 * wm + fi + ky * p.Ct;
+        const int sw = (e >> 2) & 3;
+        aoff_hi[ky] = e * 4 + (fk ^ sw);
+        aoff_lo[ky] = e * 4 + ((2 + fk) ^ sw);
+    }
+    // weight group g = 6 c + j of N tile tn: 12 KiB at ((tn * nch + c) * 6 + j) * 12288 bytes of the packed blob
+    auto issue_group = [&](int ubase, int g) {
+        if (!(OM_W14_ABLATE & 8) && g < ngroups) {
+            const int slot = g % 3;
+            const int soff = ubase + g * (W14_UGRP * 16);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14_UGRP + wave * 64), 16, dvo[0], soff, 0, 0);
+            if (wave < 4)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14_UGRP + (wave + 8) * 64), 16, dvo[1], soff, 0, 0);
         }
-        // weight group g = 6 c + j: 12 KiB at ((tile_n * nch + c) * 6 + j) * 12288 bytes of the packed blob
+    };
+    Wino14Tile tl;
+    if (tile < p.total_tiles) {
+        wino14_decode(p, tile, tl);
         const int ubase = tl.tile_n * p.nch * 6 * (W14_UGRP * 16);
-        auto issue_group = [&](int g) {
-            if (!(OM_W14_ABLATE & 8) && g < ngroups) {
-                const int slot = g % 3;
-                const int soff = ubase + g * (W14_UGRP * 16);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14_UGRP + wave * 64), 16, dvo[0], soff, 0, 0);
-                if (wave < 4)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14_UGRP + (wave + 8) * 64), 16, dvo[1], soff, 0, 0);
-            }
-        };
+        issue_group(ubase, 0);
+        issue_group(ubase, 1);
+    }
+    while (tile < p.total_tiles) {
+        const int ubase = tl.tile_n * p.nch * 6 * (W14_UGRP * 16);
         f32x16 acc[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        issue_group(0);
-        issue_group(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();           // prologue: chunk 0 (producers) and weight groups 0, 1 are in LDS
-        // fragments are read one step ahead, across the group barrier too: weight group g + 1 -- requested at the top of group g - 1
+        __builtin_amdgcn_s_barrier();           // prologue: chunk 0 (producers), weight groups 0, 1 and the next ticket are in LDS
+        const int next_tile = __builtin_amdgcn_readfirstlane(s_ticket[tslot ^ 1]);
+#if OM_W14_TRACE
+        unsigned long long pt0, pt1, pt2, pt3 = 0;
+        W14_STAMP(pt0);
+#endif
+        // fragments are read one step ahead, across the group barrier too: weight group g + 1 -- requested in group g - 1
         // -- is waited for at the END of group g - 1 (one group of matrix work for 12 KiB from L2), and the next chunk's V is
         // published by the barrier that ends group 4
         f32x4 ca[4], na[4];        // A hi, A lo, B hi, B lo of the current / next step
@@ -336,53 +474,75 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
 #pragma unroll
             for (int j = 0; j < 6; ++j, ++g) {
                 const int slot = g % 3, slot1 = slot == 2 ? 0 : slot + 1;
-                // groups g and g + 1 are in LDS; every wave has left group g - 1: its slot takes group g + 2, which has to land
-                // by the end of this group
-                issue_group(g + 2);
+#if OM_W14_TRACE
+                unsigned long long ta, tb, tc, td;
+                W14_STAMP(ta);
+#endif
+                // groups g and g + 1 are in LDS; every wave has left group g - 1: its slot takes group g + 2 (requested below),
+                // which has to land by the end of this group
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
+                    if constexpr (OM_W14_ABLATE & 2048) continue;       // idle consumers: the producers' own speed
                     if (ky < 2) read_frags(na, sV, j, ky + 1, slot);
                     else if (j < 5) read_frags(na, sV, j + 1, 0, slot1);
                     else if (c + 1 < p.nch) read_frags(na, sVn, 0, 0, slot1);
                     const f16x8 ah = __builtin_bit_cast(f16x8, ca[0]), al = __builtin_bit_cast(f16x8, ca[1]);
                     const f16x8 bh = __builtin_bit_cast(f16x8, ca[2]), bl = __builtin_bit_cast(f16x8, ca[3]);
                     // weights first: D[i = channel][j = entry]
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[j], 0, 0, 0);
+                    if constexpr (OM_W14_ABLATE & 1024) {       // no matrix instructions: the operands still have to arrive
+                        asm volatile("" ::"v"(ah), "v"(al), "v"(bh), "v"(bl));
+                    } else {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[j], 0, 0, 0);
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) ca[i] = na[i];
+                    // the request (60-200 cycles of issue) behind the first matrix instructions, not in front of them
+                    if (ky == W14_DMA_AFTER) {
+                        issue_group(ubase, g + 2);
+#if OM_W14_TRACE
+                        W14_STAMP(tb);
+#endif
+                    }
                 }
                 // my pieces of weight group g + 2 have landed; my reads of this group's slot and plane are done
+#if OM_W14_TRACE
+                W14_STAMP(tc);
+#endif
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#if OM_W14_TRACE
+                W14_STAMP(td);
+#endif
                 if (!(OM_W14_ABLATE & 4)) __builtin_amdgcn_s_barrier();
+#if OM_W14_TRACE
+                W14_SETTLE(ta, tb, tc, td);
+                if ((wave == 0 || wave == 4) && first_tile) w14_trace_put(p, wave >> 2, g, ta, tb, tc, td);
+#endif
             }
         }
-        // ---- inverse transform position by position (A^T rows (1,1,1,1,1,0), (0,1,-1,2,-2,0), (0,1,1,4,4,0), (0,1,-1,8,-8,1))
-        // into four fp32 C tiles in LDS (128 KiB of the 156; every operand is dead: the last group's barrier has passed)
-        {
-            f32x4* sC = smem;
-            const int ml = 32 * wm + fi;
-#pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                f32x16 yv;
-                if (px == 0) yv = acc[0] + acc[1] + acc[2] + acc[3] + acc[4];
-                else if (px == 1) yv = (acc[1] - acc[2]) + 2.f * (acc[3] - acc[4]);
-                else if (px == 2) yv = (acc[1] + acc[2]) + 4.f * (acc[3] + acc[4]);
-                else yv = (acc[1] - acc[2]) + 8.f * (acc[3] - acc[4]) + acc[5];
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int n4 = (32 * wn) / 4 + 2 * gq + fk;
-                    const f32x4 v = {yv[4 * gq], yv[4 * gq + 1], yv[4 * gq + 2], yv[4 * gq + 3]};
-                    sC[px * (W14_BM * 16) + ml * 16 + (n4 ^ (ml & 7))] = v;
-                }
-            }
+#if OM_W14_TRACE
+        W14_STAMP(pt1);
+#endif
+        // every operand in LDS is dead (the last group's barrier has passed): the next tile's first two weight groups are
+        // requested before the epilogue, its first chunk is being transformed by the producers meanwhile
+        Wino14Tile tn = tl;
+        if (next_tile < p.total_tiles) {
+            wino14_decode(p, next_tile, tn);
+            const int ub = tn.tile_n * p.nch * 6 * (W14_UGRP * 16);
+            issue_group(ub, 0);
+            issue_group(ub, 1);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        wino14_store(p, smem, tl, tid);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        wino14_epilogue(p, acc, tl, smem + W14_VBUF + wave * 256, wm, wn, lane);
+#if OM_W14_TRACE
+        W14_STAMP(pt2);
+        W14_SETTLE(pt0, pt1, pt2, pt3);
+        if (wave == 0 && first_tile) w14_trace_put(p, 0, 60, pt0, pt1, pt2, pt3);
+        first_tile = false;
+#endif
+        tl = tn;
+        tile = next_tile;
+        tslot ^= 1;
     }
 }
 
@@ -439,6 +599,10 @@ int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream) {
     const size_t ub = wino14_weight_halfs(a.cout_pad, a.cin) * 2;
     OM_REQUIRE(ub < 0x7FFFFFF0ull, OM_EINVAL, "wino14: weights exceed a buffer descriptor");
     p.u_bytes = (int)ub;
+#if OM_W14_TRACE
+    p.trace = g_w14_trace;
+    OM_REQUIRE(p.trace, OM_EINVAL, "wino14 trace build: om_debug_w14_trace() first");
+#endif
     const long long grid = total < 256 ? total : 256;        // one 768-thread workgroup per CU (156 KiB of LDS)
     hipLaunchKernelGGL(wino14_split_kernel, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
