@@ -39,6 +39,8 @@
 namespace om {
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4v __attribute__((__vector_size__(4 * sizeof(unsigned))));
 
@@ -53,8 +55,12 @@ constexpr int W14_EMAX = 160;                 // LDS entries per plane: (R + 2) 
 constexpr int W14_VPLANE = W14_EMAX * 4;      // f32x4 units (16 B) per plane
 constexpr int W14_VBUF = 6 * W14_VPLANE;      // one transformed chunk: 61440 B
 constexpr int W14_UGRP = 3 * W14_BN * 4;      // one (j; ky = 0..2) weight group: 12288 B
-constexpr int W14_ITEMS = 3;                  // (entry, channel quad) items per producer thread: 3 * 256 >= 4 * W14_EMAX
-constexpr int W14_NX = 6 * W14_ITEMS;         // input loads per producer thread and chunk
+#ifndef W14_QUEUE
+#define W14_QUEUE 0            // per-XCD tile queues: 0 = M blocks partitioned (N-tile siblings share the input behind one L2),
+#endif                         // 1 = N tiles partitioned (an XCD streams one or two N tiles' weights: they stay in its L2)
+#ifndef W14_B_ACROSS
+#define W14_B_ACROSS 0         // 1: the first weight fragments of a group are read before the barrier that starts it (its weights
+#endif                         // landed a group earlier); 0: after it -- the requests get two groups to land
 #ifndef W14_DMA_AFTER
 #define W14_DMA_AFTER 0        // the weight request follows the matrix instructions of this kernel row of the group
 #endif
@@ -86,6 +92,7 @@ static unsigned long long* g_w14_trace = nullptr;
 extern "C" void om_debug_w14_trace(void* buf) { g_w14_trace = static_cast<unsigned long long*>(buf); }
 #define W14_STAMP(x) asm volatile("s_memtime %0" : "=s"(x)::"memory")
 #define W14_SETTLE(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d)::"memory")
+#define W14_SETTLE2(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory")
 __device__ __forceinline__ void w14_trace_put(const Wino14Params& p, int slot, int g, unsigned long long a, unsigned long long b,
                                               unsigned long long c, unsigned long long d) {
     if (blockIdx.x < 8 && g < 64 && (threadIdx.x & 63) == 0) {
@@ -94,6 +101,10 @@ __device__ __forceinline__ void w14_trace_put(const Wino14Params& p, int slot, i
     }
 }
 #endif
+
+// Order in which the six planes (transform points) of a chunk are multiplied: group g of a chunk works on plane w14_plane(g) of V
+// and of U.  Pairs (1, 2), (3, 4), (0, 5): what the producers make in one group from shared differences of the same pixels.
+__host__ __device__ constexpr int w14_plane(int g) { return g == 0 ? 1 : g == 1 ? 2 : g == 2 ? 3 : g == 3 ? 4 : g == 4 ? 0 : 5; }
 
 struct Wino14Tile {
     int g0, t0, n0, tile_n;
@@ -211,7 +222,44 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ngroups = 6 * p.nch;
 
-    if (tid == 0) s_ticket[0] = atomicAdd(p.ticket, 1);
+    // EIGHT tile queues, one per XCD (ticket words 0..7), as in conv_wino24.hip: XCD x owns the row/column blocks
+    // [m_tiles x / 8, m_tiles (x + 1) / 8) and its workgroups draw (block, N tile) pairs N fastest, so the n_tiles workgroups
+    // that transform the same input block run at the same time behind the SAME L2 -- the first one's requests go to HBM, the
+    // others' hit (the producers cannot hide an HBM round trip: their registers hold barely one chunk in flight).  A workgroup
+    // whose queue is empty moves on to the next XCD's (never back), so the last round still balances over the whole chip.
+    // Placement only: results do not depend on which workgroup computes a tile.  Drawn by ONE thread (the producers' first),
+    // which keeps the queue position.
+    int q_xcd = 0, q_hops = 0;
+    auto draw_tile = [&]() {
+        const int m_tiles = p.total_tiles / p.n_tiles;
+#if W14_QUEUE == 1
+        // queue q: N tiles k, k + classes, ... (k = q % classes) of the M blocks' part q / classes
+        const int classes = p.n_tiles >= 8 ? 8 : (p.n_tiles == 4 || p.n_tiles == 2 || p.n_tiles == 1) ? p.n_tiles : 1;
+        const int mparts = 8 / classes;
+#endif
+        while (q_hops < 8) {
+            const int q = (q_xcd + q_hops) & 7;
+#if W14_QUEUE == 1
+            const int k = q % classes, mp = q / classes;
+            const int pm0 = (int)((long long)m_tiles * mp / mparts), pm1 = (int)((long long)m_tiles * (mp + 1) / mparts);
+            const int nk = (p.n_tiles - k + classes - 1) / classes;
+            const int v = atomicAdd(p.ticket + q, 1);
+            if (v < (pm1 - pm0) * nk) return (pm0 + v / nk) * p.n_tiles + k + classes * (v % nk);
+#else
+            const int pm0 = (int)((long long)m_tiles * q >> 3), pm1 = (int)((long long)m_tiles * (q + 1) >> 3);
+            const int v = atomicAdd(p.ticket + q, 1);
+            if (v < (pm1 - pm0) * p.n_tiles) return pm0 * p.n_tiles + v;
+#endif
+            ++q_hops;
+        }
+        return p.total_tiles;
+    };
+    if (tid == 512) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(q_xcd));
+        q_xcd &= 7;
+        if (OM_W14_ABLATE & 8192) q_xcd = 0;        // measurement: one queue order for the whole chip
+        s_ticket[0] = draw_tile();
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int tile = __builtin_amdgcn_readfirstlane(s_ticket[0]);
@@ -229,17 +277,22 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
         if (!(OM_W14_ABLATE & 4096)) __builtin_amdgcn_s_setprio(3);
         const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
 
-        // items: entry e = rr * Ct + t is padded row g0 - 1 + rr, tile column t0 + t; per item the byte offset of its first
-        // pixel (x = 4 t - 1) and a 6-bit "pixel exists" mask
-        int xbase[W14_ITEMS], xlds[W14_ITEMS];
-        unsigned xok[W14_ITEMS];
+        // Items.  Entry e = rr * Ct + t is padded row g0 - 1 + rr, tile column t0 + t: six pixels x = 4 t - 1 .. 4 t + 4 of 16
+        // channels per chunk.  A thread owns channel QUAD pid & 3 of entries pid >> 2 (item 0) and 64 + (pid >> 2) (item 1), and a
+        // channel PAIR of entry 128 + (pid >> 3) (item 2: quad (pid >> 1) & 3, pair pid & 1) -- the 32 entries beyond 128 are half
+        // an item's work per thread as pairs, a whole item's as quads (every instruction of a partly filled round costs the same).
+        // Per item: the byte offset of its first pixel, a 6-bit "pixel exists" mask, the LDS byte address of its hi halfs in
+        // plane 0 (lo: the 16-byte chunk two further on; -1: no such entry).
+        int xbase[3], xlds[3];
+        unsigned xok[3];
         auto setup_items = [&](int tile_id) {
             Wino14Tile tl;
             wino14_decode(p, tile_id, tl);
 #pragma unroll
-            for (int k = 0; k < W14_ITEMS; ++k) {
-                const int idx = pid + 256 * k;
-                const int e = idx >> 2, q = idx & 3;
+            for (int k = 0; k < 3; ++k) {
+                const int e = k < 2 ? 64 * k + (pid >> 2) : 128 + (pid >> 3);
+                const int q = k < 2 ? pid & 3 : (pid >> 1) & 3;
+                const int ch = k < 2 ? 4 * q : 4 * q + 2 * (pid & 1);
                 const int rr = e / p.Ct, t = e - rr * p.Ct;
                 const int g = tl.g0 - 1 + rr;
                 const int b = g / hp2;
@@ -250,68 +303,95 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
 #pragma unroll
                 for (int x = 0; x < 6; ++x) ok |= (rowok && (unsigned)(x0 + x) < (unsigned)p.W ? 1u : 0u) << x;
                 xok[k] = ok;
-                xbase[k] = (((b * p.H + y) * p.W + x0) * p.in_ps + 4 * q) * 4;
-                // LDS byte address of the item's 8 hi bytes in plane 0 (lo: the chunk two further on); -1: no such entry
+                xbase[k] = (((b * p.H + y) * p.W + x0) * p.in_ps + ch) * 4;
                 const int sw = (e >> 2) & 3;
-                xlds[k] = e < ecount ? e * 64 + (((q >> 1) ^ sw) * 16) + (q & 1) * 8 : -1;
+                xlds[k] = e < ecount ? e * 64 + (((q >> 1) ^ sw) * 16) + (ch & 7) * 2 : -1;
             }
         };
-        f32x4 xr[W14_NX];
-        if (OM_W14_ABLATE & 128)
-            for (int i = 0; i < W14_NX; ++i) xr[i] = f32x4{(float)i, 1.f, (float)lane, 2.f};
-        auto load_item = [&](int k, int c) {
-            if (OM_W14_ABLATE & (16 | 128)) return;
+        f32x4 xq[2][6];         // the two quad items' pixels
+        f32x2 xp[2][6];         // the pair item's, of two chunks in turn (it is in use in every group: see the schedule below)
+        auto item_offset = [&](int k, int x, int c) {
+            // a pixel outside the image (or a pad row) gets an offset beyond the descriptor's range: the load returns zeros
+            int off = ((xok[k] >> x) & 1u) ? xbase[k] + x * p.in_ps * 4 + c * 64 : (int)0x80000000;
+            if (OM_W14_ABLATE & 512) off = lane * 16 + (k * 6 + x) * 1024;      // measurement: every request hits the same 18 KiB
+            return off;
+        };
+        auto load_quad = [&](int k, int c) {
+            if (OM_W14_ABLATE & 16) return;
 #pragma unroll
-            for (int x = 0; x < 6; ++x) {
-                // a pixel outside the image (or a pad row) gets an offset beyond the descriptor's range: the load returns zeros
-                int off = ((xok[k] >> x) & 1u) ? xbase[k] + x * p.in_ps * 4 + c * 64 : (int)0x80000000;
-                if (OM_W14_ABLATE & 512) off = lane * 16 + (k * 6 + x) * 1024;      // measurement: every request hits the same 18 KiB
-                xr[k * 6 + x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+            for (int x = 0; x < 6; ++x) xq[k][x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, item_offset(k, x, c), 0, 0));
+        };
+        auto load_pair = [&](auto buf, int c) {
+            if (OM_W14_ABLATE & 16) return;
+#pragma unroll
+            for (int x = 0; x < 6; ++x)
+                xp[decltype(buf)::value][x] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, item_offset(2, x, c), 0, 0));
+        };
+        // hi/lo split of one transformed value per channel and its LDS stores (hi: RNE fp16 of x; lo: RNE fp16 of x - hi, the
+        // difference exact in one v_fma_mix_f32 per element -- the fp16 operand is widened by the instruction)
+        auto split_store4 = [&](const f32x4& v, char* dst, int lo_off) {
+            const f16x4 h = __builtin_convertvector(v, f16x4);
+            const u32x2 hb = __builtin_bit_cast(u32x2, h);
+            f32x4 rem;
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rem[0]) : "v"(hb[0]), "v"(v[0]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rem[1]) : "v"(hb[0]), "v"(v[1]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rem[2]) : "v"(hb[1]), "v"(v[2]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rem[3]) : "v"(hb[1]), "v"(v[3]));
+            const f16x4 l = __builtin_convertvector(rem, f16x4);
+            if ((OM_W14_ABLATE & 256) && h[0] != (_Float16)123.f) return;
+            *reinterpret_cast<u32x2*>(dst) = hb;
+            *reinterpret_cast<u32x2*>(dst + lo_off) = __builtin_bit_cast(u32x2, l);
+        };
+        auto split_store2 = [&](const f32x2& v, char* dst, int lo_off) {
+            const f16x2 h = __builtin_convertvector(v, f16x2);
+            const unsigned hb = __builtin_bit_cast(unsigned, h);
+            f32x2 rem;
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rem[0]) : "v"(hb), "v"(v[0]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rem[1]) : "v"(hb), "v"(v[1]));
+            const f16x2 l = __builtin_convertvector(rem, f16x2);
+            if ((OM_W14_ABLATE & 256) && h[0] != (_Float16)123.f) return;
+            *reinterpret_cast<unsigned*>(dst) = hb;
+            *reinterpret_cast<unsigned*>(dst + lo_off) = __builtin_bit_cast(unsigned, l);
+        };
+        // B^T along the row (the column transform of conv_wino24.hip), one transform point (plane) at a time:
+        //   v0 = 4 d0 - 5 d2 + d4   v1 = (d3 + d4) - 4 (d1 + d2)   v2 = (d4 - d3) + 4 (d1 - d2)
+        //   v5 = 4 d1 - 5 d3 + d5   v3 = (d4 - d2) + 2 (d3 - d1)   v4 = (d4 - d2) - 2 (d3 - d1)
+        auto point = [&](const auto* d, int j) {
+            using T = std::remove_cv_t<std::remove_reference_t<decltype(d[0])>>;
+            const T c4 = 4.f, cm4 = -4.f, c2 = 2.f, cm2 = -2.f, cm5 = -5.f;
+            switch (j) {
+                case 0: return __builtin_elementwise_fma(d[2], cm5, __builtin_elementwise_fma(d[0], c4, d[4]));
+                case 1: return __builtin_elementwise_fma(d[1] + d[2], cm4, d[3] + d[4]);
+                case 2: return __builtin_elementwise_fma(d[1] - d[2], c4, d[4] - d[3]);
+                case 3: return __builtin_elementwise_fma(d[3] - d[1], c2, d[4] - d[2]);
+                case 4: return __builtin_elementwise_fma(d[3] - d[1], cm2, d[4] - d[2]);
+                default: return __builtin_elementwise_fma(d[3], cm5, __builtin_elementwise_fma(d[1], c4, d[5]));
             }
         };
-        // B^T along the row (the column transform of conv_wino24.hip), hi/lo split, 8-byte LDS stores into V buffer vb.  An item
-        // is transformed in two halves -- planes 0-2 (pixels 0..4), planes 3-5 (pixels 1..5) -- so that every group carries the
-        // same producer work
-        auto transform_half = [&](int k, int vb, int half) {
+        // two planes (positions i and i + 1 of the consumers' plane order) of quad item k into V buffer vb
+        auto quad_planes = [&](int k, int vb, int i) {
             if ((OM_W14_ABLATE & (16 | 64)) || xlds[k] < 0) return;
-            const f32x4* d = xr + k * 6;
-            f32x4 v[3];
-            if (half == 0) {
-                const f32x4 a12 = d[1] + d[2], s12 = d[1] - d[2];
-                const f32x4 a34 = d[3] + d[4], s34 = d[4] - d[3];
-                v[0] = 4.f * d[0] - 5.f * d[2] + d[4];
-                v[1] = a34 - 4.f * a12;
-                v[2] = 4.f * s12 + s34;
-            } else {
-                v[0] = (d[4] - d[2]) + 2.f * (d[3] - d[1]);
-                v[1] = (d[4] - d[2]) - 2.f * (d[3] - d[1]);
-                v[2] = 4.f * d[1] - 5.f * d[3] + d[5];
-            }
-            char* base = reinterpret_cast<char*>(smem + vb * W14_VBUF) + xlds[k] + half * (3 * W14_VPLANE * 16);
+            char* base = reinterpret_cast<char*>(smem + vb * W14_VBUF) + xlds[k];
             // lo lives two 16-byte chunks after hi (chunk index XOR-swizzled: + 2 flips bit 1 of the chunk)
             const int lo_off = ((((xlds[k] >> 4) & 3) ^ 2) - ((xlds[k] >> 4) & 3)) * 16;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const f16x4 h = __builtin_convertvector(v[j], f16x4);
-                const u32x2 hb = __builtin_bit_cast(u32x2, h);
-                // x - hi in one v_fma_mix_f32 per element (the fp16 operand is widened by the instruction; exact)
-                f32x4 rem;
-                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rem[0]) : "v"(hb[0]), "v"(v[j][0]));
-                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rem[1]) : "v"(hb[0]), "v"(v[j][1]));
-                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(rem[2]) : "v"(hb[1]), "v"(v[j][2]));
-                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rem[3]) : "v"(hb[1]), "v"(v[j][3]));
-                const f16x4 l = __builtin_convertvector(rem, f16x4);
-                if ((OM_W14_ABLATE & 256) && h[0] != (_Float16)123.f) continue;
-                *reinterpret_cast<u32x2*>(base + j * (W14_VPLANE * 16)) = hb;
-                *reinterpret_cast<u32x2*>(base + j * (W14_VPLANE * 16) + lo_off) = __builtin_bit_cast(u32x2, l);
-            }
+            const int ja = w14_plane(i), jb = w14_plane(i + 1);
+            split_store4(point(xq[k], ja), base + ja * (W14_VPLANE * 16), lo_off);
+            split_store4(point(xq[k], jb), base + jb * (W14_VPLANE * 16), lo_off);
+        };
+        auto pair_plane = [&](auto buf, int vb, int i) {
+            if ((OM_W14_ABLATE & (16 | 64)) || xlds[2] < 0) return;
+            char* base = reinterpret_cast<char*>(smem + vb * W14_VBUF) + xlds[2];
+            const int lo_off = ((((xlds[2] >> 4) & 3) ^ 2) - ((xlds[2] >> 4) & 3)) * 16;
+            const int j = w14_plane(i);
+            split_store2(point(xp[decltype(buf)::value], j), base + j * (W14_VPLANE * 16), lo_off);
         };
 
         // the first tile's first chunk; every later tile's is requested during the tile before it
         if (tile < p.total_tiles) {
             setup_items(tile);
-#pragma unroll
-            for (int k = 0; k < W14_ITEMS; ++k) load_item(k, 0);
+            load_quad(0, 0);
+            load_quad(1, 0);
+            load_pair(std::integral_constant<int, 0>{}, 0);
         }
         while (tile < p.total_tiles) {
 #if OM_W14_TRACE
@@ -320,13 +400,16 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
 #endif
             // prologue: the next ticket requested, chunk 0 transformed, chunk 1 requested
             int next_ticket = 0;
-            if (pid == 0) next_ticket = atomicAdd(p.ticket, 1);
+            if (pid == 0) next_ticket = draw_tile();
 #pragma unroll
-            for (int k = 0; k < W14_ITEMS; ++k) { transform_half(k, 0, 0); transform_half(k, 0, 1); }
+            for (int i = 0; i < 6; i += 2) { quad_planes(0, 0, i); quad_planes(1, 0, i); }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) pair_plane(std::integral_constant<int, 0>{}, 0, i);
             if (pid == 0) s_ticket[tslot ^ 1] = next_ticket;
             if (p.nch > 1) {
-#pragma unroll
-                for (int k = 0; k < W14_ITEMS; ++k) load_item(k, 1);
+                load_quad(0, 1);
+                load_quad(1, 1);
+                load_pair(std::integral_constant<int, 1>{}, 1);
             }
 #if OM_W14_TRACE
             W14_STAMP(pp1);
@@ -334,56 +417,73 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const int next_tile = __builtin_amdgcn_readfirstlane(s_ticket[tslot ^ 1]);
-            // One chunk of matrix work = six groups; the producers' share of group j, in one of three straight-line forms:
-            //   0  (chunks 0 .. nch - 3)  half of item j / 2 of chunk c + 1 is transformed into the other V buffer (planes 0-2 in
-            //                             group 2 k, planes 3-5 in group 2 k + 1), then its registers take the request for item k
-            //                             of chunk c + 2 -- requested one whole chunk of matrix work before it is needed (the
-            //                             input comes from HBM for the first of the N-tile siblings: ~3 us under load);
-            //   1  (chunk nch - 2)        the transform only;
-            //   2  (chunk nch - 1)        nothing left to transform and every request of this tile has landed: the registers
-            //                             take the first chunk of the NEXT tile, one item per other group.
-            // The forms are separate code, without a branch around any request, because the compiler's wait for "item k has
-            // landed" counts the requests issued after it on the worst path: with `if (c + 2 < nch)` around each request it
-            // waited for all but the three youngest -- two groups' worth of HBM latency in every group.  Planes 0-2 of the
-            // last item are complete at the barrier that ends group 4: the consumers read the next chunk's first fragments
-            // (plane 0) during group 5.
-            auto chunk = [&](int c, auto form) {
+            // One chunk of matrix work = six groups, one plane each, in the order w14_plane(0..5).  The producers' share of group
+            // g while chunk c is being multiplied -- every group the same work, 2 1/2 planes of a quad item:
+            //   groups 0-2   planes (2 g, 2 g + 1) of quad item 0 of chunk c + 1;   groups 3-5   the same of quad item 1;
+            //   every group  plane g of the pair item of chunk c + 1
+            // into the other V buffer.  Position i of chunk c + 1 is read by the consumers from group i - 1 on (position 0: from
+            // group 5 of chunk c): item 1's planes (0, 1) are complete at the barrier that ends group 3.  A quad item's registers
+            // take the request for chunk c + 2 after its last planes (groups 2 and 5: four groups of matrix work before their
+            // first use; the input comes from HBM for the first of the N-tile siblings, ~3 us under load); the pair item, in
+            // use in every group, alternates between two register sets (chunk parity `par`), the free one requested in group 0.
+            // Three straight-line forms, without a branch around any request -- the compiler's wait for "this item has landed"
+            // counts the requests issued after it on the worst path, and with `if (c + 2 < nch)` around each request it waited
+            // for all but the three youngest (two groups' worth of HBM latency in every group):
+            //   0  (chunks 0 .. nch - 3)  transform chunk c + 1, request chunk c + 2;     1  (chunk nch - 2)  the transform only;
+            //   2  (chunk nch - 1)        nothing left to transform, every request of this tile has landed: the registers take
+            //                             the first chunk of the NEXT tile.
+            auto chunk = [&](int c, auto form, auto par) {
                 constexpr int FORM = decltype(form)::value;
+                constexpr int PAR = decltype(par)::value;           // c & 1: chunk c + 1's pair item is in xp[PAR ^ 1]
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
+                for (int g = 0; g < 6; ++g) {
 #if OM_W14_TRACE
-                    unsigned long long ta, tb, tc, td;
+                    unsigned long long ta, tb = 0, tc, td = 0;
                     W14_STAMP(ta);
-                    W14_STAMP(tb);
 #endif
                     if constexpr (FORM < 2) {
-                        transform_half(j >> 1, (c & 1) ^ 1, j & 1);
                         if constexpr (FORM == 0) {
-                            if (j & 1) load_item(j >> 1, c + 2);
+                            if (g == 0) load_pair(std::integral_constant<int, PAR>{}, c + 2);
+                        }
+                        quad_planes(g / 3, PAR ^ 1, 2 * (g % 3));
+                        pair_plane(std::integral_constant<int, PAR ^ 1>{}, PAR ^ 1, g);
+                        if constexpr (FORM == 0) {
+                            if (g == 2) load_quad(0, c + 2);
+                            if (g == 5) load_quad(1, c + 2);
                         }
                     } else {
                         if (next_tile < p.total_tiles) {
-                            if (j == 0) setup_items(next_tile);
-                            if ((j & 1) == 0) load_item(j >> 1, 0);
+                            if (g == 0) { setup_items(next_tile); load_quad(0, 0); }
+                            if (g == 2) load_quad(1, 0);
+                            if (g == 4) load_pair(std::integral_constant<int, 0>{}, 0);
                         }
                     }
 #if OM_W14_TRACE
                     W14_STAMP(tc);
 #endif
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my LDS writes are done
-#if OM_W14_TRACE
-                    W14_STAMP(td);
-#endif
                     if (!(OM_W14_ABLATE & 4)) __builtin_amdgcn_s_barrier();
 #if OM_W14_TRACE
-                    W14_SETTLE(ta, tb, tc, td);
-                    if (wave == 8 && first_tile) w14_trace_put(p, 2, c * 6 + j, ta, tb, tc, td);
+                    W14_SETTLE2(ta, tc);
+                    if (wave == 8 && first_tile) w14_trace_put(p, 2, c * 6 + g, ta, tb, tc, td);
 #endif
                 }
             };
-            for (int c = 0; c + 2 < p.nch; ++c) chunk(c, std::integral_constant<int, 0>{});
-            if (p.nch > 1) chunk(p.nch - 2, std::integral_constant<int, 1>{});
-            chunk(p.nch - 1, std::integral_constant<int, 2>{});
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            int c = 0;
+            for (; c + 3 < p.nch; c += 2) { chunk(c, I0{}, I0{}); chunk(c + 1, I0{}, I1{}); }
+            if (c + 2 < p.nch) {            // c even, nch odd
+                chunk(c, I0{}, I0{});
+                chunk(c + 1, I1{}, I1{});
+                chunk(c + 2, I2{}, I0{});
+            } else if (c + 1 < p.nch) {     // c even, nch even
+                chunk(c, I1{}, I0{});
+                chunk(c + 1, I2{}, I1{});
+            } else {                        // nch == 1
+                chunk(c, I2{}, I0{});
+            }
 #if OM_W14_TRACE
             W14_SETTLE(pp0, pp1, pp2, pp3);
             if (wave == 8 && !first_tile && pp3 == 0) w14_trace_put(p, 2, 62, pp0, pp1, pp2, pp3);      // a steady-state prologue
@@ -425,7 +525,7 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
     auto issue_group = [&](int ubase, int g) {
         if (!(OM_W14_ABLATE & 8) && g < ngroups) {
             const int slot = g % 3;
-            const int soff = ubase + g * (W14_UGRP * 16);
+            const int soff = ubase + (g - g % 6 + w14_plane(g % 6)) * (W14_UGRP * 16);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14_UGRP + wave * 64), 16, dvo[0], soff, 0, 0);
             if (wave < 4)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14_UGRP + (wave + 8) * 64), 16, dvo[1], soff, 0, 0);
@@ -456,70 +556,89 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
         // -- is waited for at the END of group g - 1 (one group of matrix work for 12 KiB from L2), and the next chunk's V is
         // published by the barrier that ends group 4
         f32x4 ca[4], na[4];        // A hi, A lo, B hi, B lo of the current / next step
+        auto read_a = [&](f32x4(&f)[4], const f32x4* sV, int j, int ky) {
+            f[0] = sV[w14_plane(j) * W14_VPLANE + aoff_hi[ky]];
+            f[1] = sV[w14_plane(j) * W14_VPLANE + aoff_lo[ky]];
+        };
+        auto read_b = [&](f32x4(&f)[4], int ky, int slot) {
+            f[2] = s_u[slot * W14_UGRP + ky * (W14_BN * 4) + boff_hi];
+            f[3] = s_u[slot * W14_UGRP + ky * (W14_BN * 4) + boff_lo];
+        };
         auto read_frags = [&](f32x4(&f)[4], const f32x4* sV, int j, int ky, int slot) {
             if constexpr (OM_W14_ABLATE & 2) {
                 f[0] = f[1] = f[2] = f[3] = f32x4{(float)(j + ky), 1.f, 2.f, (float)lane};
             } else {
-                f[0] = sV[j * W14_VPLANE + aoff_hi[ky]];
-                f[1] = sV[j * W14_VPLANE + aoff_lo[ky]];
-                f[2] = s_u[slot * W14_UGRP + ky * (W14_BN * 4) + boff_hi];
-                f[3] = s_u[slot * W14_UGRP + ky * (W14_BN * 4) + boff_lo];
+                read_a(f, sV, j, ky);
+                read_b(f, ky, slot);
             }
         };
-        read_frags(ca, smem, 0, 0, 0);
+        if (W14_B_ACROSS) read_frags(ca, smem, 0, 0, 0);
+        else read_a(ca, smem, 0, 0);
         int g = 0;
         for (int c = 0; c < p.nch; ++c) {
             const f32x4* sV = smem + (c & 1) * W14_VBUF;
             const f32x4* sVn = smem + ((c & 1) ^ 1) * W14_VBUF;
-#pragma unroll
-            for (int j = 0; j < 6; ++j, ++g) {
+            // (six explicit instances, not a loop the optimizer may decline to unroll: acc[] must stay in registers)
+            auto group = [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
                 const int slot = g % 3, slot1 = slot == 2 ? 0 : slot + 1;
 #if OM_W14_TRACE
-                unsigned long long ta, tb, tc, td;
+                unsigned long long ta, tb = 0, tc = 0, td;
                 W14_STAMP(ta);
 #endif
                 // groups g and g + 1 are in LDS; every wave has left group g - 1: its slot takes group g + 2 (requested below),
                 // which has to land by the end of this group
+                if (W14_DMA_AFTER < 0) issue_group(ubase, g + 2);
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     if constexpr (OM_W14_ABLATE & 2048) continue;       // idle consumers: the producers' own speed
+                    if (!W14_B_ACROSS && ky == 0) read_b(ca, 0, slot);       // this group's weights: published by the barrier just passed
                     if (ky < 2) read_frags(na, sV, j, ky + 1, slot);
-                    else if (j < 5) read_frags(na, sV, j + 1, 0, slot1);
-                    else if (c + 1 < p.nch) read_frags(na, sVn, 0, 0, slot1);
+                    else if (W14_B_ACROSS) {
+                        if (j < 5) read_frags(na, sV, j + 1, 0, slot1);
+                        else if (c + 1 < p.nch) read_frags(na, sVn, 0, 0, slot1);
+                    } else {
+                        if (j < 5) read_a(na, sV, j + 1, 0);
+                        else if (c + 1 < p.nch) read_a(na, sVn, 0, 0);
+                    }
                     const f16x8 ah = __builtin_bit_cast(f16x8, ca[0]), al = __builtin_bit_cast(f16x8, ca[1]);
                     const f16x8 bh = __builtin_bit_cast(f16x8, ca[2]), bl = __builtin_bit_cast(f16x8, ca[3]);
                     // weights first: D[i = channel][j = entry]
                     if constexpr (OM_W14_ABLATE & 1024) {       // no matrix instructions: the operands still have to arrive
                         asm volatile("" ::"v"(ah), "v"(al), "v"(bh), "v"(bl));
                     } else {
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[j], 0, 0, 0);
+                        constexpr int pl = w14_plane(j);
+                        acc[pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[pl], 0, 0, 0);
+                        acc[pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[pl], 0, 0, 0);
+                        acc[pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[pl], 0, 0, 0);
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) ca[i] = na[i];
                     // the request (60-200 cycles of issue) behind the first matrix instructions, not in front of them
                     if (ky == W14_DMA_AFTER) {
                         issue_group(ubase, g + 2);
-#if OM_W14_TRACE
-                        W14_STAMP(tb);
-#endif
                     }
                 }
                 // my pieces of weight group g + 2 have landed; my reads of this group's slot and plane are done
-#if OM_W14_TRACE
-                W14_STAMP(tc);
-#endif
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (W14_B_ACROSS || g + 2 >= ngroups) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else if (wave < 4) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");      // all but the pieces requested in this group
+                else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
 #if OM_W14_TRACE
                 W14_STAMP(td);
 #endif
                 if (!(OM_W14_ABLATE & 4)) __builtin_amdgcn_s_barrier();
 #if OM_W14_TRACE
-                W14_SETTLE(ta, tb, tc, td);
-                if ((wave == 0 || wave == 4) && first_tile) w14_trace_put(p, wave >> 2, g, ta, tb, tc, td);
+                W14_SETTLE2(ta, td);
+                if (wave == 0 && first_tile) w14_trace_put(p, 0, g, ta, tb, tc, td);
 #endif
-            }
+                ++g;
+            };
+            group(std::integral_constant<int, 0>{});
+            group(std::integral_constant<int, 1>{});
+            group(std::integral_constant<int, 2>{});
+            group(std::integral_constant<int, 3>{});
+            group(std::integral_constant<int, 4>{});
+            group(std::integral_constant<int, 5>{});
         }
 #if OM_W14_TRACE
         W14_STAMP(pt1);

@@ -20,7 +20,8 @@ def main():
     B = 32
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     tot14 = tot24 = 0.0
-    for hw, cin, cout, n in SHAPES:
+    shapes = SHAPES if not os.environ.get("OM_SHAPES") else [SHAPES[int(i)] for i in os.environ["OM_SHAPES"].split(",")]
+    for hw, cin, cout, n in shapes:
         x = torch.randn(B, hw, hw, cin, device=dev)
         w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
         out = torch.empty(B, hw, hw, cout, device=dev)

@@ -44,12 +44,11 @@ def main():
             t0 = int(t[blk, 0, 6, 0])
             print(" block %d (first tile; groups 6..23; cycles from group 6's start)" % blk)
             for g in range(6, min(24, 6 * (cin // 16))):
-                row = []
-                for s, name in ((0, "c0"), (1, "c4"), (2, "p8")):
-                    a, b, c, d = (int(v) - t0 for v in t[blk, s, g])
-                    row.append("%s a=%6d b=+%4d c=+%4d d=+%4d" % (name, a, b - a, c - a, d - a))
+                a, _, _, d = (int(v) - t0 for v in t[blk, 0, g])
+                pa, _, pc, _ = (int(v) - t0 for v in t[blk, 2, g])
                 nxt = int(t[blk, 0, g + 1, 0]) - int(t[blk, 0, g, 0]) if g + 1 < 6 * (cin // 16) else 0
-                print("  g%2d  %s   | group %5d cycles" % (g, "   ".join(row), nxt))
+                print("  g%2d  consumer 0: start %6d, operands landed +%4d   producer 8: start %6d, work issued +%4d   | group %5d cycles" % (
+                    g, a, d - a, pa, pc - pa, nxt))
             ph = [int(v) for v in t[blk, 0, 60]]
             print("   consumer wave 0, first tile: main loop %d cycles, epilogue (+ next tile's weight requests) %d cycles" % (ph[1] - ph[0], ph[2] - ph[1]))
             pp = [int(v) for v in t[blk, 2, 62]]
