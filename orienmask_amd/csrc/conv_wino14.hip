@@ -76,7 +76,7 @@ struct Wino14Params {
     int* ticket;
     int* status;
     int B, H, W, in_ps, in_bytes;
-    int cout, out_ps, res_ps, leaky, vec_io;
+    int cout, out_ps, res_ps, leaky, fast_io, out_bytes, res_bytes;
     int R, Ct, ncb, gtot;   // block = R padded rows x Ct tile columns; ncb column blocks per row block; gtot = B * (H + 2)
     int n_tiles, total_tiles, nch;      // nch = cin / 16
     int u_bytes;
@@ -118,11 +118,6 @@ __device__ __forceinline__ void wino14_decode(const Wino14Params& p, int tile, W
     t.g0 = rb * p.R; t.t0 = cb * p.Ct; t.n0 = t.tile_n * W14_BN;
 }
 
-// unaligned views or a last channel quad beyond cout: one element at a time (a call, so that the sixteen store sites stay small)
-__device__ __noinline__ void wino14_store_scalar(float* o, const float* rp, f32x4 v, int nvalid) {
-    for (int k = 0; k < 4 && k < nvalid; ++k) o[k] = rp ? v[k] + rp[k] : v[k];
-}
-
 // Epilogue of a consumer wave, from its six plane accumulators, with no workgroup barrier: the inverse transform position by
 // position (A^T rows (1,1,1,1,1,0), (0,1,-1,2,-2,0), (0,1,1,4,4,0), (0,1,-1,8,-8,1)), a transpose of the wave's 32 entries x 32
 // channels through 4 KiB of LDS of its own, then scale / shift, LeakyReLU, residual and 16-byte stores.  In the accumulators a
@@ -131,8 +126,23 @@ __device__ __noinline__ void wino14_store_scalar(float* o, const float* rp, f32x
 // r = 0..3 -- eight lanes complete a 128-byte line -- and needs one scale / shift quad for the whole tile.
 // (The first version staged four fp32 C tiles of the whole workgroup in LDS: two barriers and a store phase of all 768 threads.)
 // sT: this wave's 256 f32x4 of the V buffer that the next tile does not write before its prologue barrier (buffer 1).
+//
+// FAST (16-byte aligned views, cout a multiple of 4, views below 2 GiB): NOTHING in it waits for a store.  Loads and stores
+// retire through one in-order counter (vmcnt), so waiting for any load -- a residual quad, a spilled register -- behind a store
+// waits for that store's round trip: the first version of this function did so sixteen times per tile, 24 000 of a cin = 128
+// tile's 88 000 cycles (profiles/r03_w14_trace_tile_phases.txt).  Here every request is unconditional (an out-of-range offset
+// for entries outside the image: the buffer descriptor drops the store and returns zeros for the load), so the compiler's
+// counts are exact; the residual of position px + 1 is requested BEFORE the stores of position px; no spills, no calls.
+// before_requests(): called once, after the set-up (whose register traffic may wait for everything outstanding) and before the
+// first store: the caller's requests for the next tile's first weight groups go there, so that exactly W14_EPI_OPS<MODE>
+// vector-memory operations follow them.
+template <int MODE> constexpr int W14_EPI_OPS = MODE == 0 ? 16 : MODE == 1 ? 28 : 0;
+template <int MODE, typename F>
 __device__ __forceinline__ void wino14_epilogue(const Wino14Params& p, const f32x16 (&acc)[6], const Wino14Tile& tl, f32x4* sT, int wm,
-                                                int wn, int lane) {
+                                                int wn, int lane, F before_requests) {
+    // everything below is recomputed per tile from an opaque copy of the lane id: hoisted out of the tile loop, the per-lane
+    // entry coordinates would be live across the main loop, i.e. spilled, and reloaded here one round trip at a time
+    asm volatile("" : "+v"(lane));
     const int fi = lane & 31, fk = lane >> 5;
     const int hp2 = p.H + 2;
     const int c8 = lane & 7;
@@ -140,9 +150,8 @@ __device__ __forceinline__ void wino14_epilogue(const Wino14Params& p, const f32
     const int nvalid = p.cout - nb;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + nb);      // padded to cout_pad
     const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + nb);
-    // the four entries this lane stores
-    long long pix0[4];
-    int oxe[4];         // first pixel column of the entry; >= W: nothing to store
+    // the four entries this lane stores: pixel index of the entry's first pixel, and its column (>= W: nothing to store)
+    int pix0[4], oxe[4];
 #pragma unroll
     for (int rd = 0; rd < 4; ++rd) {
         const int ml = 32 * wm + 8 * rd + (lane >> 3);
@@ -150,48 +159,102 @@ __device__ __forceinline__ void wino14_epilogue(const Wino14Params& p, const f32
         const int gg = tl.g0 + r;
         const int b = gg / hp2;
         const int y = gg - b * hp2 - 1;
-        const bool rowok = r < p.R && gg < p.gtot && y >= 0 && y < p.H;
+        const bool rowok = r < p.R && gg < p.gtot && y >= 0 && y < p.H && nvalid > 0;
         oxe[rd] = rowok ? 4 * (tl.t0 + t) : p.W;
-        pix0[rd] = ((long long)b * p.H + y) * p.W + 4 * (tl.t0 + t);
+        pix0[rd] = (b * p.H + y) * p.W + 4 * (tl.t0 + t);
     }
     float nonfinite = 0.f;          // range guard of the split representation (conv_igemm_split.hip: split_epilogue)
-#pragma unroll
-    for (int px = 0; px < 4; ++px) {
+    auto position = [&](int px, int gq, int k) {
+        const int i = 4 * gq + k;
+        if (px == 0) return acc[0][i] + acc[1][i] + acc[2][i] + acc[3][i] + acc[4][i];
+        if (px == 1) return (acc[1][i] - acc[2][i]) + 2.f * (acc[3][i] - acc[4][i]);
+        if (px == 2) return (acc[1][i] + acc[2][i]) + 4.f * (acc[3][i] + acc[4][i]);
+        return (acc[1][i] - acc[2][i]) + 8.f * (acc[3][i] - acc[4][i]) + acc[5][i];
+    };
+    auto transpose_in = [&](int px) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            f32x4 v;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = 4 * gq + k;
-                if (px == 0) v[k] = acc[0][i] + acc[1][i] + acc[2][i] + acc[3][i] + acc[4][i];
-                else if (px == 1) v[k] = (acc[1][i] - acc[2][i]) + 2.f * (acc[3][i] - acc[4][i]);
-                else if (px == 2) v[k] = (acc[1][i] + acc[2][i]) + 4.f * (acc[3][i] + acc[4][i]);
-                else v[k] = (acc[1][i] - acc[2][i]) + 8.f * (acc[3][i] - acc[4][i]) + acc[5][i];
-            }
+            const f32x4 v = {position(px, gq, 0), position(px, gq, 1), position(px, gq, 2), position(px, gq, 3)};
             sT[fi * 8 + ((2 * gq + fk) ^ (fi & 7))] = v;        // row = entry, 16-byte chunk = channel quad, XOR-swizzled
         }
-        // the wave's own LDS operations complete in order: no wait between its writes and its reads, nor before the next
-        // position's writes
+    };
+    // the wave's own LDS operations complete in order: no wait between its writes and its reads, nor before the next
+    // position's writes
+    auto transpose_out = [&](int rd) {
+        const int e = 8 * rd + (lane >> 3);
+        return sT[e * 8 + (c8 ^ (e & 7))];
+    };
+    // entries beyond the block's R rows multiplied whatever the LDS held: they are neither stored nor range-checked
+    auto activate = [&](f32x4 v, bool ok) {
+        float nf = 0.f;
 #pragma unroll
-        for (int rd = 0; rd < 4; ++rd) {
-            const int e = 8 * rd + (lane >> 3);
-            f32x4 v = sT[e * 8 + (c8 ^ (e & 7))];
-            // entries beyond the block's R rows multiplied whatever the LDS held: they are neither stored nor range-checked
-            if (oxe[rd] + px >= p.W || nvalid <= 0) continue;
+        for (int k = 0; k < 4; ++k) {
+            const float tv = fmaf(v[k], sc[k], sh[k]);
+            nf = fmaf(tv, 0.f, nf);
+            v[k] = p.leaky ? fmaxf(tv, tv * 0.1f) : tv;         // LeakyReLU(0.1): the larger of x and 0.1 x
+        }
+        nonfinite += ok ? nf : 0.f;
+        return v;
+    };
+    if constexpr (MODE < 2) {
+        const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+        const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, MODE == 1 ? p.res_bytes : 0, 0x00020000);
+        auto offset = [&](int rd, int px, int ps) { return oxe[rd] + px < p.W ? ((pix0[rd] + px) * ps + nb) * 4 : (int)0x80000000; };
+        f32x4 rc[4];
+        if constexpr (MODE == 1) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float tv = fmaf(v[k], sc[k], sh[k]);
-                nonfinite = fmaf(tv, 0.f, nonfinite);
-                v[k] = p.leaky ? (tv > 0.f ? tv : tv * 0.1f) : tv;
+            for (int rd = 0; rd < 4; ++rd) rc[rd] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, offset(rd, 0, p.res_ps), 0, 0));
+        }
+        before_requests();
+        // Positions in the order 0, 3, 1, 2: plane 0 is dead after the first, plane 5 after the second.  Four explicit copies
+        // separated by compiler barriers: as one unrolled loop the scheduler hoists every residual request to the top (and
+        // spills them), as a rolled loop all six planes stay live and the per-entry offsets spill instead -- and a spilled
+        // register reloaded between two stores waits for the older store's round trip.
+        auto one_position = [&](auto pxc, auto nextc) {
+            constexpr int px = decltype(pxc)::value, nx = decltype(nextc)::value;
+            transpose_in(px);
+            f32x4 v[4];
+#pragma unroll
+            for (int rd = 0; rd < 4; ++rd) {
+                v[rd] = activate(transpose_out(rd), oxe[rd] + px < p.W);
+                if constexpr (MODE == 1) v[rd] += rc[rd];
             }
-            if ((OM_W14_ABLATE & 32) && v[0] != 123.f) continue;
-            float* o = p.out + (pix0[rd] + px) * p.out_ps + nb;
-            const float* rp = p.res ? p.res + (pix0[rd] + px) * p.res_ps + nb : nullptr;
-            if (p.vec_io && nvalid >= 4) {
-                if (rp) v += *reinterpret_cast<const f32x4*>(rp);
-                *reinterpret_cast<f32x4*>(o) = v;
-            } else {
-                wino14_store_scalar(o, rp, v, nvalid);
+            if constexpr (MODE == 1 && nx >= 0) {       // the next position's residual BEFORE this position's stores
+#pragma unroll
+                for (int rd = 0; rd < 4; ++rd)
+                    rc[rd] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, offset(rd, nx, p.res_ps), 0, 0));
+            }
+#pragma unroll
+            for (int rd = 0; rd < 4; ++rd) {
+                if ((OM_W14_ABLATE & 32) && v[rd][0] != 123.f) continue;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v[rd]), rs_out, offset(rd, px, p.out_ps), 0, 0);
+            }
+            asm volatile("" ::: "memory");
+        };
+        using std::integral_constant;
+        one_position(integral_constant<int, 0>{}, integral_constant<int, 3>{});
+        one_position(integral_constant<int, 3>{}, integral_constant<int, 1>{});
+        one_position(integral_constant<int, 1>{}, integral_constant<int, 2>{});
+        one_position(integral_constant<int, 2>{}, integral_constant<int, -1>{});
+    } else {
+        before_requests();
+        // any view, any cout: one element at a time
+#pragma unroll 1
+        for (int px = 0; px < 4; ++px) {
+            if (px == 0) transpose_in(0);
+            else if (px == 1) transpose_in(1);
+            else if (px == 2) transpose_in(2);
+            else transpose_in(3);
+#pragma unroll 1
+            for (int rd = 0; rd < 4; ++rd) {
+                const int ox = rd == 0 ? oxe[0] : rd == 1 ? oxe[1] : rd == 2 ? oxe[2] : oxe[3];
+                const int px0 = rd == 0 ? pix0[0] : rd == 1 ? pix0[1] : rd == 2 ? pix0[2] : pix0[3];
+                const bool ok = ox + px < p.W;
+                const f32x4 v = activate(transpose_out(rd), ok);
+                if (!ok) continue;
+                float* o = p.out + (long long)(px0 + px) * p.out_ps + nb;
+                const float* rp = p.res ? p.res + (long long)(px0 + px) * p.res_ps + nb : nullptr;
+                for (int k = 0; k < 4 && k < nvalid; ++k) o[k] = rp ? v[k] + rp[k] : v[k];
             }
         }
     }
@@ -212,6 +275,8 @@ __device__ __forceinline__ void wino14_epilogue(const Wino14Params& p, const f32
 // barrier), so no barrier separates two tiles; the producers request the next tile's first chunk during the LAST chunk of this
 // one (their input registers are free then) and transform it while the consumers -- who first request the next tile's first
 // two weight groups -- run their epilogue.
+// MODE: the epilogue's form -- 0 buffer-descriptor stores, no residual; 1 the same with a residual; 2 any view, any cout
+template <int MODE>
 __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino14Params p) {
     __shared__ f32x4 smem[2 * W14_VBUF + 3 * W14_UGRP + 1];      // ONE LDS object (conv_igemm.hip); last 16 B: two ticket words
     int* const s_ticket = reinterpret_cast<int*>(smem + 2 * W14_VBUF + 3 * W14_UGRP);
@@ -266,6 +331,7 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
     int tslot = 0;                      // s_ticket[tslot] is this tile's ticket, s_ticket[tslot ^ 1] takes the next one
 #if OM_W14_TRACE
     bool first_tile = true;
+    int n_traced = 0;
 #endif
 
     if (wave >= 8) {
@@ -532,6 +598,7 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
         }
     };
     Wino14Tile tl;
+    bool first_of_wg = true;
     if (tile < p.total_tiles) {
         wino14_decode(p, tile, tl);
         const int ubase = tl.tile_n * p.nch * 6 * (W14_UGRP * 16);
@@ -545,7 +612,11 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
         for (int j = 0; j < 6; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // weight groups 0 and 1 have landed: they were requested before the previous tile's epilogue stores, which need not have
+        // (the counter retires in order; the very first tile has nothing behind its requests)
+        if ((OM_W14_ABLATE & 32) || W14_EPI_OPS<MODE> == 0 || first_of_wg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W14_EPI_OPS<MODE>) : "memory");
+        first_of_wg = false;
         __builtin_amdgcn_s_barrier();           // prologue: chunk 0 (producers), weight groups 0, 1 and the next ticket are in LDS
         const int next_tile = __builtin_amdgcn_readfirstlane(s_ticket[tslot ^ 1]);
 #if OM_W14_TRACE
@@ -646,17 +717,20 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
         // every operand in LDS is dead (the last group's barrier has passed): the next tile's first two weight groups are
         // requested before the epilogue, its first chunk is being transformed by the producers meanwhile
         Wino14Tile tn = tl;
-        if (next_tile < p.total_tiles) {
-            wino14_decode(p, next_tile, tn);
-            const int ub = tn.tile_n * p.nch * 6 * (W14_UGRP * 16);
-            issue_group(ub, 0);
-            issue_group(ub, 1);
-        }
-        wino14_epilogue(p, acc, tl, smem + W14_VBUF + wave * 256, wm, wn, lane);
+        if (next_tile < p.total_tiles) wino14_decode(p, next_tile, tn);
+        wino14_epilogue<MODE>(p, acc, tl, smem + W14_VBUF + wave * 256, wm, wn, lane, [&]() {
+            if (next_tile < p.total_tiles) {
+                const int ub = tn.tile_n * p.nch * 6 * (W14_UGRP * 16);
+                issue_group(ub, 0);
+                issue_group(ub, 1);
+            }
+        });
 #if OM_W14_TRACE
         W14_STAMP(pt2);
         W14_SETTLE(pt0, pt1, pt2, pt3);
         if (wave == 0 && first_tile) w14_trace_put(p, 0, 60, pt0, pt1, pt2, pt3);
+        if (wave == 0 && n_traced < 8) w14_trace_put(p, 1, 48 + n_traced, pt0, pt1, pt2, pt3);      // phases of this workgroup's first eight tiles
+        ++n_traced;
         first_tile = false;
 #endif
         tl = tn;
@@ -703,9 +777,17 @@ int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream) {
     p.ticket = a.ticket; p.status = a.status;
     p.B = a.B; p.H = a.H; p.W = a.W; p.in_ps = a.in_pix_stride; p.in_bytes = (int)in_bytes;
     p.cout = a.cout; p.out_ps = a.out_pix_stride; p.res_ps = a.res_pix_stride; p.leaky = a.leaky;
-    p.vec_io = (a.out_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
-                (!a.res || (a.res_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)))
-                   ? 1 : 0;
+    // the epilogue's buffer-descriptor form: 16-byte aligned views below 2 GiB, whole channel quads
+    const long long npix = (long long)a.B * a.H * a.W;
+    const long long out_bytes = ((npix - 1) * a.out_pix_stride + a.cout) * 4;
+    const long long res_bytes = a.res ? ((npix - 1) * a.res_pix_stride + a.cout) * 4 : 0;
+    p.fast_io = (a.cout % 4 == 0 && a.out_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+                 (!a.res || (a.res_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)) &&
+                 out_bytes < 0x7FFFFFF0ll && res_bytes < 0x7FFFFFF0ll)
+                    ? 1 : 0;
+    p.out_bytes = p.fast_io ? (int)out_bytes : 0;
+    p.res_bytes = p.fast_io ? (int)res_bytes : 0;
+    OM_REQUIRE(npix < (1ll << 31), OM_EINVAL, "wino14: %lld pixels out of range", npix);
     int R = 0, Ct = 0, ncb = 0, nrb = 0;
     wino14_geometry(a.B, a.H, a.W, &R, &Ct, &ncb, &nrb);
     OM_REQUIRE(R >= 1 && Ct >= 1, OM_EINVAL, "wino14: no block shape for %d x %d", a.H, a.W);
@@ -723,7 +805,9 @@ int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream) {
     OM_REQUIRE(p.trace, OM_EINVAL, "wino14 trace build: om_debug_w14_trace() first");
 #endif
     const long long grid = total < 256 ? total : 256;        // one 768-thread workgroup per CU (156 KiB of LDS)
-    hipLaunchKernelGGL(wino14_split_kernel, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);
+    if (!p.fast_io) hipLaunchKernelGGL(wino14_split_kernel<2>, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);
+    else if (a.res) hipLaunchKernelGGL(wino14_split_kernel<1>, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);
+    else hipLaunchKernelGGL(wino14_split_kernel<0>, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }

@@ -51,6 +51,14 @@ def main():
                     g, a, d - a, pa, pc - pa, nxt))
             ph = [int(v) for v in t[blk, 0, 60]]
             print("   consumer wave 0, first tile: main loop %d cycles, epilogue (+ next tile's weight requests) %d cycles" % (ph[1] - ph[0], ph[2] - ph[1]))
+            prev_end = None
+            for i in range(8):
+                q = [int(v) for v in t[blk, 1, 48 + i]]
+                if q[0] == 0:
+                    break
+                gap = "" if prev_end is None else "  (epilogue end -> this loop's start: %d)" % (q[0] - prev_end)
+                print("   tile %d of this workgroup: main loop %6d, epilogue %6d%s" % (i, q[1] - q[0], q[2] - q[1], gap))
+                prev_end = q[2]
             pp = [int(v) for v in t[blk, 2, 62]]
             print("   producer wave 8, a later tile: prologue (ticket, chunk 0 landed + transformed, chunk 1 requested) %d cycles" % (pp[1] - pp[0]))
             break
