@@ -21,6 +21,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int STEM_TX = 32, STEM_TY = 8, STEM_CO = 32;
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4s __attribute__((__vector_size__(4 * sizeof(unsigned))));
+typedef unsigned u32x2s __attribute__((__vector_size__(2 * sizeof(unsigned))));
 
 constexpr int STEM_STRIPS = 8;      // 8-row strips one workgroup walks down (weights and scale/shift loaded once)
 constexpr int STEM_PATCH = 3 * (STEM_TY + 2) * (STEM_TX + 2);
@@ -37,6 +39,12 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * STEM_TX, b = blockIdx.z;
     const float* img = in + (size_t)b * 3 * H * W;
+    // Every request goes through a buffer descriptor of THIS image's planes / output rows with an out-of-range offset where the
+    // pixel does not exist (zeros for the padding, dropped stores), not through a branch: loads and stores retire through one
+    // in-order counter, and with conditional requests the compiler's wait for the next strip's patch was vmcnt(0) -- every strip
+    // waited for the round trip of the previous strip's eight stores (conv_wino14.hip's epilogue).
+    const auto rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, 3 * H * W * 4, 0x00020000);
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * H * W * STEM_CO, 0, H * W * STEM_CO * (int)sizeof(OutT), 0x00020000);
     // the next strip's patch elements travel through registers while the current strip computes
     float stage[STEM_LD];
     auto fetch = [&](int y0) {
@@ -47,9 +55,8 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
             const int r = e - c * (STEM_TY + 2) * (STEM_TX + 2);
             const int py = r / (STEM_TX + 2), px = r - py * (STEM_TX + 2);
             const int gy = y0 + py - 1, gx = x0 + px - 1;
-            float v = 0.f;
-            if (e < STEM_PATCH && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = img[((size_t)c * H + gy) * W + gx];
-            stage[i] = v;
+            const bool ok = e < STEM_PATCH && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            stage[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_img, ok ? ((c * H + gy) * W + gx) * 4 : (int)0x80000000, 0, 0));
         }
     };
     auto commit = [&]() {
@@ -73,13 +80,18 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
     }
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + quad * 4);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + quad * 4);
+    // the weights and scale / shift have arrived BEFORE the loop as far as the compiler's wait bookkeeping is concerned: pending at
+    // the loop's entry, they made the first use inside it `vmcnt(0)` in every iteration -- a wait for the patch requested a moment ago
+#pragma unroll
+    for (int t = 0; t < 27; ++t) asm volatile("" ::"v"(wr[t]));
+    asm volatile("" ::"v"(sc), "v"(sh));
     for (int si = 0; si < STEM_STRIPS; ++si) {
         const int y0 = (strip0 + si) * STEM_TY;
         if (y0 >= H) break;
         commit();
         __syncthreads();
         if (si + 1 < STEM_STRIPS && y0 + STEM_TY < H) fetch(y0 + STEM_TY);
-#pragma unroll 2
+#pragma unroll      // all eight rows: the stores behind the next strip's requests are then counted exactly (vmcnt(8 + ...))
         for (int ty = 0; ty < STEM_TY; ++ty) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -102,14 +114,12 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
                 o[k] = v > 0.f ? v : v * 0.1f;
             }
             const int gy = y0 + ty, gx = x0 + px;
-            if (gy < H && gx < W) {
-                OutT* dst = out + (((size_t)b * H + gy) * W + gx) * STEM_CO + quad * 4;
-                if constexpr (sizeof(OutT) == 4) {
-                    *reinterpret_cast<f32x4*>(dst) = o;
-                } else {
-                    const f16x4 h = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
-                    *reinterpret_cast<f16x4*>(dst) = h;
-                }
+            const int off = gy < H && gx < W ? ((gy * W + gx) * STEM_CO + quad * 4) * (int)sizeof(OutT) : (int)0x80000000;
+            if constexpr (sizeof(OutT) == 4) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, o), rs_out, off, 0, 0);
+            } else {
+                const f16x4 h = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2s, h), rs_out, off, 0, 0);
             }
         }
         __syncthreads();      // everyone is done with the patch before the next strip overwrites it
@@ -135,6 +145,7 @@ int launch_conv_stem(const float* in_nchw, int B, int H, int W, const float* w, 
     OM_REQUIRE(in_nchw && w && scale && shift && out_nhwc, OM_EINVAL, "stem: null pointer");
     OM_REQUIRE(cout == STEM_CO, OM_EINVAL, "stem: cout=%d, only 32 supported", cout);
     OM_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0, OM_EINVAL, "stem: bad shape B=%d H=%d W=%d", B, H, W);
+    OM_REQUIRE((long long)H * W * STEM_CO * 4 < 0x7FFFFFF0ll, OM_EINVAL, "stem: an image of %d x %d exceeds a buffer descriptor", H, W);
     dim3 grid((W + STEM_TX - 1) / STEM_TX, (H + STEM_TY * STEM_STRIPS - 1) / (STEM_TY * STEM_STRIPS), B);
     hipLaunchKernelGGL(conv_stem_kernel<float>, grid, dim3(256), 0, stream, in_nchw, w, scale, shift, out_nhwc, H, W);
     OM_CHECK_HIP(hipGetLastError());
@@ -146,6 +157,7 @@ int launch_conv_stem_f16(const float* in_nchw, int B, int H, int W, const float*
     OM_REQUIRE(in_nchw && w && scale && shift && out_nhwc_f16, OM_EINVAL, "stem: null pointer");
     OM_REQUIRE(cout == STEM_CO, OM_EINVAL, "stem: cout=%d, only 32 supported", cout);
     OM_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0, OM_EINVAL, "stem: bad shape B=%d H=%d W=%d", B, H, W);
+    OM_REQUIRE((long long)H * W * STEM_CO * 4 < 0x7FFFFFF0ll, OM_EINVAL, "stem: an image of %d x %d exceeds a buffer descriptor", H, W);
     dim3 grid((W + STEM_TX - 1) / STEM_TX, (H + STEM_TY * STEM_STRIPS - 1) / (STEM_TY * STEM_STRIPS), B);
     hipLaunchKernelGGL(conv_stem_kernel<_Float16>, grid, dim3(256), 0, stream, in_nchw, w, scale, shift,
                        static_cast<_Float16*>(out_nhwc_f16), H, W);

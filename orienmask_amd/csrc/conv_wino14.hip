@@ -9,20 +9,23 @@
 // Same layer as conv_wino24.hip (Conv2d 3x3 s1 p1 -> BatchNorm2d(eval) -> LeakyReLU(0.1) (+ residual),
 // /root/reference/model/base.py:104-137, model/backbone/darknet.py:14-15) and the same F(4,3) matrices as its column transform.
 //
-// Why this form (MI355X, measured in round 3: profiles/r03_*): with the two-kernel F(2x4) form the transformed input (3x the
-// activation) is written and read through HBM -- 53 of the forward's 83 GB per step -- and the forward as a whole moves 4.6 TB/s,
-// i.e. it is bound by that traffic, not by the matrix pipe (20 % busy).  Keeping V on chip needs the accumulators of ALL planes of
+// Why this form (MI355X, measured in round 3: profiles/r03_experiments.md): with the two-kernel F(2x4) form the
+// transformed input (3x the activation) is written and read through HBM -- 53 of the forward's 83 GB per step.  Keeping V on chip needs the accumulators of ALL planes of
 // a tile resident while the channel chunks stream by (the transform of a chunk yields every plane at once): 24 planes x 16
 // registers for F(2x4) leaves room for one 32x32 tile per SIMD; F(4,3) along the rows only has SIX planes -- 96 registers per
 // 32x32 wave tile, eight waves per workgroup, a 128 x 64 tile per CU -- at 4.5 instead of 3 matrix products per output, which the
 // idle matrix pipe has room for.  Per 16-channel chunk a workgroup
 //   * (four producer waves) loads the (R + 2) x (4 Ct + 2) input pixels of its R x Ct block of 1x4 output tiles straight into
-//     registers (one chunk ahead), applies B^T (14 vector operations per 6 planes), splits into hi/lo fp16 and writes
-//     V_j[row][t] as 64-byte LDS entries [8 hi | 8 hi | 8 lo | 8 lo];
+//     registers (one chunk ahead), applies B^T, splits into hi/lo fp16 and writes V_j[row][t] as 64-byte LDS entries
+//     [8 hi | 8 hi | 8 lo | 8 lo] -- 2 1/2 planes per group of matrix work (see the schedule at `chunk` below);
 //   * (eight consumer waves) runs 18 (ky, j) steps of three v_mfma_f32_32x32x16_f16 per wave: the A fragment of tap ky is the SAME LDS plane read Ct
 //     entries further on (row oy + ky of the block: conv3x3_f16.hip's shared patch, one dimension up), so V is stored once for
 //     the three kernel rows; zero padding is zero ENTRIES (rows / columns outside the image are written as zeros), no masks;
-//   * streams U through a three-slot LDS-DMA ring of (j; ky = 0..2) groups, 12 KiB each, contiguous in the packed blob.
+//   * streams U through a three-slot LDS-DMA ring of (j; ky = 0..2) groups, 12 KiB each, contiguous in the packed blob; a
+//     group's first weight fragments are read AFTER the barrier that starts the group, so a group requested in group g is not
+//     needed before group g + 2 (two groups to land: the landing time of this stream is the consumers' critical path).
+// What binds the kernel is the CU's vector-memory request path (L1 pending-request stalls 41 % of the time: 72 KB of weights and
+// 61 KB of input per chunk of a 128 x 64 tile against ~20 B/clk of ingest), not HBM, the matrix pipe (27 % busy) or the producers.
 // Tiles are blocks of the PADDED row space G = b (H + 2) + y + 1 (one zero row above and below every image), so a block may
 // span images (17 x 17 layers) and the row shift ky needs no per-lane case.  The inverse transform runs once per tile, in the
 // epilogue, position by position from the six plane accumulators.
@@ -55,6 +58,9 @@ constexpr int W14_EMAX = 160;                 // LDS entries per plane: (R + 2) 
 constexpr int W14_VPLANE = W14_EMAX * 4;      // f32x4 units (16 B) per plane
 constexpr int W14_VBUF = 6 * W14_VPLANE;      // one transformed chunk: 61440 B
 constexpr int W14_UGRP = 3 * W14_BN * 4;      // one (j; ky = 0..2) weight group: 12288 B
+#ifndef W14_SPREAD
+#define W14_SPREAD 1           // 1: planes (0, 5) first, so that pixels 0 and 5 of a quad item can be requested a group earlier
+#endif                         //    and no group carries more than four requests; 0: planes (1, 2), (3, 4), (0, 5), six per load group
 #ifndef W14_QUEUE
 #define W14_QUEUE 0            // per-XCD tile queues: 0 = M blocks partitioned (N-tile siblings share the input behind one L2),
 #endif                         // 1 = N tiles partitioned (an XCD streams one or two N tiles' weights: they stay in its L2)
@@ -104,7 +110,9 @@ __device__ __forceinline__ void w14_trace_put(const Wino14Params& p, int slot, i
 
 // Order in which the six planes (transform points) of a chunk are multiplied: group g of a chunk works on plane w14_plane(g) of V
 // and of U.  Pairs (1, 2), (3, 4), (0, 5): what the producers make in one group from shared differences of the same pixels.
-__host__ __device__ constexpr int w14_plane(int g) { return g == 0 ? 1 : g == 1 ? 2 : g == 2 ? 3 : g == 3 ? 4 : g == 4 ? 0 : 5; }
+__host__ __device__ constexpr int w14_plane(int g) {
+    return W14_SPREAD ? (g == 0 ? 0 : g == 1 ? 5 : g - 1) : (g == 0 ? 1 : g == 1 ? 2 : g == 2 ? 3 : g == 3 ? 4 : g == 4 ? 0 : 5);
+}
 
 struct Wino14Tile {
     int g0, t0, n0, tile_n;
@@ -382,17 +390,22 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
             if (OM_W14_ABLATE & 512) off = lane * 16 + (k * 6 + x) * 1024;      // measurement: every request hits the same 18 KiB
             return off;
         };
-        auto load_quad = [&](int k, int c) {
-            if (OM_W14_ABLATE & 16) return;
-#pragma unroll
-            for (int x = 0; x < 6; ++x) xq[k][x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, item_offset(k, x, c), 0, 0));
-        };
-        auto load_pair = [&](auto buf, int c) {
+        // pixels [x0, x1) of an item
+        auto load_quad_px = [&](int k, int c, int x0, int x1) {
             if (OM_W14_ABLATE & 16) return;
 #pragma unroll
             for (int x = 0; x < 6; ++x)
-                xp[decltype(buf)::value][x] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, item_offset(2, x, c), 0, 0));
+                if (x >= x0 && x < x1) xq[k][x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, item_offset(k, x, c), 0, 0));
         };
+        auto load_quad = [&](int k, int c) { load_quad_px(k, c, 0, 6); };
+        auto load_pair_px = [&](auto buf, int c, int x0, int x1) {
+            if (OM_W14_ABLATE & 16) return;
+#pragma unroll
+            for (int x = 0; x < 6; ++x)
+                if (x >= x0 && x < x1)
+                    xp[decltype(buf)::value][x] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, item_offset(2, x, c), 0, 0));
+        };
+        auto load_pair = [&](auto buf, int c) { load_pair_px(buf, c, 0, 6); };
         // hi/lo split of one transformed value per channel and its LDS stores (hi: RNE fp16 of x; lo: RNE fp16 of x - hi, the
         // difference exact in one v_fma_mix_f32 per element -- the fp16 operand is widened by the instruction)
         auto split_store4 = [&](const f32x4& v, char* dst, int lo_off) {
@@ -508,14 +521,23 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
                     W14_STAMP(ta);
 #endif
                     if constexpr (FORM < 2) {
-                        if constexpr (FORM == 0) {
+                        if constexpr (FORM == 0 && !W14_SPREAD) {
                             if (g == 0) load_pair(std::integral_constant<int, PAR>{}, c + 2);
                         }
                         quad_planes(g / 3, PAR ^ 1, 2 * (g % 3));
                         pair_plane(std::integral_constant<int, PAR ^ 1>{}, PAR ^ 1, g);
-                        if constexpr (FORM == 0) {
+                        if constexpr (FORM == 0 && !W14_SPREAD) {
                             if (g == 2) load_quad(0, c + 2);
                             if (g == 5) load_quad(1, c + 2);
+                        }
+                        if constexpr (FORM == 0 && W14_SPREAD) {
+                            // planes (0, 5) come first: only they read pixels 0 and 5, whose registers are free after the
+                            // item's first group (2 requests); pixels 1..4 after its last (4); the pair item's free set in
+                            // two threes: 2, 3, 4, 2, 3, 4 requests per group
+                            if (g == 0 || g == 3) { load_quad_px(g / 3, c + 2, 0, 1); load_quad_px(g / 3, c + 2, 5, 6); }
+                            if (g == 2 || g == 5) load_quad_px(g / 3, c + 2, 1, 5);
+                            if (g == 1) load_pair_px(std::integral_constant<int, PAR>{}, c + 2, 0, 3);
+                            if (g == 4) load_pair_px(std::integral_constant<int, PAR>{}, c + 2, 3, 6);
                         }
                     } else {
                         if (next_tile < p.total_tiles) {
