@@ -102,7 +102,7 @@ extern "C" void om_debug_w14_trace(void* buf) { g_w14_trace = static_cast<unsign
 __device__ __forceinline__ void w14_trace_put(const Wino14Params& p, int slot, int g, unsigned long long a, unsigned long long b,
                                               unsigned long long c, unsigned long long d) {
     if (blockIdx.x < 8 && g < 64 && (threadIdx.x & 63) == 0) {
-        unsigned long long* t = p.trace + ((blockIdx.x * 3 + slot) * 64 + g) * 4;
+        unsigned long long* t = p.trace + ((blockIdx.x * 12 + slot) * 64 + g) * 4;
         t[0] = a; t[1] = b; t[2] = c; t[3] = d;
     }
 }
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
                     if (!(OM_W14_ABLATE & 4)) __builtin_amdgcn_s_barrier();
 #if OM_W14_TRACE
                     W14_SETTLE2(ta, tc);
-                    if (wave == 8 && first_tile) w14_trace_put(p, 2, c * 6 + g, ta, tb, tc, td);
+                    if (first_tile) w14_trace_put(p, wave, c * 6 + g, ta, tb, tc, td);
 #endif
                 }
             };
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
             }
 #if OM_W14_TRACE
             W14_SETTLE(pp0, pp1, pp2, pp3);
-            if (wave == 8 && !first_tile && pp3 == 0) w14_trace_put(p, 2, 62, pp0, pp1, pp2, pp3);      // a steady-state prologue
+            if (wave == 8 && !first_tile && pp3 == 0) w14_trace_put(p, 8, 62, pp0, pp1, pp2, pp3);      // a steady-state prologue
             first_tile = false;
 #endif
             tile = next_tile;
@@ -667,10 +667,23 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
         };
         if (W14_B_ACROSS) read_frags(ca, smem, 0, 0, 0);
         else read_a(ca, smem, 0, 0);
+        // weights first: D[i = channel][j = entry]
+        auto mma = [&](const f32x4(&f)[4], auto plc) {
+            constexpr int pl = decltype(plc)::value;
+            const f16x8 ah = __builtin_bit_cast(f16x8, f[0]), al = __builtin_bit_cast(f16x8, f[1]);
+            const f16x8 bh = __builtin_bit_cast(f16x8, f[2]), bl = __builtin_bit_cast(f16x8, f[3]);
+            if constexpr (OM_W14_ABLATE & 1024) {
+                asm volatile("" ::"v"(ah), "v"(al), "v"(bh), "v"(bl));
+            } else {
+                acc[pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[pl], 0, 0, 0);
+                acc[pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[pl], 0, 0, 0);
+                acc[pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[pl], 0, 0, 0);
+            }
+        };
         int g = 0;
         for (int c = 0; c < p.nch; ++c) {
             const f32x4* sV = smem + (c & 1) * W14_VBUF;
-            const f32x4* sVn = smem + ((c & 1) ^ 1) * W14_VBUF;
+            [[maybe_unused]] const f32x4* sVn = smem + ((c & 1) ^ 1) * W14_VBUF;
             // (six explicit instances, not a loop the optimizer may decline to unroll: acc[] must stay in registers)
             auto group = [&](auto jc) {
                 constexpr int j = decltype(jc)::value;
@@ -694,17 +707,7 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
                         if (j < 5) read_a(na, sV, j + 1, 0);
                         else if (c + 1 < p.nch) read_a(na, sVn, 0, 0);
                     }
-                    const f16x8 ah = __builtin_bit_cast(f16x8, ca[0]), al = __builtin_bit_cast(f16x8, ca[1]);
-                    const f16x8 bh = __builtin_bit_cast(f16x8, ca[2]), bl = __builtin_bit_cast(f16x8, ca[3]);
-                    // weights first: D[i = channel][j = entry]
-                    if constexpr (OM_W14_ABLATE & 1024) {       // no matrix instructions: the operands still have to arrive
-                        asm volatile("" ::"v"(ah), "v"(al), "v"(bh), "v"(bl));
-                    } else {
-                        constexpr int pl = w14_plane(j);
-                        acc[pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc[pl], 0, 0, 0);
-                        acc[pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc[pl], 0, 0, 0);
-                        acc[pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc[pl], 0, 0, 0);
-                    }
+                    mma(ca, std::integral_constant<int, w14_plane(j)>{});
 #pragma unroll
                     for (int i = 0; i < 4; ++i) ca[i] = na[i];
                     // the request (60-200 cycles of issue) behind the first matrix instructions, not in front of them
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
                 if (!(OM_W14_ABLATE & 4)) __builtin_amdgcn_s_barrier();
 #if OM_W14_TRACE
                 W14_SETTLE2(ta, td);
-                if (wave == 0 && first_tile) w14_trace_put(p, 0, g, ta, tb, tc, td);
+                if (first_tile) w14_trace_put(p, wave, g, ta, tb, tc, td);
 #endif
                 ++g;
             };
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
         W14_STAMP(pt2);
         W14_SETTLE(pt0, pt1, pt2, pt3);
         if (wave == 0 && first_tile) w14_trace_put(p, 0, 60, pt0, pt1, pt2, pt3);
-        if (wave == 0 && n_traced < 8) w14_trace_put(p, 1, 48 + n_traced, pt0, pt1, pt2, pt3);      // phases of this workgroup's first eight tiles
+        if (wave == 1 && n_traced < 8) w14_trace_put(p, 1, 48 + n_traced, pt0, pt1, pt2, pt3);      // phases of this workgroup's first eight tiles
         ++n_traced;
         first_tile = false;
 #endif

@@ -29,26 +29,26 @@ def main():
         u14, e14 = winograd14_weights_split(w, cout)
         s14 = torch.pow(torch.tensor(2.0), -e14.float()).to(dev)
         u14 = u14.to(dev)
-        trace = torch.zeros(8 * 3 * 64 * 4, dtype=torch.int64, device=dev)
+        trace = torch.zeros(8 * 12 * 64 * 4, dtype=torch.int64, device=dev)
         raw.om_debug_w14_trace(p(trace))
         st = omlib.current_stream_ptr(dev)
         for _ in range(3):
             trace.zero_()
             omlib.check(L.om_conv2d_wino14_split(p(x), B, hw, hw, cin, cin, p(u14), p(s14), p(hd), cout, 1, None, 0, p(out), cout, None, st), "w14")
         torch.cuda.synchronize()
-        t = trace.cpu().view(8, 3, 64, 4)
+        t = trace.cpu().view(8, 12, 64, 4)
         print("== %dx%d %d->%d" % (hw, hw, cin, cout))
         for blk in range(8):
             if t[blk, 0, 6, 0] == 0:
                 continue
             t0 = int(t[blk, 0, 6, 0])
             print(" block %d (first tile; groups 6..23; cycles from group 6's start)" % blk)
+            print("  per group: cycles from the group's start (consumer wave 0) at which each wave reached the barrier -- consumers 0-7: operands landed; producers 8-11: work issued")
             for g in range(6, min(24, 6 * (cin // 16))):
-                a, _, _, d = (int(v) - t0 for v in t[blk, 0, g])
-                pa, _, pc, _ = (int(v) - t0 for v in t[blk, 2, g])
-                nxt = int(t[blk, 0, g + 1, 0]) - int(t[blk, 0, g, 0]) if g + 1 < 6 * (cin // 16) else 0
-                print("  g%2d  consumer 0: start %6d, operands landed +%4d   producer 8: start %6d, work issued +%4d   | group %5d cycles" % (
-                    g, a, d - a, pa, pc - pa, nxt))
+                a0 = int(t[blk, 0, g, 0])
+                arr = [int(t[blk, w, g, 3 if w < 8 else 2]) - a0 for w in range(12)]
+                nxt = int(t[blk, 0, g + 1, 0]) - a0 if g + 1 < 6 * (cin // 16) else 0
+                print("  g%2d  %s  | group %5d" % (g, " ".join("%5d" % v for v in arr), nxt))
             ph = [int(v) for v in t[blk, 0, 60]]
             print("   consumer wave 0, first tile: main loop %d cycles, epilogue (+ next tile's weight requests) %d cycles" % (ph[1] - ph[0], ph[2] - ph[1]))
             prev_end = None
@@ -59,7 +59,7 @@ def main():
                 gap = "" if prev_end is None else "  (epilogue end -> this loop's start: %d)" % (q[0] - prev_end)
                 print("   tile %d of this workgroup: main loop %6d, epilogue %6d%s" % (i, q[1] - q[0], q[2] - q[1], gap))
                 prev_end = q[2]
-            pp = [int(v) for v in t[blk, 2, 62]]
+            pp = [int(v) for v in t[blk, 8, 62]]
             print("   producer wave 8, a later tile: prologue (ticket, chunk 0 landed + transformed, chunk 1 requested) %d cycles" % (pp[1] - pp[0]))
             break
 
