@@ -507,10 +507,16 @@ def main():
                         note=("fp16 operands, fp32 accumulate on v_mfma_f32_32x32x16_f16 (dense peak 2.5 PFLOP/s); direct "
                               "convolution, executed = algorithmic") if f16 else
                              ("achieved = flops the fp16 matrix pipe executed (split operands: three v_mfma_f32_32x32x16_f16 per "
+                              "product group; the fused kernel's F(4,3) along the rows multiplies 4.5 of the direct convolution's 9 "
+                              "products per output, so executed = 3 x 1/2 of the direct-convolution flops; the input transform is "
+                              "inside the kernel, there is no pre-pass) over the kernel's time, against the dense fp16 peak.  The "
+                              "matrix pipe's minimum time for these launches (executed flops / 2.5 PFLOP/s) and HBM's (algorithmic "
+                              "bytes / 8 TB/s) are both ~1/6 of the measured time: what binds is the CU's vector-memory request path "
+                              "(DESIGN.md 3.6, profiles/r03_pmc_wino14_*.txt); `hbm` holds the memory-side view of the same launches")
+                             if split and dom.startswith("wino14") else
+                             ("achieved = flops the fp16 matrix pipe executed (split operands: three v_mfma_f32_32x32x16_f16 per "
                               "product group, i.e. 3 x 1/3 of the direct-convolution flops for Winograd F(2x4,3x3)) over the time of "
-                              "the GEMM kernel AND its input-transform pre-pass, against the dense fp16 peak.  The matrix pipe's "
-                              "minimum time for this kernel (executed flops / 2.5 PFLOP/s) and HBM's (algorithmic bytes / 8 TB/s) are "
-                              "within 5 % of each other; `hbm` holds the memory-side view of the same launches") if split else
+                              "the GEMM kernel AND its input-transform pre-pass, against the dense fp16 peak") if split else
                              ("achieved = flops the f32 matrix pipe executed (exact fp32 MFMA; Winograd F(2x4,3x3) runs 1/3 of the "
                               "direct-convolution multiplies) over the time of the GEMM kernel AND its input-transform pre-pass; "
                               "achieved_algorithmic counts direct-convolution flops over the same time"),
@@ -525,8 +531,10 @@ def main():
                         binding=("fp16: matrix pipe and HBM are within 2x of each other (SURVEY.md 8d); forward_hbm_frac is the "
                                  "north_star's HBM-roofline figure") if f16 else
                                 ("split operands: 5.3x the fp32 matrix rate, so the forward's matrix-pipe minimum (executed flops / "
-                                 "2.5 PFLOP/s) and its HBM minimum (algorithmic bytes / 8 TB/s) are of the same size; the measured "
-                                 "HBM traffic (conv_stack_hbm_pmc) is the binding resource") if split else
+                                 "2.5 PFLOP/s) and its HBM minimum (algorithmic bytes / 8 TB/s) are of the same size; since round 3 the "
+                                 "transformed input of the 3x3 layers stays on chip and the measured HBM traffic (conv_stack_hbm_pmc) is "
+                                 "~1.3x the algorithmic bytes: the 3x3 kernel is bound by the CU's outstanding-request limit, the 1x1 "
+                                 "layers at 136^2 / 68^2 by HBM") if split else
                                 "fp32 FLOPs on the f32-input matrix cores; the HBM bound is several x further away")
         if split:
             roofline["hbm"] = dict(bound="hbm", unit="GB/s", peak=PEAK_HBM_GBS,
@@ -534,10 +542,9 @@ def main():
                                    frac=round(d["bytes"] / (dom_timed_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                                    traffic_gbs=round(traffic * d["launches"] / (dom_timed_ms * 1e-3) / 1e9, 1) if traffic else None,
                                    traffic_frac=round(traffic * d["launches"] / (dom_timed_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if traffic else None,
-                                   note="the same launches (GEMM + pre-pass) against HBM: achieved = algorithmic bytes per launch "
-                                        "(layer input, output, residual and weights once) / time; traffic_* = the PMC bytes "
-                                        "(`traffic`) / time -- the transformed input is written and read through HBM, which is "
-                                        "what the algorithmic figure does not contain")
+                                   note="the same launches against HBM: achieved = algorithmic bytes per launch (layer input, output, "
+                                        "residual and weights once) / time; traffic_* = the PMC bytes (`traffic`) / time (round 2's "
+                                        "two-kernel form moved the transformed input through HBM: 4.26x the algorithmic bytes)")
         if args.layers:
             for name, ms, pre in layer_ms:
                 wk = arch.layer_work(specs[name], B, H, W)

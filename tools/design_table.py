@@ -1,19 +1,22 @@
 """Regenerate the table of DESIGN.md section 5.0 from the committed bench lines under profiles/ (between the markers
-<!-- table5.0 --> and <!-- /table5.0 -->).  usage: python tools/design_table.py [round tag, default r02]"""
+<!-- table5.0 --> and <!-- /table5.0 -->).  usage: python tools/design_table.py [round tag, default r03]"""
 import csv
 import json
 import os
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 P = lambda n: os.path.join(REPO, "profiles", "%s_%s" % (tag, n))
 J = lambda n: json.loads(open(P(n)).readline())
 d, e, h, sp = J("bench.json"), J("bench_f32_operands.json"), J("bench_f16.json"), J("bench_sparse_heads.json")
 r, re_, c = d["roofline"], e["roofline"], d["cpu_baseline"]
 tot = n = 0
 for row in csv.DictReader(open(P("rocprofv3_kernel_stats.csv"))):
-    if "wino24_gemm_kernel" in row["Name"] and "true>" in row["Name"].split("(")[0]:      # the split instantiations <SK, true>
+    # every instantiation of the dominant kernel (round 2: the split instantiations <SK, true> of wino24_gemm_kernel; round 3: the
+    # three epilogue forms of wino14_split_kernel)
+    base = r["kernel"].split("<")[0]
+    if base in row["Name"] and (base != "wino24_gemm_kernel" or "true>" in row["Name"].split("(")[0]):
         tot += float(row["TotalDurationNs"]); n += int(row["Calls"])
 rp = round(tot / max(n, 1) / 1e6, 4)
 st, ste = r["conv_stack_hbm_pmc"], re_["conv_stack_hbm_pmc"]
@@ -24,13 +27,13 @@ rows = """| | value |
 | end-to-end, split operands, two batches in flight (`value`) | **%s images/s** (%s ms/step); sparse heads (`--heads sparse`, ~25 detections per image): %s |
 | ... one batch at a time (`one_batch_in_flight`) | %s images/s (%s ms/step; forward kernels %s ms, postprocess kernels %s ms) |
 | the same steps with fp32 operands (`f32_operands` in the same line; `%s_bench_f32_operands.json` is `bench.py --dtype f32`) | %s / %s images/s in the default run; %s / %s in its own run (round 1: 990) |
-| `roofline`, split operands | dominant kernel `%s`, %d launches/step, charged with their input-transform pre-pass: **%s TFLOP/s executed on the fp16 pipe = %s of 2.5 PF** (without the pre-pass %s TF); avg launch %s ms by HIP events in the timed region vs %s ms by rocprofv3 (`%s_rocprofv3_kernel_stats.csv`, both split instantiations weighted). Against HBM (`roofline.hbm`): %s GB/s algorithmic = %s of 8 TB/s; PMC traffic %s GB per launch against %s GB algorithmic = %s GB/s = **%s of 8 TB/s** over the same time |
+| `roofline`, split operands | dominant kernel `%s`, %d launches/step (fused: no pre-pass): **%s TFLOP/s executed on the fp16 pipe = %s of 2.5 PF** (%s TF by the same events without a pre-pass, i.e. the same); avg launch %s ms by HIP events in the timed region vs %s ms by rocprofv3 (`%s_rocprofv3_kernel_stats.csv`, all instantiations weighted). Against HBM (`roofline.hbm`): %s GB/s algorithmic = %s of 8 TB/s; PMC traffic %s GB per launch against %s GB algorithmic = %s GB/s = **%s of 8 TB/s** over the same time |
 | `roofline`, fp32 operands | `%s`: %s TFLOP/s executed = %s of the 157.3 TF f32-MFMA peak incl. the pre-pass (%s without); PMC traffic %s GB per launch |
 | conv stack HBM by PMC (north_star: "rocprof-reported HBM GB/s for the conv stack") | split: %s GB per step over %s ms of convolution kernels = **%s GB/s = %s of 8 TB/s** (algorithmic %s GB/s = %s); fp32 operands: %s GB over %s ms = %s GB/s = %s |
 | whole step (`roofline.step`, over the step time behind `value`) | split: %s TF executed = %s of 2.5 PF, PMC conv-stack bytes %s GB/s = **%s of 8 TB/s** (algorithmic %s); fp32 operands: %s TF = %s of 157.3 TF, PMC %s GB/s = %s; fp16 configuration: %s TF = %s of 2.5 PF, PMC %s GB/s = %s |
 | postprocess occupancy (north_star: "occupancy for NMS/mask-assembly") | §3.2 last bullet; `roofline.postprocess_occupancy` in the bench line |
 | cpu_baseline (oracle, GPU box's host, %s hardware threads) | thread sweep on one image (forward): %s; best: %s images/s end to end on %s threads; bs=1 forward %s ms, postprocess %s ms (the oracle's decode runs single-threaded for reproducibility, §3.2); reported baseline, not a target |
-| fp16 configuration (`--dtype f16`, `%s_bench_f16.json`) | %s images/s (bs=32) with three batches in flight, %s one at a time (kernels unchanged this round) |
+| fp16 configuration (`--dtype f16`, `%s_bench_f16.json`) | %s images/s (bs=32) with three batches in flight, %s one at a time (round 3 changed only its stem kernel) |
 """ % (d["value"], d["ms_per_step"], sp["value"], d["one_batch_in_flight"]["value"], d["one_batch_in_flight"]["ms_per_step"],
        r["forward_kernels_ms_per_step"], r["postprocess_ms_per_step"],
        tag, d["f32_operands"]["value"], d["f32_operands"]["one_batch_in_flight"], e["value"], e["one_batch_in_flight"]["value"],
