@@ -126,12 +126,13 @@ int om_model_load_weights(om_model* m, const void* packed_dev, size_t bytes, int
  *    fp32 accumulation (the lo*lo term, <= 2^-22 of the product, is dropped): 5.3x the matrix rate at the same bytes per
  *    element.  Representation error <= 2^-22 |x| for |x| >= 2^-14 * 2^11 and 2^-25 absolute below (measured end to end in
  *    DESIGN.md 3.5).  Weights are pre-scaled per output channel by the packer; activations are split as they are, so a
- *    layer input must stay below fp16's 65504 in magnitude -- for a stride-1 3x3 layer its TRANSFORMED input, up to 20x
- *    the activation.  An operand beyond that range turns the layer's outputs into NaN, and every split-operand kernel
+ *    layer input must stay below fp16's 65504 in magnitude -- for a stride-1 3x3 layer its TRANSFORMED input, up to 10x
+ *    the activation in the fused F(4,3) kernel om_forward runs (20x in om_conv2d_winograd24_split).  An operand beyond that range turns the layer's outputs into NaN, and every split-operand kernel
  *    raises OM_STATUS_SPLIT_RANGE in the forward's status word when it stores a non-finite output (below): the caller
  *    re-runs that batch with mode 0 (orienmask_amd/model.py does).  Needs om_model_load_weights_split; activations between
- *    layers stay fp32.  In this mode the stride-1 3x3 layers run F(2x4,3x3) at EVERY size (mode 0 switches to F(2x2,3x3)
- *    below 1700 1/32-scale cells per batch), so an image's outputs do not depend on the batch it is in. */
+ *    layers stay fp32.  In this mode the stride-1 3x3 layers run the fused F(4,3)-along-the-rows kernel (conv_wino14.hip:
+ *    the transformed input never leaves the CU) at EVERY size (mode 0 switches between F(2x4,3x3) and F(2x2,3x3) at 1700
+ *    1/32-scale cells per batch), so an image's outputs do not depend on the batch it is in. */
 size_t om_model_weight_split_words(const om_model* m);
 int om_model_load_weights_split(om_model* m, const void* packed_split_dev, size_t bytes);
 int om_model_set_precision(om_model* m, int mode);

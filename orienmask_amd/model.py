@@ -80,7 +80,7 @@ def resolve_status(pred, flags):
         if not _warned_range:
             import warnings
             warnings.warn("orienmask_amd: an activation left the fp16 range of the split-operand representation "
-                          "(precision 'f32_split': |layer input| < 65504, < ~3275 in front of a stride-1 3x3 layer), or the fp32 "
+                          "(precision 'f32_split': |layer input| < 65504, < ~6550 in front of a stride-1 3x3 layer), or the fp32 "
                           "result itself is non-finite; this batch is re-run with fp32 operands (precision 'f32').  Set "
                           "precision='f32' for a checkpoint that does this on every batch.")
             _warned_range = True
