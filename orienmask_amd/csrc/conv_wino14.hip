@@ -58,9 +58,6 @@ constexpr int W14_EMAX = 160;                 // LDS entries per plane: (R + 2) 
 constexpr int W14_VPLANE = W14_EMAX * 4;      // f32x4 units (16 B) per plane
 constexpr int W14_VBUF = 6 * W14_VPLANE;      // one transformed chunk: 61440 B
 constexpr int W14_UGRP = 3 * W14_BN * 4;      // one (j; ky = 0..2) weight group: 12288 B
-#ifndef W14_LATE
-#define W14_LATE 1             // a group's last kernel row is multiplied at the start of the next group (see `group`)
-#endif
 #ifndef W14_SPREAD
 #define W14_SPREAD 1           // 1: planes (0, 5) first, so that pixels 0 and 5 of a quad item can be requested a group earlier
 #endif                         //    and no group carries more than four requests; 0: planes (1, 2), (3, 4), (0, 5), six per load group
@@ -668,8 +665,7 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
                 read_b(f, ky, slot);
             }
         };
-        if (W14_LATE) {}
-        else if (W14_B_ACROSS) read_frags(ca, smem, 0, 0, 0);
+        if (W14_B_ACROSS) read_frags(ca, smem, 0, 0, 0);
         else read_a(ca, smem, 0, 0);
         // weights first: D[i = channel][j = entry]
         auto mma = [&](const f32x4(&f)[4], auto plc) {
@@ -689,43 +685,6 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
             const f32x4* sV = smem + (c & 1) * W14_VBUF;
             [[maybe_unused]] const f32x4* sVn = smem + ((c & 1) ^ 1) * W14_VBUF;
             // (six explicit instances, not a loop the optimizer may decline to unroll: acc[] must stay in registers)
-#if W14_LATE
-            // The LAST kernel row of a group is multiplied at the start of the NEXT group, from registers read before the barrier:
-            // the new group's first fragments (its weights are readable only after the barrier) are requested first and arrive
-            // under those three matrix instructions (and the other wave's) instead of in front of an idle matrix pipe -- without
-            // this the first matrix instruction of a group issues ~260 cycles after the barrier.  The two fragment sets swap roles
-            // every group (six groups per chunk: the roles repeat per chunk).  Per accumulator the order of the sums is unchanged.
-            auto group = [&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                const int slot = g % 3;
-                f32x4(&P)[4] = (j & 1) ? na : ca;       // holds the pending row on entry
-                f32x4(&Q)[4] = (j & 1) ? ca : na;
-#if OM_W14_TRACE
-                unsigned long long ta, tb = 0, tc = 0, td;
-                W14_STAMP(ta);
-#endif
-                read_frags(Q, sV, j, 0, slot);
-                if (j > 0 || c > 0) mma(P, std::integral_constant<int, w14_plane((j + 5) % 6)>{});
-                issue_group(ubase, g + 2);
-                read_frags(P, sV, j, 1, slot);
-                mma(Q, std::integral_constant<int, w14_plane(j)>{});
-                read_frags(Q, sV, j, 2, slot);
-                mma(P, std::integral_constant<int, w14_plane(j)>{});
-                // Q is the pending row
-                if (g + 2 >= ngroups) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                else if (wave < 4) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");      // all but the pieces requested in this group
-                else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-#if OM_W14_TRACE
-                W14_STAMP(td);
-#endif
-                if (!(OM_W14_ABLATE & 4)) __builtin_amdgcn_s_barrier();
-#if OM_W14_TRACE
-                W14_SETTLE2(ta, td);
-                if (first_tile) w14_trace_put(p, wave, g, ta, tb, tc, td);
-#endif
-                ++g;
-            };
-#else
             auto group = [&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 const int slot = g % 3, slot1 = slot == 2 ? 0 : slot + 1;
@@ -770,7 +729,6 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
 #endif
                 ++g;
             };
-#endif
             group(std::integral_constant<int, 0>{});
             group(std::integral_constant<int, 1>{});
             group(std::integral_constant<int, 2>{});
@@ -778,9 +736,6 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
             group(std::integral_constant<int, 4>{});
             group(std::integral_constant<int, 5>{});
         }
-#if W14_LATE
-        mma(ca, std::integral_constant<int, w14_plane(5)>{});         // the last group's pending row (group 5 leaves it in `ca`)
-#endif
 #if OM_W14_TRACE
         W14_STAMP(pt1);
 #endif
