@@ -189,7 +189,10 @@ int om_model_keep_activations(om_model* m, int keep);
  * milliseconds of the layer's main kernel (layer_ms) and of its pre-pass (layer_pre_ms: the Winograd input
  * transform; 0 for single-kernel layers), plus the number of forwards. */
 /* Tile shape (rows x channels per workgroup) of the conv kernel instantiation that runs layer `index` at
- * this problem size; 0 x 0 for the stem kernel.  Lets a profile be grouped by kernel. */
+ * this problem size; 0 x 0 for the stem kernel.  Lets a profile be grouped by kernel.  algo: 0 conv_stem_kernel, 1 conv_igemm_f32,
+ * 2 / 3 Winograd F(2x2) GEMM / fused, 5 / 6 F(2x4) GEMM with fp32 / split operands, 7 conv_igemm_split, 8 wino14_split (fused
+ * F(4,3)), 9 conv_stem2_split_kernel (precision mode 1: backbone.conv1 + backbone.conv2.0 in one kernel, reported for conv1),
+ * 10 "part of the previous layer's kernel" (reported for conv2.0 then: om_forward launches nothing for it). */
 int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, int* bn, int* algo);
 /* algo: 0 = conv_stem_kernel, 1 = conv_igemm_f32_kernel<bm,bn>, 2 = wino_input_kernel + wino_gemm_kernel<bm,bn>,
  *       3 = wino_fused_kernel<bn> (input transform fused into the GEMM's loader),
@@ -261,6 +264,15 @@ int om_conv2d_wino14_split(const float* in, int B, int H, int W, int cin, int in
 /* first layer: in [B,3,H,W] NCHW -> out [B,H,W,cout] NHWC, 3x3 stride 1. */
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale,
                    const float* shift, int cout, float* out, om_stream stream);
+/* The first TWO layers as om_forward runs them in precision mode 1 (conv_stem2.hip): backbone.conv1 (3 -> 32, 3x3, BN, LeakyReLU;
+ * w1 [32][27], scale1 / shift1 [32] as for om_conv2d_stem) and backbone.conv2.0 (32 -> 64, 3x3 stride 2, BN, LeakyReLU when
+ * leaky2; w2_split / scale2_split as om_layer_info.wsplit_off / wsplit_scale_off describe, shift2 [64]) in one kernel:
+ * in [B,3,H,W] NCHW (H, W even) -> out [B,H/2,W/2,out_pix_stride] NHWC.  Bit-identical to om_conv2d_stem followed by
+ * om_conv2d_split on its output.  status_dev as for om_conv2d_split.
+ * Replaces /root/reference/model/backbone/darknet.py:20-22 (conv1, conv2's first block) as called from model/base.py:104-137. */
+int om_conv2d_stem2_split(const float* in, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
+                          const void* w2_split, const float* scale2_split, const float* shift2, int cout2, int leaky2, float* out,
+                          int out_pix_stride, int32_t* status_dev, om_stream stream);
 
 /* ---- preprocess: FastCOCOTransform.__call__ + pad, fused ------------------------------
  * Replaces /root/reference/data/transform.py:444-510 (permute, Resize = F.interpolate bilinear

@@ -1,0 +1,326 @@
+// The first two layers of DarkNet-53 as ONE kernel in split-operand mode (precision mode 1):
+//   backbone.conv1   = conv_bn_leaky(3, 32, 3, padding=1)              (/root/reference/model/backbone/darknet.py:20)
+//   backbone.conv2.0 = conv_bn_leaky(32, 64, 3, stride=2, padding=1)   (darknet.py:21-22, model/base.py:104-137)
+// Separately (conv_stem.hip, conv_igemm_split.hip) the 32-channel full-resolution activation between them is written and
+// read through HBM: 1.2 GB each way at bs = 32, 544^2 -- 0.37 + 0.55 ms for two layers whose arithmetic needs 0.2 ms
+// (VERDICT round 2, item 5).  Here a workgroup owns 8 x 16 outputs of conv2.0 x all 64 channels and
+//   1. stages the 3 x 19 x 35 image patch under them in LDS (zero padded: out-of-range offsets of a buffer descriptor),
+//   2. computes conv1's 17 x 33 x 32 activations of that patch -- on the matrix pipe too: blocks of 32 activations x 32 channels
+//      x K = 27 (padded to 32) with split operands like every other layer of this mode (image window and weights as hi/lo fp16
+//      pairs, three matrix instructions per 16 of K, fp32 accumulation) -- BatchNorm, LeakyReLU, splits them into hi/lo fp16
+//      (conv_igemm_split.hip: split8) and writes them to LDS in the matrix instruction's operand order (zeros outside the image:
+//      conv2.0's padding),
+//   3. multiplies: 9 taps x 2 chunks of 16 channels, three v_mfma_f32_32x32x16_f16 per step in conv_igemm_split_kernel's order,
+//      the stride-2 gather being LDS addressing; conv2.0's packed hi/lo weights (73.7 KB for 64 output channels) stay in LDS
+//      for the kernel's life,
+//   4. scale / shift, LeakyReLU, 16-byte stores through a per-wave LDS transpose (conv_wino14.hip's epilogue: nothing waits for a
+//      store).
+// LDS: weights 73 728 + activations 17 x 36 x 128 = 78 336 + patch 7 980 bytes: one 512-thread workgroup per CU, tiles by a
+// static stride (every tile costs the same).
+#include "om_common.h"
+
+namespace om {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4s __attribute__((__vector_size__(4 * sizeof(unsigned))));
+
+constexpr int S2_TY = 8, S2_TX = 16;                    // conv2.0 outputs per tile
+constexpr int S2_SR = 2 * S2_TY + 1, S2_SC = 2 * S2_TX + 1;      // conv1 activations under them: 17 x 33
+constexpr int S2_SLOTS = 36;                            // LDS slots (128 B: a pixel's 32 channels as hi/lo) per activation row
+constexpr int S2_PR = S2_SR + 2, S2_PC = S2_SC + 2;     // image patch: 19 x 35
+constexpr int S2_W_BYTES = 18 * 64 * 64;                // [step = tap * 2 + chunk][row][64 B]
+constexpr int S2_S_BYTES = S2_SR * S2_SLOTS * 128;
+constexpr int S2_P_FLOATS = 3 * S2_PR * S2_PC;
+constexpr int S2_THREADS = 512;
+
+struct Stem2Params {
+    const float* img;       // [B,3,H,W]
+    const float* w1;        // [32][27]
+    const float* sc1;
+    const float* sh1;
+    const _Float16* w2;     // conv_weights_split rows of conv2.0: [64][9][2][4][8] halfs
+    const float* sc2;       // scale * 2^-e
+    const float* sh2;
+    float* out;             // NHWC [B, H/2, W/2, out_ps]
+    int* status;
+    int B, H, W, Ho, Wo, out_ps, leaky2;
+    int tiles_x, tiles_y, total_tiles;
+};
+
+__global__ __launch_bounds__(S2_THREADS, 2) void conv_stem2_split_kernel(const Stem2Params p) {
+    __shared__ f32x4 smem[(S2_W_BYTES + S2_S_BYTES + S2_P_FLOATS * 4 + 15) / 16];
+    char* const sW = reinterpret_cast<char*>(smem);
+    char* const sS = sW + S2_W_BYTES;
+    float* const sP = reinterpret_cast<float*>(sS + S2_S_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- conv2.0's weights: global [row][step][chunk] -> LDS [step][row][chunk ^ ((row >> 2) & 3)], once
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.w2);
+#pragma unroll
+        for (int i = 0; i < S2_W_BYTES / 16 / S2_THREADS; ++i) {
+            const int idx = tid + i * S2_THREADS;
+            const int n = idx / 72, rem = idx - n * 72;
+            const int step = rem >> 2, k = rem & 3;
+            *reinterpret_cast<f32x4*>(sW + step * 4096 + n * 64 + ((k ^ ((n >> 2) & 3)) * 16)) = src[idx];
+        }
+    }
+    // ---- conv1's role: ALSO on the matrix pipe.  (On the vector ALUs -- a thread per activation and channel quad, 27 x 4 fused
+    // multiply-adds each, as conv_stem_kernel does -- this phase took 11 100 of a tile's 18 100 cycles: the 114 instructions
+    // around the 56 packed multiply-adds of an activation cost as much as they do.)  A wave multiplies blocks of 32 activations
+    // x 32 channels x K = 27 (padded to 32: two steps of 16): the weights as hi/lo fp16 in registers for the kernel's life, the
+    // 3 x 3 x 3 image window of an activation gathered from the LDS patch, split, three matrix instructions per step.
+    const int fi = lane & 31, fk = lane >> 5;
+    f16x8 w1h[2], w1l[2];
+    int koff[2][8];                 // patch offset of contraction index k = 16 s + 8 fk + i relative to the window's origin
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = 16 * s2 + 8 * fk + i;             // k = (kh * 3 + kw) * 3 + ci, the order of w1's rows
+            const int kk = k < 27 ? k : 0;
+            const int t = kk / 3, ci = kk - 3 * t;
+            const int kh = t / 3, kw = t - 3 * kh;
+            koff[s2][i] = (ci * S2_PR + kh) * S2_PC + kw;
+            const float w = k < 27 ? p.w1[fi * 27 + kk] : 0.f;
+            const _Float16 h = (_Float16)w;
+            w1h[s2][i] = h;
+            w1l[s2][i] = (_Float16)(w - (float)h);
+        }
+    // the 16 channels a lane holds of an activation after the products: 8 (r >> 2) + 4 fk + (r & 3)
+    f32x4 sc1[4], sh1[4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        sc1[gq] = *reinterpret_cast<const f32x4*>(p.sc1 + 8 * gq + 4 * fk);
+        sh1[gq] = *reinterpret_cast<const f32x4*>(p.sh1 + 8 * gq + 4 * fk);
+    }
+    // ---- conv2.0's role: wave = 32 outputs (two tile rows) x 32 channels
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m = 32 * wm + fi;
+    const int oy = m >> 4, ox = m & 15;
+    const int nrow = 32 * wn + fi;
+    const int boff_hi = nrow * 64 + ((fk ^ ((nrow >> 2) & 3)) * 16);
+    const int boff_lo = nrow * 64 + (((2 + fk) ^ ((nrow >> 2) & 3)) * 16);
+    // epilogue role (conv_wino14.hip): lane holds channels 4 (lane & 7).. of outputs 8 rd + (lane >> 3) of the wave's 32
+    const int c8 = lane & 7;
+    const int nb = 32 * wn + 4 * c8;
+    const f32x4 sc2 = *reinterpret_cast<const f32x4*>(p.sc2 + nb);
+    const f32x4 sh2 = *reinterpret_cast<const f32x4*>(p.sh2 + nb);
+    // the pre-loop loads have landed as far as the compiler's wait bookkeeping goes (conv_stem.hip)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) asm volatile("" ::"v"(sc1[gq]), "v"(sh1[gq]));
+    asm volatile("" ::"v"(w1h[0]), "v"(w1h[1]), "v"(w1l[0]), "v"(w1l[1]), "v"(sc2), "v"(sh2));
+    float nonfinite = 0.f;
+
+    // the image patch of a tile travels through registers: requested before the PREVIOUS tile's matrix phase, so that its round
+    // trip to HBM runs under that phase -- and the requests are older than that tile's output stores (one in-order counter: a
+    // wait for a load behind a store would wait for the store's round trip too)
+    constexpr int NSTAGE = (S2_P_FLOATS + S2_THREADS - 1) / S2_THREADS;
+    float stage[NSTAGE];
+    auto request_patch = [&](int tile) {
+        const int b = tile / (p.tiles_x * p.tiles_y);
+        const int tr = tile - b * (p.tiles_x * p.tiles_y);
+        const int ty = tr / p.tiles_x, tx = tr - ty * p.tiles_x;
+        const int y0 = 2 * ty * S2_TY - 1, x0 = 2 * tx * S2_TX - 1;
+        const auto rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.img + (size_t)b * 3 * p.H * p.W), 0, 3 * p.H * p.W * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int e = tid + i * S2_THREADS;
+            const int c = e / (S2_PR * S2_PC), r = e - c * (S2_PR * S2_PC);
+            const int py = r / S2_PC, px = r - py * S2_PC;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;          // patch row 0 / column 0: one above / left of conv1's first
+            const bool ok = tile < p.total_tiles && e < S2_P_FLOATS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            stage[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_img, ok ? ((c * p.H + gy) * p.W + gx) * 4 : (int)0x80000000, 0, 0));
+        }
+    };
+    request_patch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+        const int b = tile / (p.tiles_x * p.tiles_y);
+        const int tr = tile - b * (p.tiles_x * p.tiles_y);
+        const int ty = tr / p.tiles_x, tx = tr - ty * p.tiles_x;
+        const int oy0 = ty * S2_TY, ox0 = tx * S2_TX;
+        const int y0 = 2 * oy0 - 1, x0 = 2 * ox0 - 1;       // conv1 activation (row 0, column 0) of the tile
+#ifdef OM_S2_TRACE
+        unsigned long long t0, t1, t2, t3, t4;
+        asm volatile("s_memtime %0" : "=s"(t0)::"memory");
+#endif
+        // ---- 1. the image patch: rows y0 - 1 .., columns x0 - 1 ..
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int e = tid + i * S2_THREADS;
+            if (e < S2_P_FLOATS) sP[e] = stage[i];
+        }
+        __syncthreads();
+#ifdef OM_S2_TRACE
+        asm volatile("s_memtime %0" : "=s"(t1)::"memory");
+#endif
+        // ---- 2. conv1 + BatchNorm + LeakyReLU, hi/lo split, into conv2.0's matrix operand layout
+#pragma unroll 1
+        for (int blk = wave; blk < (S2_SR * S2_SC + 31) / 32; blk += S2_THREADS / 64) {
+            const int pix = blk * 32 + fi;
+            const int pc = pix < S2_SR * S2_SC ? pix : S2_SR * S2_SC - 1;       // lanes beyond the last activation repeat it
+            const int r = pc / S2_SC, col = pc - r * S2_SC;
+            const float* win = sP + r * S2_PC + col;
+            f32x16 acc1;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc1[q] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[i] = win[koff[s2][i]];
+                    if (s2 == 1 && i >= 3) v[i] = fk ? 0.f : v[i];      // k = 27..31 do not exist
+                }
+                f16x8 ah, al;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    ah[i] = (_Float16)v[i];
+                    al[i] = (_Float16)(v[i] - (float)ah[i]);
+                }
+                // weights first: D[i = channel][j = activation]
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[s2], al, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l[s2], ah, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[s2], ah, acc1, 0, 0, 0);
+            }
+            const bool inside = pix < S2_SR * S2_SC && (unsigned)(y0 + r) < (unsigned)p.H && (unsigned)(x0 + col) < (unsigned)p.W;
+            // slot: even columns first, then odd ones, so that the outputs of a tile row read consecutive slots for every tap
+            const int slot = r * S2_SLOTS + (col & 1) * 17 + (col >> 1);
+            const int sq = (slot >> 1) & 3, sg = (slot >> 3) & 1;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                // channels 8 gq + 4 fk ..: quad 2 gq + fk -> 16-channel group gq >> 1, operand chunk fk, half gq & 1 of the chunk
+                f32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float t = fmaf(acc1[4 * gq + k], sc1[gq][k], sh1[gq][k]);
+                    o[k] = inside ? (t > 0.f ? t : t * 0.1f) : 0.f;         // outside the image: conv2.0's zero padding
+                }
+                const f16x4 h = __builtin_convertvector(o, f16x4);
+                f16x4 l;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) l[k] = (_Float16)(o[k] - (float)h[k]);
+                if (pix < S2_SR * S2_SC) {
+                    char* row = sS + slot * 128 + (((gq >> 1) ^ sg) * 64) + (gq & 1) * 8;
+                    *reinterpret_cast<u32x2*>(row + ((fk ^ sq) * 16)) = __builtin_bit_cast(u32x2, h);
+                    *reinterpret_cast<u32x2*>(row + (((2 + fk) ^ sq) * 16)) = __builtin_bit_cast(u32x2, l);
+                }
+            }
+        }
+        __syncthreads();
+#ifdef OM_S2_TRACE
+        asm volatile("s_memtime %0" : "=s"(t2)::"memory");
+#endif
+        request_patch(tile + gridDim.x);        // the patch is dead: its registers take the next tile's
+        // ---- 3. conv2.0
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+        // fragments one step ahead of the matrix instructions that use them
+        f32x4 cur[4], nxt[4];
+        auto read_step = [&](f32x4(&f)[4], int step) {
+            const int tap = step >> 1, c = step & 1;
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const int slot = (2 * oy + kh) * S2_SLOTS + (kw & 1) * 17 + ox + (kw >> 1);
+            const int sq = (slot >> 1) & 3, sg = (slot >> 3) & 1;
+            const char* arow = sS + slot * 128 + ((c ^ sg) * 64);
+            const char* brow = sW + step * 4096;
+            f[0] = *reinterpret_cast<const f32x4*>(arow + ((fk ^ sq) * 16));
+            f[1] = *reinterpret_cast<const f32x4*>(arow + (((2 + fk) ^ sq) * 16));
+            f[2] = *reinterpret_cast<const f32x4*>(brow + boff_hi);
+            f[3] = *reinterpret_cast<const f32x4*>(brow + boff_lo);
+        };
+        read_step(cur, 0);
+#pragma unroll
+        for (int step = 0; step < 18; ++step) {
+            if (step + 1 < 18) read_step(nxt, step + 1);
+            const f16x8 ah = __builtin_bit_cast(f16x8, cur[0]), al = __builtin_bit_cast(f16x8, cur[1]);
+            const f16x8 bh = __builtin_bit_cast(f16x8, cur[2]), bl = __builtin_bit_cast(f16x8, cur[3]);
+            // weights first: D[i = channel][j = output], the three products in conv_igemm_split_kernel's order
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, acc2, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+        }
+#ifdef OM_S2_TRACE
+        asm volatile("s_memtime %0" : "=s"(t3)::"memory");
+#endif
+        __syncthreads();        // every wave is done with the activations: their LDS takes the transposes
+        // ---- 4. epilogue: 32 x 32 transpose through 4 KiB of the wave's own, then one channel quad of four outputs per lane
+        {
+            f32x4* sT = reinterpret_cast<f32x4*>(sS) + wave * 256;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 v = {acc2[4 * gq], acc2[4 * gq + 1], acc2[4 * gq + 2], acc2[4 * gq + 3]};
+                sT[fi * 8 + ((2 * gq + fk) ^ (fi & 7))] = v;
+            }
+            const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * p.Ho * p.Wo * p.out_ps, 0, p.Ho * p.Wo * p.out_ps * 4, 0x00020000);
+#pragma unroll
+            for (int rd = 0; rd < 4; ++rd) {
+                const int e = 8 * rd + (lane >> 3);
+                f32x4 v = sT[e * 8 + (c8 ^ (e & 7))];
+                const int mm = 32 * wm + e;
+                const int oyy = oy0 + (mm >> 4), oxx = ox0 + (mm & 15);
+                const bool ok = oyy < p.Ho && oxx < p.Wo;
+                float nf = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float t = fmaf(v[k], sc2[k], sh2[k]);
+                    nf = fmaf(t, 0.f, nf);
+                    v[k] = p.leaky2 ? (t > 0.f ? t : t * 0.1f) : t;
+                }
+                nonfinite += ok ? nf : 0.f;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), rs_out,
+                                                       ok ? ((oyy * p.Wo + oxx) * p.out_ps + nb) * 4 : (int)0x80000000, 0, 0);
+            }
+        }
+#ifdef OM_S2_TRACE
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t4)::"memory");
+        if (blockIdx.x == 0 && tid == 0 && tile == blockIdx.x + 3 * gridDim.x) {
+            unsigned long long* tr = reinterpret_cast<unsigned long long*>(p.status);
+            tr[0] = t0; tr[1] = t1; tr[2] = t2; tr[3] = t3; tr[4] = t4;
+        }
+#endif
+        // the next tile's barrier (after its patch is staged) orders these transposes before the next activations
+    }
+#ifndef OM_S2_TRACE
+    if (p.status && nonfinite != nonfinite) atomicOr(p.status, OM_STATUS_SPLIT_RANGE);
+#endif
+}
+
+// w2_split / scale2_split: conv2.0's packed hi/lo weights and scale * 2^-e (include/orienmask_hip.h: om_layer_info.wsplit_off)
+int launch_conv_stem2_split(const float* in_nchw, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
+                            const void* w2_split, const float* scale2_split, const float* shift2, int cout2, int leaky2,
+                            float* out_nhwc, int out_pix_stride, int* status, hipStream_t stream) {
+    OM_REQUIRE(in_nchw && w1 && scale1 && shift1 && w2_split && scale2_split && shift2 && out_nhwc, OM_EINVAL, "stem2: null pointer");
+    OM_REQUIRE(cout2 == 64, OM_EINVAL, "stem2: cout=%d, only 64 supported", cout2);
+    OM_REQUIRE(B > 0 && H > 1 && W > 1 && H % 2 == 0 && W % 2 == 0, OM_EINVAL, "stem2: bad shape B=%d H=%d W=%d", B, H, W);
+    OM_REQUIRE(out_pix_stride % 4 == 0 && out_pix_stride >= 64 && (reinterpret_cast<uintptr_t>(out_nhwc) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(w2_split) & 15) == 0,
+               OM_EINVAL, "stem2: output view / weights must be 16-byte aligned");
+    OM_REQUIRE((long long)(H / 2) * (W / 2) * out_pix_stride * 4 < 0x7FFFFFF0ll && (long long)3 * H * W * 4 < 0x7FFFFFF0ll, OM_EINVAL,
+               "stem2: an image of %d x %d exceeds a buffer descriptor", H, W);
+    Stem2Params p;
+    p.img = in_nchw; p.w1 = w1; p.sc1 = scale1; p.sh1 = shift1;
+    p.w2 = static_cast<const _Float16*>(w2_split); p.sc2 = scale2_split; p.sh2 = shift2;
+    p.out = out_nhwc; p.status = status;
+    p.B = B; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2; p.out_ps = out_pix_stride; p.leaky2 = leaky2;
+    p.tiles_x = (p.Wo + S2_TX - 1) / S2_TX; p.tiles_y = (p.Ho + S2_TY - 1) / S2_TY;
+    const long long total = (long long)B * p.tiles_x * p.tiles_y;
+    OM_REQUIRE(total < (1ll << 31), OM_EINVAL, "stem2: %lld tiles out of range", total);
+    p.total_tiles = (int)total;
+    const unsigned grid = (unsigned)(total < 256 ? total : 256);
+    hipLaunchKernelGGL(conv_stem2_split_kernel, dim3(grid), dim3(S2_THREADS), 0, stream, p);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
+}  // namespace om

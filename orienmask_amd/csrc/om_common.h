@@ -108,6 +108,10 @@ int launch_conv_winograd24(const ConvArgs& a, float* scratch, hipStream_t stream
 size_t wino24_scratch_floats(int B, int H, int W, int C);
 // fused F(4,3)-along-the-rows form with split operands (conv_wino14.hip): a.w = packed hi/lo weights [n_tiles][cin/16][6][3][64][32]
 int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream);
+// backbone.conv1 + backbone.conv2.0 as one kernel with split operands (conv_stem2.hip): image NCHW -> conv2.0's NHWC output
+int launch_conv_stem2_split(const float* in_nchw, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
+                            const void* w2_split, const float* scale2_split, const float* shift2, int cout2, int leaky2,
+                            float* out_nhwc, int out_pix_stride, int* status, hipStream_t stream);
 size_t wino14_weight_halfs(int cout_pad, int cin);
 void wino14_geometry(int B, int H, int W, int* R, int* Ct, int* ncb, int* nrb);
 bool wino_enabled();

@@ -234,6 +234,17 @@ struct om_model {
         return precision == 1 || (long long)B * (H / 32) * (W / 32) >= 1700ll;
     }
 
+    // split-operand mode: conv1 (the stem) and conv2.0 run as ONE kernel (conv_stem2.hip) when the second is the 32 -> 64 3x3
+    // stride-2 layer reading the first one's output -- unless every activation is kept for om_layer_output_view
+    bool stem2_fused(size_t index) const {
+        if (precision != 1 || keep_all || index != 0 || layers.size() < 2 || !layers[0].stem) return false;
+        const om::LayerDef& a = layers[0];
+        const om::LayerDef& b = layers[1];
+        return a.info.cout == 32 && b.info.cin == 32 && b.info.cout == 64 && b.info.cout_pad == 64 && b.info.ksize == 3 &&
+               b.info.stride == 2 && !b.has_res && b.out_mode == 0 && b.in.buf == a.out.buf && b.in.ch_off == a.out.ch_off &&
+               b.info.wsplit_off >= 0 && b.info.wino_planes != 24;
+    }
+
     size_t buf_floats(int i, int B, int H, int W) const {
         return (size_t)B * (H / bufs[i].div) * (W / bufs[i].div) * bufs[i].C;
     }
@@ -430,6 +441,7 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
         }
     };
 
+    bool fused_into_previous = false;
     for (const om::LayerDef& L : m->layers) {
         const om_layer_info& li = L.info;
         hipEvent_t ev_stop = nullptr, ev_mid = nullptr;
@@ -454,6 +466,27 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
         const float* scale = m->weights + li.scale_off;
         const float* shift = m->weights + li.shift_off;
         const int Hin = H / L.in_div, Win = W / L.in_div;
+        if (fused_into_previous) {          // conv2.0 after the fused conv1 + conv2.0 kernel: nothing to launch (its events bracket nothing)
+            fused_into_previous = false;
+            if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
+            continue;
+        }
+        if (L.stem && m->stem2_fused(&L - m->layers.data())) {
+            // split-operand mode: conv1 and conv2.0 as one kernel (conv_stem2.hip) -- conv1's activation never reaches memory
+            const om::LayerDef& N = m->layers[(&L - m->layers.data()) + 1];
+            if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
+            int rc = om::launch_conv_stem2_split(x, B, Hin, Win, w, scale, shift, m->weights_split + N.info.wsplit_off,
+                                                 m->weights_split + N.info.wsplit_scale_off, m->weights + N.info.shift_off, N.info.cout,
+                                                 N.info.leaky, static_cast<float*>(ptr_of(N.out)), m->pix_stride(N.out.buf), status, stream);
+            if (rc != OM_OK) {
+                char msg[512];
+                std::snprintf(msg, sizeof(msg), "%s", om::g_err);
+                om::set_error("layers %s + %s: %s", li.name, N.info.name, msg);
+                return rc;
+            }
+            fused_into_previous = true;
+            continue;
+        }
         if (L.stem) {
             if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
             int rc = f16 ? om::launch_conv_stem_f16(x, B, Hin, Win, w, scale, shift, li.cout, ptr_of(L.out), stream)
@@ -599,7 +632,9 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
     OM_REQUIRE(m && bm && bn && algo, OM_EINVAL, "om_layer_tile: null argument");
     OM_REQUIRE(index >= 0 && index < (int)m->layers.size(), OM_EINVAL, "om_layer_tile: index %d", index);
     const om::LayerDef& L = m->layers[index];
+    if (L.stem && m->stem2_fused((size_t)index)) { *bm = 128; *bn = 64; *algo = 9; return OM_OK; }      // conv1 + conv2.0 in one kernel
     if (L.stem) { *bm = 0; *bn = 0; *algo = 0; return OM_OK; }
+    if (index == 1 && m->stem2_fused(0)) { *bm = 0; *bn = 0; *algo = 10; return OM_OK; }                // ... which this layer is part of
     if (L.info.wino_off >= 0 && om::wino_enabled() && L.info.wino_planes == 24 && m->precision == 1) {
         *algo = 8; *bm = 128; *bn = 64;
         return OM_OK;
@@ -839,6 +874,13 @@ int om_conv2d_wino14_split(const float* in, int B, int H, int W, int cin, int in
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale, const float* shift,
                    int cout, float* out, om_stream stream) {
     return om::launch_conv_stem(in, B, H, W, w, scale, shift, cout, out, static_cast<hipStream_t>(stream));
+}
+
+int om_conv2d_stem2_split(const float* in, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
+                          const void* w2_split, const float* scale2_split, const float* shift2, int cout2, int leaky2, float* out,
+                          int out_pix_stride, int32_t* status_dev, om_stream stream) {
+    return om::launch_conv_stem2_split(in, B, H, W, w1, scale1, shift1, w2_split, scale2_split, shift2, cout2, leaky2, out,
+                                       out_pix_stride, status_dev, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -87,6 +87,7 @@ SIGNATURES = {
     "om_conv2d": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "om_conv2d_mode": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "om_conv2d_stem": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "om_conv2d_stem2_split": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
     "om_preprocess": (_i, [_vp, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                            _i, _i, _i, _i, _f, _vp, _vp]),
     "om_pad_nchw": (_i, [_vp, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),

@@ -425,8 +425,9 @@ class OrienMaskYOLOFPNPlus(nn.Module):
                        "om_layer_tile")
             fmt = {0: "conv_stem_kernel", 1: "conv_igemm_f32_kernel<%d,%d>", 2: "wino_gemm_kernel<%d,%d>",
                    3: "wino_fused_kernel<%d,%d>", 5: "wino24_gemm_kernel<%d,%d>", 6: "wino24_gemm_kernel<%d,%d,split>",
-                   7: "conv_igemm_split_kernel<%d,%d>", 8: "wino14_split_kernel<%d,%d>"}[algo.value]
-            out.append((l["name"], fmt % ((bm.value, bn.value) if algo.value else ())))
+                   7: "conv_igemm_split_kernel<%d,%d>", 8: "wino14_split_kernel<%d,%d>",
+                   9: "conv_stem2_split_kernel<%d,%d>", 10: "(in the previous layer's kernel)"}[algo.value]
+            out.append((l["name"], fmt % ((bm.value, bn.value) if algo.value not in (0, 10) else ())))
         return out
 
     def profile_read(self):

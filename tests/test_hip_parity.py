@@ -600,6 +600,56 @@ def test_stem_matches_torch(dev):
     assert _rel_err(got, want) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 40, 72), (1, 34, 50), (3, 16, 32), (1, 96, 160)])
+def test_stem2_split_matches_two_kernels(dev, shape):
+    """conv_stem2.hip -- backbone.conv1 + backbone.conv2.0 (3x3 stride 2, 32 -> 64) as ONE kernel in split-operand mode, conv1's
+    activation never in memory, conv1 itself on the matrix pipe with split operands -- against float64 (the bound of the
+    two-kernel path, 2e-6 of scale) and against om_conv2d_stem followed by om_conv2d_split (fp32 conv1 on the vector ALUs: same
+    values to 2e-6), on sizes with partial tiles in both directions and an output view with a pixel stride of its own."""
+    from orienmask_amd.pack import conv_weights_split
+    B, H, W = shape
+    L = omlib.load()
+    g = torch.Generator().manual_seed(sum(shape) + 5)
+    x = torch.rand(B, 3, H, W, generator=g) * 2 - 0.5
+    w1 = torch.randn(32, 3, 3, 3, generator=g) * 0.3
+    sc1 = torch.rand(32, generator=g) + 0.5
+    sh1 = torch.randn(32, generator=g) * 0.2
+    w2 = torch.randn(64, 32, 3, 3, generator=g) / (32 * 9) ** 0.5
+    sc2 = torch.rand(64, generator=g) + 0.5
+    sh2 = torch.randn(64, generator=g) * 0.2
+    a = torch.nn.functional.conv2d(x.double(), w1.double(), None, 1, 1) * sc1.double().view(1, -1, 1, 1) + sh1.double().view(1, -1, 1, 1)
+    a = torch.where(a > 0, a, a * 0.1)
+    want = torch.nn.functional.conv2d(a, w2.double(), None, 2, 1) * sc2.double().view(1, -1, 1, 1) + sh2.double().view(1, -1, 1, 1)
+    want = torch.where(want > 0, want, want * 0.1)
+    w1p = w1.permute(0, 2, 3, 1).reshape(32, 27).contiguous().to(dev)
+    ws, e = conv_weights_split(w2, 64)
+    sp2 = (sc2.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e.double())).float().to(dev)
+    xd, sc1d, sh1d, wsd, sh2d = x.to(dev), sc1.to(dev), sh1.to(dev), ws.to(dev), sh2.to(dev)
+    st = omlib.current_stream_ptr(dev)
+    Ho, Wo = H // 2, W // 2
+    # two kernels
+    mid = torch.empty(B, H, W, 32, device=dev)
+    omlib.check(L.om_conv2d_stem(_p(xd), B, H, W, _p(w1p), _p(sc1d), _p(sh1d), 32, _p(mid), st), "om_conv2d_stem")
+    two = torch.full((B, Ho, Wo, 64), float("nan"), device=dev)
+    omlib.check(L.om_conv2d_split(_p(mid), B, H, W, 32, 32, _p(wsd), _p(sp2), _p(sh2d), 64, 3, 2, 1, None, 0, _p(two), 64, 0, 1, 0, 0,
+                                  None, st), "om_conv2d_split")
+    # one kernel, into a channel slice of a wider buffer
+    ostride = 80
+    buf = torch.full((B, Ho, Wo, ostride), float("nan"), device=dev)
+    view = buf[..., 8:]
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    omlib.check(L.om_conv2d_stem2_split(_p(xd), B, H, W, _p(w1p), _p(sc1d), _p(sh1d), _p(wsd), _p(sp2), _p(sh2d), 64, 1,
+                                        ctypes.c_void_p(view.data_ptr()), ostride, _p(status), st), "om_conv2d_stem2_split")
+    one = buf[..., 8:72]
+    assert int(status.item()) == 0
+    assert torch.isnan(buf[..., :8]).all() and torch.isnan(buf[..., 72:]).all()      # nothing outside the 64 channels
+    e1 = _rel_err(one.cpu().permute(0, 3, 1, 2).double(), want)
+    e2 = _rel_err(two.cpu().permute(0, 3, 1, 2).double(), want)
+    e12 = _rel_err(one.cpu().double(), two.cpu().double())
+    print("stem2 %s: one kernel %.2e, two kernels %.2e of scale against float64; against each other %.2e" % (shape, e1, e2, e12))
+    assert e1 < 2e-6 and e1 <= 2 * e2 + 5e-7 and e12 < 2e-6
+
+
 # ------------------------------------------------------------------------------------------------
 # forward
 # ------------------------------------------------------------------------------------------------
