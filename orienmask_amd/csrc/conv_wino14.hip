@@ -48,11 +48,8 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4v __attribute__((__vector_size__(4 * sizeof(unsigned))));
 
 #ifndef OM_W14_ABLATE
-#define OM_W14_ABLATE 0        // measurement builds only (wrong numerics; profiles/r03_experiments.md 3): 2 no fragment reads, 4 no
-#endif                         // per-group barrier, 8 no weight DMA, 16 no input requests / transform, 32 no epilogue stores, 64
-                               // requests but no transform, 128 transform of fake registers, 256 no V stores, 512 every request
-                               // hits the same 18 KiB, 1024 no matrix instructions, 2048 idle consumers, 4096 no s_setprio,
-                               // 8192 one queue order for the whole chip
+#define OM_W14_ABLATE 0        // measurement builds only (wrong numerics): 2 no fragment reads, 4 no per-group barrier, 8 no weight
+#endif                         // DMA, 16 no input loads / transform, 32 no epilogue stores, 1024 no matrix instructions
 #ifndef OM_W14_TRACE
 #define OM_W14_TRACE 0         // measurement builds only: s_memtime stamps of one tile's groups (tools/wino14_trace.py)
 #endif
