@@ -42,7 +42,6 @@ struct IgemmSParams {
     int ks, stride, pad;
     int M, kc, ksteps, taps;               // kc = cin / 16
     int n_tiles, total_tiles;
-    int rep;        // out_mode 1 with few tiles: every tile is computed by `rep` = up workgroups, each storing one replica row
     int leaky, res_pix_stride, out_pix_stride, out_mode, up;
     int vec_io;
     int total_in_pixels;
@@ -56,7 +55,7 @@ constexpr int split_blocks_per_cu() { return BM * BN >= 256 * 128 ? 2 : (BM * BN
 // channel = 8*(r>>2) + 4*(lane>>5) + (r&3)): one wave-row (WM pixels x BN channels) at a time through LDS.
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void split_epilogue(const IgemmSParams& p, f32x4* smem, const f32x16 (&acc)[WM / 32][WN / 32],
-                                               int m0, int n0, int tid, int wm, int wn, int fi, int fk, int dy_lo, int dy_hi) {
+                                               int m0, int n0, int tid, int wm, int wn, int fi, int fk) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int CH8 = BN / 8;
     constexpr int RP = 256 / CH8;
@@ -132,7 +131,7 @@ __device__ __forceinline__ void split_epilogue(const IgemmSParams& p, f32x4* sme
                     const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
                     const int Wu = p.Wo * p.up;
                     const size_t base = ((size_t)bi * p.Ho * p.up + (size_t)oy * p.up) * Wu + (size_t)ox * p.up;
-                    for (int dy = dy_lo; dy < dy_hi; ++dy)
+                    for (int dy = 0; dy < p.up; ++dy)
                         for (int dx = 0; dx < p.up; ++dx) {
                             float* o = p.out + (base + (size_t)dy * Wu + dx) * p.out_pix_stride + n;
                             if (vec) {
@@ -214,11 +213,6 @@ __global__ __launch_bounds__(256, (split_blocks_per_cu<BM, BN>())) void conv_ige
         int tile = *s_ticket;
         if (tile >= p.total_tiles) break;
         tile = __builtin_amdgcn_readfirstlane(tile);
-        // nearest up-sampling into a concat buffer (the skip / route layers: 17^2 .. 68^2 inputs, up^2 stores per output) is bound by
-        // the stores of at most 145 workgroups: with p.rep = up the tile is computed up times (its arithmetic is nothing) and each
-        // copy stores one of the up replica rows
-        const int part = tile % p.rep;
-        tile /= p.rep;
         const int tile_n = tile % p.n_tiles;
         const int tile_m = tile / p.n_tiles;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -354,7 +348,7 @@ __global__ __launch_bounds__(256, (split_blocks_per_cu<BM, BN>())) void conv_ige
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
 
-        split_epilogue<BM, BN, WM, WN>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk, p.rep > 1 ? part : 0, p.rep > 1 ? part + 1 : p.up);
+        split_epilogue<BM, BN, WM, WN>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk);
     }
 }
 
@@ -362,9 +356,7 @@ template <int BM, int BN, int WM, int WN>
 static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hipStream_t stream) {
     const int m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = cout_pad / BN;
-    long long total = (long long)m_tiles * p.n_tiles;
-    p.rep = (p.out_mode == 1 && p.up > 1 && total < 256ll * blocks_per_cu) ? p.up : 1;
-    total *= p.rep;
+    const long long total = (long long)m_tiles * p.n_tiles;
     OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "conv split: %lld tiles out of range", total);
     p.total_tiles = (int)total;
     const long long grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
