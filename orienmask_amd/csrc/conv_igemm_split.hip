@@ -28,6 +28,10 @@
 
 namespace om {
 
+#ifndef OM_SPLIT_WIDE
+#define OM_SPLIT_WIDE 1        // 128 x 128 tiles with 128-byte operand rows (conv_igemm_split_wide_kernel) where cin % 32 == 0
+#endif
+
 struct IgemmSParams {
     const _Float16* in;   // the fp32 activations, addressed in halfs (pixel stride and channel counts doubled)
     const _Float16* w;    // packed hi/lo weights: [cout_pad][taps][cin / 16][4][8] halfs
@@ -352,7 +356,184 @@ __global__ __launch_bounds__(256, (split_blocks_per_cu<BM, BN>())) void conv_ige
     }
 }
 
+// The same tile with WHOLE-LINE operand rows: a ring stage holds 128 bytes of every row -- two k-steps of 16 channels -- instead
+// of 64.  A 16-channel fp32 chunk of a pixel (and 16 channels of a packed weight row) is half a 128-byte cache line, and the CU's
+// vector-memory path is bound by the NUMBER of requests it can keep in flight (conv_wino14.hip / DESIGN.md 3.6): fetched 64 bytes
+// per k-step every line is requested twice, one k-step apart.  LDS-DMA streams with twelve waves per CU: 37 B/clk/CU in half
+// lines, 70 in whole lines (tools/scratch/ldsdma_rowbytes.hip).  Two stages of (BM + BN) x 128 B (64 KiB for 128 x 128: two
+// workgroups per CU), one barrier per stage = per two k-steps, the stage after next requested in the middle of a stage (two
+// k-steps of flight, as in the three-stage form).  Needs cin % 32 == 0 (every k-pair inside one kernel tap).
 template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const IgemmSParams p) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NWN = BN / WN;
+    constexpr int A_CH = BM / 32, B_CH = BN / 32, NP = A_CH + B_CH;     // 32 rows x 128 B per workgroup-wide piece
+    constexpr int NBUF = 2;
+    constexpr int STAGE = (BM + BN) * 8;            // f32x4 (16-byte) units per ring stage
+    static_assert((BM / WM) * (BN / WN) == 4, "four waves per workgroup");
+    static_assert(BM % 32 == 0 && BN % 32 == 0, "whole 32-row pieces");
+    static_assert(WM * BN / 4 <= NBUF * STAGE, "one wave-row of the fp32 C tile must fit in the operand ring");
+    __shared__ f32x4 smem[NBUF * STAGE + 1];      // ONE LDS object (see conv_igemm.hip)
+    int* const s_ticket = reinterpret_cast<int*>(smem + NBUF * STAGE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int lrow = tid >> 3, lcol = tid & 7;     // loader: row within a 32-row piece, 16-byte position in the 128-byte row
+    const int scol = lcol ^ ((lrow >> 1) & 7);     // logical chunk this lane fetches (the LDS image stays lane-linear)
+    const int fi = lane & 31, fk = lane >> 5;
+    const int fsw = (fi >> 1) & 7;
+
+    for (;;) {
+        if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int tile = *s_ticket;
+        if (tile >= p.total_tiles) break;
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        const int tile_n = tile % p.n_tiles;
+        const int tile_m = tile / p.n_tiles;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+        int rowoff[A_CH];
+        unsigned invmask[A_CH];
+        const int b_first = (m0 < p.M ? m0 : p.M - 1) / p.HoWo;
+#pragma unroll
+        for (int j = 0; j < A_CH; ++j) {
+            int m = m0 + lrow + 32 * j;
+            const bool mok = m < p.M;
+            if (!mok) m = p.M - 1;
+            const int b = m / p.HoWo;
+            const int rr = m - b * p.HoWo;
+            const int oy = rr / p.Wo;
+            const int ox = rr - oy * p.Wo;
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+            rowoff[j] = (((b - b_first) * p.H * p.W + iy0 * p.W + ix0) * p.in_pix_stride_h + scol * 8) * 2;
+            unsigned badrow = 0, badcol = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                badrow |= ((unsigned)(iy0 + k) < (unsigned)p.H ? 0u : 1u) << k;
+                badcol |= ((unsigned)(ix0 + k) < (unsigned)p.W ? 0u : 1u) << k;
+            }
+            unsigned inv;
+            if (p.ks == 3) {
+                inv = ((badrow & 1u) ? 0x007u : 0u) | ((badrow & 2u) ? 0x038u : 0u) | ((badrow & 4u) ? 0x1C0u : 0u) | badcol * 0x49u;
+            } else {
+                inv = (badrow | badcol) & 1u;
+            }
+            invmask[j] = mok ? inv : 0xFFFFFFFFu;
+        }
+        int rowoffB[B_CH];
+        const int row_halfs = p.taps * p.cin_h;
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) rowoffB[j] = ((n0 + lrow + 32 * j) * row_halfs + scol * 8) * 2;
+        const _Float16* in_base = p.in + (size_t)b_first * p.H * p.W * p.in_pix_stride_h;
+        const size_t in_left = ((size_t)p.total_in_pixels - (size_t)b_first * p.H * p.W) * p.in_pix_stride_h * 2;
+        const int in_bytes = in_left < 0x7FFFFFFFull ? (int)in_left : 0x7FFFFFFF;
+
+        const int kc2 = p.kc >> 1;                  // pairs of 16-channel chunks per tap
+        const int nstages = p.taps * kc2;
+        int n_kh = 0, n_kw = 0, n_cc = 0;          // stage being fetched: (tap row, tap col, 32-channel chunk)
+        auto advance = [&]() {
+            if (++n_cc == kc2) {
+                n_cc = 0;
+                if (++n_kw == p.ks) { n_kw = 0; ++n_kh; }
+            }
+        };
+        auto issue_piece = [&](int piece, int buf, bool live) {
+            f32x4* dst = smem + buf * STAGE + wave_u * 64;
+            if (piece < A_CH) {
+                const int j = piece;
+                const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in_base), 0, live ? in_bytes : 0, 0x00020000);
+                const int tap = n_kh * p.ks + n_kw;
+                const int tap_off = ((n_kh * p.W + n_kw) * p.in_pix_stride_h + n_cc * 64) * 2;      // scalar
+                const int voff = (rowoff[j] + tap_off) | ((invmask[j] << (31 - tap)) & 0x80000000u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(dst + j * 256), 16, voff, 0, 0, 0);
+            } else {
+                const int j = piece - A_CH;
+                const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, live ? p.w_bytes : 0, 0x00020000);
+                const int koff = ((n_kh * p.ks + n_kw) * p.cin_h + n_cc * 64) * 2;                  // scalar
+                const int vo = rowoffB[j] + koff;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(dst + BM * 8 + j * 256), 16, vo, 0, 0, 0);
+            }
+        };
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+        const f32x4* fragA = smem + (wm * WM + fi) * 8;
+        const f32x4* fragB = smem + BM * 8 + (wn * WN + fi) * 8;
+        f32x4 xa0[TM], xa1[TM], nbh[TN], nbl[TN];      // raw operands of the NEXT k-step
+        f16x8 ah[TM], al[TM], bh[TN], bl[TN];          // operands of the current k-step
+        auto read_raw = [&](int buf, int sub) {
+            const int c0 = (4 * sub + fk) ^ fsw, c1 = (4 * sub + 2 + fk) ^ fsw;
+            const int bo = buf * STAGE;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) { xa0[a] = fragA[bo + a * 32 * 8 + c0]; xa1[a] = fragA[bo + a * 32 * 8 + c1]; }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) { nbh[b] = fragB[bo + b * 32 * 8 + c0]; nbl[b] = fragB[bo + b * 32 * 8 + c1]; }
+        };
+        auto convert = [&]() {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) split8(xa0[a], xa1[a], ah[a], al[a]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) { bh[b] = __builtin_bit_cast(f16x8, nbh[b]); bl[b] = __builtin_bit_cast(f16x8, nbl[b]); }
+        };
+        auto multiply = [&]() {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    // weights first: D[i = channel][j = pixel]; the order of conv_igemm_split_kernel
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[b], al[a], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[b], ah[a], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[b], ah[a], acc[a][b], 0, 0, 0);
+                }
+        };
+
+        // prologue: stages 0 and 1 requested; stage 0 waited for, its first k-step converted
+#pragma unroll
+        for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 0, true);
+        advance();
+#pragma unroll
+        for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 1, 1 < nstages);
+        advance();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NP) : "memory");
+        __builtin_amdgcn_s_barrier();
+        read_raw(0, 0);
+        convert();
+        int buf = 0;
+        for (int s = 0; s < nstages; ++s) {
+            read_raw(buf, 1);
+            multiply();                              // k-step (s, 0)
+            convert();                               // operands of (s, 1); my reads of `buf` are complete
+            // stage s + 1 (requested one stage ago) has landed; every wave is done reading `buf`: it takes stage s + 2
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const bool live2 = s + 2 < nstages;
+#pragma unroll
+            for (int piece = 0; piece < NP; ++piece) issue_piece(piece, buf, live2);
+            advance();
+            read_raw(buf ^ 1, 0);
+            multiply();                              // k-step (s, 1)
+            convert();                               // operands of (s + 1, 0)
+            buf ^= 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        split_epilogue<BM, BN, WM, WN>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool WIDE = false>
 static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hipStream_t stream) {
     const int m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = cout_pad / BN;
@@ -360,7 +541,8 @@ static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hi
     OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "conv split: %lld tiles out of range", total);
     p.total_tiles = (int)total;
     const long long grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
-    hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    if constexpr (WIDE) hipLaunchKernelGGL((conv_igemm_split_wide_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }
@@ -421,6 +603,7 @@ int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream) {
         bm = a.force_bm; bn = a.force_bn;
     }
     if (bm == 256 && bn == 128) return launch_tile_split<256, 128, 128, 64>(p, a.cout_pad, 2, stream);
+    if (bm == 128 && bn == 128 && a.cin % 32 == 0 && !a.force_bm && OM_SPLIT_WIDE) return launch_tile_split<128, 128, 64, 64, true>(p, a.cout_pad, 2, stream);
     if (bm == 128 && bn == 128) return launch_tile_split<128, 128, 64, 64>(p, a.cout_pad, 3, stream);
     if (bm == 128 && bn == 64) return launch_tile_split<128, 64, 64, 32>(p, a.cout_pad, 4, stream);
     if (bm == 64 && bn == 64) return launch_tile_split<64, 64, 32, 32>(p, a.cout_pad, 4, stream);
