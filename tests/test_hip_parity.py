@@ -295,6 +295,32 @@ def test_conv_split_layer_matches_torch(dev, case):
     assert err < 2e-6, case
 
 
+@pytest.mark.parametrize("case", [(8, 68, 68, 256, 128, 1, 1), (4, 68, 68, 128, 256, 3, 2), (2, 34, 34, 96, 128, 3, 2)])
+def test_conv_split_wide_rows_equal_narrow(dev, case):
+    """conv_igemm_split_wide_kernel (128 x 128 tile, ring stages of 128-byte operand rows: what the tile chooser's 128 x 128 runs
+    where cin % 32 == 0) against conv_igemm_split_kernel<128,128> (64-byte rows; forced through the per-call tile shape): the same
+    products in the same order per accumulator -- bit-identical outputs, stride-2 padding taps and a partial last M tile included."""
+    from orienmask_amd.pack import conv_weights_split
+    B, H, W, cin, cout, k, stride = case
+    L = omlib.load()
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(B, H, W, cin, generator=g).to(dev)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    ws, e = conv_weights_split(w, cout)
+    wd = ws.to(dev)
+    sp = torch.pow(torch.tensor(2.0), -e.float()).to(dev)
+    hp = (torch.randn(cout, generator=g) * 0.2).to(dev)
+    Ho, Wo = H // stride, W // stride
+    outs = []
+    for bm, bn in ((0, 0), (128, 128)):
+        out = torch.full((B, Ho, Wo, cout), float("nan"), device=dev)
+        omlib.check(L.om_conv2d_split(_p(x), B, H, W, cin, cin, _p(wd), _p(sp), _p(hp), cout, k, stride, 1, None, 0, _p(out), cout, 0, 1,
+                                      bm, bn, None, omlib.current_stream_ptr(dev)), "om_conv2d_split")
+        outs.append(out.cpu())
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("mode", ["upsample", "nchw"])
 def test_conv_split_output_modes(dev, mode):
     """The split-operand kernel's other two epilogues: nearest up-sampling into a channel slice of a concat buffer, and the
