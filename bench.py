@@ -194,6 +194,9 @@ def main():
                          "the per-kernel events of the roofline object) and reported as `one_batch_in_flight`.  Default: 2 in fp32, "
                          "3 in fp16 (its steps are a third as long and the host's read of the counts weighs more: 3790 against 3700 "
                          "images/s; in fp32 a third batch changes nothing, a fourth costs 3 %)")
+    ap.add_argument("--replicated-concat", action="store_true",
+                    help="A/B: f32_split with the routes / skips stored replicated into the concat buffers (set_upsample_on_read(False)) "
+                         "instead of read up-sampled by the 1x1 layer behind the concat")
     ap.add_argument("--lib", default=None,
                     help="path of another build of liborienmask_hip.so to load instead of the in-tree one (A/B runs of two "
                          "builds on the same GPU box: tools/ab_bench.sh)")
@@ -245,6 +248,8 @@ def main():
         sd = synth.synth_state_dict(WEIGHT_SEED, obj_bias=obj_bias, head_gain=HEAD_GAIN)
         net.load_state_dict(sd, strict=True)
     broadcast_packed_weights(net, dev, src=0)                      # one RCCL broadcast, untimed
+    if args.replicated_concat:
+        net.set_upsample_on_read(False)
     post = OrienMaskYOLOPostProcess(device=dev, **post_config(H, W))
     x_cpu = synth.synth_image_batch(1000 + rank, B, H, W)
     x = x_cpu.to(dev)

@@ -137,6 +137,12 @@ size_t om_model_weight_split_words(const om_model* m);
 int om_model_load_weights_split(om_model* m, const void* packed_split_dev, size_t bytes);
 int om_model_set_precision(om_model* m, int mode);
 int om_model_get_precision(const om_model* m);
+/* Precision mode 1 only: 1 (default) = the routes and skips (the 1x1 layers whose output the reference up-samples and concatenates,
+ * orienmask_yolo_fpnplus.py:78-86) store ONE copy at their own resolution and the 1x1 layer behind the concat reads them
+ * up-sampled (om_conv2d_split_gather); 0 = they store their output replicated into the concat buffer, as modes 0 / fp16 do.
+ * Same values bit for bit; changes om_forward_workspace_bytes (call it again).  Not active while om_model_keep_activations
+ * is on (om_layer_output_view reports the concat slices). */
+int om_model_set_upsample_on_read(om_model* m, int enable);
 
 size_t om_forward_workspace_bytes(const om_model* m, int B, int H, int W);
 /* x: [B,3,H,W] float32 NCHW, H and W multiples of 32.
@@ -192,7 +198,9 @@ int om_model_keep_activations(om_model* m, int keep);
  * this problem size; 0 x 0 for the stem kernel.  Lets a profile be grouped by kernel.  algo: 0 conv_stem_kernel, 1 conv_igemm_f32,
  * 2 / 3 Winograd F(2x2) GEMM / fused, 5 / 6 F(2x4) GEMM with fp32 / split operands, 7 conv_igemm_split, 8 wino14_split (fused
  * F(4,3)), 9 conv_stem2_split_kernel (precision mode 1: backbone.conv1 + backbone.conv2.0 in one kernel, reported for conv1),
- * 10 "part of the previous layer's kernel" (reported for conv2.0 then: om_forward launches nothing for it). */
+ * 10 "part of the previous layer's kernel" (reported for conv2.0 then: om_forward launches nothing for it), 11 conv_igemm_split in
+ * its GATHER form (precision mode 1: the 1x1 layer behind an up-sample + concat reads the low-resolution slices where their
+ * producers stored them, om_conv2d_split_gather). */
 int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, int* bn, int* algo);
 /* algo: 0 = conv_stem_kernel, 1 = conv_igemm_f32_kernel<bm,bn>, 2 = wino_input_kernel + wino_gemm_kernel<bm,bn>,
  *       3 = wino_fused_kernel<bn> (input transform fused into the GEMM's loader),
@@ -248,6 +256,15 @@ int om_conv2d_split(const float* in, int B, int H, int W, int cin, int in_pix_st
                     const float* scale_split, const float* shift, int cout, int ksize, int stride, int leaky, const float* res,
                     int res_pix_stride, float* out, int out_pix_stride, int out_mode, int up, int tile_bm, int tile_bn,
                     int32_t* status_dev, om_stream stream);
+/* The 1x1 layer behind an up-sample + concat, as om_forward runs neck16.0 / neck8.0 / neck4.0 in precision mode 1
+ * (conv_igemm_split.hip, GATHER form): the input channels are the concatenation of nseg (1..4) NHWC tensors, segment g with
+ * seg_channels[g] channels (a multiple of 32) stored at [B, H/seg_up[g], W/seg_up[g], seg_pix_stride[g]] (seg_up a power of two
+ * dividing H and W) and read nearest-up-sampled; cout_pad must be a multiple of 128.  Bit-identical to om_conv2d_split over
+ * the materialised concat.  Replaces F.interpolate(scale_factor, 'nearest') + torch.cat + the following 1x1 Conv-BN-LeakyReLU
+ * of /root/reference/model/orienmask_yolo_fpnplus.py:78-86 (forward: route / skip concatenations). */
+int om_conv2d_split_gather(int nseg, const float* const* seg_ptr, const int* seg_channels, const int* seg_pix_stride,
+                           const int* seg_up, int B, int H, int W, const void* w_split, const float* scale_split, const float* shift,
+                           int cout, int leaky, float* out, int out_pix_stride, int32_t* status_dev, om_stream stream);
 /* ... with split operands (om_model_set_precision mode 1): u_split as om_layer_info.wsplit_off describes, scale_split =
  * scale * 2^-e per output channel; scratch as for om_conv2d_winograd24; status_dev as for om_conv2d_split. */
 int om_conv2d_winograd24_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* u_split,
@@ -267,8 +284,9 @@ int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const f
 /* The first TWO layers as om_forward runs them in precision mode 1 (conv_stem2.hip): backbone.conv1 (3 -> 32, 3x3, BN, LeakyReLU;
  * w1 [32][27], scale1 / shift1 [32] as for om_conv2d_stem) and backbone.conv2.0 (32 -> 64, 3x3 stride 2, BN, LeakyReLU when
  * leaky2; w2_split / scale2_split as om_layer_info.wsplit_off / wsplit_scale_off describe, shift2 [64]) in one kernel:
- * in [B,3,H,W] NCHW (H, W even) -> out [B,H/2,W/2,out_pix_stride] NHWC.  Bit-identical to om_conv2d_stem followed by
- * om_conv2d_split on its output.  status_dev as for om_conv2d_split.
+ * in [B,3,H,W] NCHW (H, W even) -> out [B,H/2,W/2,out_pix_stride] NHWC.  conv1's products run on the matrix pipe with split
+ * operands here (fp32 multiply-adds in om_conv2d_stem): the same values as om_conv2d_stem followed by om_conv2d_split to 2e-6 of
+ * the tensor's scale, not bit for bit.  status_dev as for om_conv2d_split.
  * Replaces /root/reference/model/backbone/darknet.py:20-22 (conv1, conv2's first block) as called from model/base.py:104-137. */
 int om_conv2d_stem2_split(const float* in, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
                           const void* w2_split, const float* scale2_split, const float* shift2, int cout2, int leaky2, float* out,

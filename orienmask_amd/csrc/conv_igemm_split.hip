@@ -50,6 +50,13 @@ struct IgemmSParams {
     int vec_io;
     int total_in_pixels;
     int w_bytes;
+    // gathered input of a 1x1 layer (conv_igemm_split_wide_kernel<..., true>): the cin channels are the concatenation of nseg
+    // tensors; segment g holds channels [32 seg_end[g-1], 32 seg_end[g]) and is stored at 1 / 2^seg_shift[g] of this layer's
+    // resolution -- the nearest-neighbour up-sampling of the reference's routes and skips (orienmask_yolo_fpnplus.py:78-86,
+    // F.interpolate + torch.cat) happens in the operand addresses instead of in replicated stores
+    int nseg, nimg;
+    const _Float16* seg_ptr[4];
+    int seg_stride_h[4], seg_shift[4], seg_end[4];
 };
 
 template <int BM, int BN>
@@ -363,7 +370,11 @@ __global__ __launch_bounds__(256, (split_blocks_per_cu<BM, BN>())) void conv_ige
 // lines, 70 in whole lines (tools/scratch/ldsdma_rowbytes.hip).  Two stages of (BM + BN) x 128 B (64 KiB for 128 x 128: two
 // workgroups per CU), one barrier per stage = per two k-steps, the stage after next requested in the middle of a stage (two
 // k-steps of flight, as in the three-stage form).  Needs cin % 32 == 0 (every k-pair inside one kernel tap).
-template <int BM, int BN, int WM, int WN>
+//
+// GATHER: the A rows come from up to four tensors at their own resolutions (IgemmSParams::nseg; 1x1 layers only).  The row
+// offsets are recomputed when the k loop crosses into the next segment (at most three times per tile); everything else is the
+// same instruction stream, and the products are summed in the same order as over the materialised concat (bit-identical).
+template <int BM, int BN, int WM, int WN, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const IgemmSParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NWN = BN / WN;
@@ -399,6 +410,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
 
         int rowoff[A_CH];
         unsigned invmask[A_CH];
+        [[maybe_unused]] int g_img[A_CH], g_y[A_CH], g_x[A_CH];      // GATHER: the row's pixel, for the segments' own resolutions
         const int b_first = (m0 < p.M ? m0 : p.M - 1) / p.HoWo;
 #pragma unroll
         for (int j = 0; j < A_CH; ++j) {
@@ -411,6 +423,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
             const int ox = rr - oy * p.Wo;
             const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
             rowoff[j] = (((b - b_first) * p.H * p.W + iy0 * p.W + ix0) * p.in_pix_stride_h + scol * 8) * 2;
+            if constexpr (GATHER) { g_img[j] = b - b_first; g_y[j] = oy; g_x[j] = ox; }
             unsigned badrow = 0, badcol = 0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -431,7 +444,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
         for (int j = 0; j < B_CH; ++j) rowoffB[j] = ((n0 + lrow + 32 * j) * row_halfs + scol * 8) * 2;
         const _Float16* in_base = p.in + (size_t)b_first * p.H * p.W * p.in_pix_stride_h;
         const size_t in_left = ((size_t)p.total_in_pixels - (size_t)b_first * p.H * p.W) * p.in_pix_stride_h * 2;
-        const int in_bytes = in_left < 0x7FFFFFFFull ? (int)in_left : 0x7FFFFFFF;
+        int in_bytes = in_left < 0x7FFFFFFFull ? (int)in_left : 0x7FFFFFFF;
+        [[maybe_unused]] int seg = 0, seg_c0 = 0, seg_c1 = 0x7FFFFFFF;      // GATHER: current segment, its 32-channel chunk range
+        [[maybe_unused]] auto set_segment = [&](int g) {
+            // (selects, not p.seg_x[g]: a run-time index into the by-value parameter block would copy the arrays to scratch)
+            auto pick = [g](const auto (&v)[4]) { return g == 0 ? v[0] : g == 1 ? v[1] : g == 2 ? v[2] : v[3]; };
+            const int sh = pick(p.seg_shift), Hs = p.Ho >> sh, Ws = p.Wo >> sh, st = pick(p.seg_stride_h);
+            in_base = pick(p.seg_ptr) + (size_t)b_first * Hs * Ws * st;
+            const size_t left = (size_t)(p.nimg - b_first) * Hs * Ws * st * 2;
+            in_bytes = left < 0x7FFFFFFFull ? (int)left : 0x7FFFFFFF;
+#pragma unroll
+            for (int j = 0; j < A_CH; ++j)
+                rowoff[j] = (((g_img[j] * Hs + (g_y[j] >> sh)) * Ws + (g_x[j] >> sh)) * st + scol * 8) * 2;
+            seg = g;
+            seg_c0 = g == 0 ? 0 : g == 1 ? p.seg_end[0] : g == 2 ? p.seg_end[1] : p.seg_end[2];
+            seg_c1 = pick(p.seg_end);
+        };
+        if constexpr (GATHER) set_segment(0);
 
         const int kc2 = p.kc >> 1;                  // pairs of 16-channel chunks per tap
         const int nstages = p.taps * kc2;
@@ -446,9 +475,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
             f32x4* dst = smem + buf * STAGE + wave_u * 64;
             if (piece < A_CH) {
                 const int j = piece;
+                if constexpr (GATHER) {
+                    if (piece == 0 && live && n_cc >= seg_c1) set_segment(seg + 1);      // uniform; the stages walk the channels in order
+                }
                 const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in_base), 0, live ? in_bytes : 0, 0x00020000);
                 const int tap = n_kh * p.ks + n_kw;
-                const int tap_off = ((n_kh * p.W + n_kw) * p.in_pix_stride_h + n_cc * 64) * 2;      // scalar
+                const int tap_off = GATHER ? (n_cc - seg_c0) * 128      // 1x1: one tap; the chunk within its segment
+                                           : ((n_kh * p.W + n_kw) * p.in_pix_stride_h + n_cc * 64) * 2;      // scalar
                 const int voff = (rowoff[j] + tap_off) | ((invmask[j] << (31 - tap)) & 0x80000000u);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(dst + j * 256), 16, voff, 0, 0, 0);
             } else {
@@ -533,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool WIDE = false>
+template <int BM, int BN, int WM, int WN, bool WIDE = false, bool GATHER = false>
 static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hipStream_t stream) {
     const int m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = cout_pad / BN;
@@ -541,7 +574,7 @@ static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hi
     OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "conv split: %lld tiles out of range", total);
     p.total_tiles = (int)total;
     const long long grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
-    if constexpr (WIDE) hipLaunchKernelGGL((conv_igemm_split_wide_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    if constexpr (WIDE) hipLaunchKernelGGL((conv_igemm_split_wide_kernel<BM, BN, WM, WN, GATHER>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
@@ -563,11 +596,11 @@ void conv_tile_for_split(int M, int cout_pad, int* bm, int* bn) {
 
 // a.w: packed hi/lo weights (include/orienmask_hip.h: om_layer_info.wsplit_off); a.scale: scale * 2^-e
 int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream) {
-    OM_REQUIRE(a.in && a.w && a.scale && a.shift && a.out, OM_EINVAL, "conv split: null pointer");
+    OM_REQUIRE((a.in || a.nseg > 0) && a.w && a.scale && a.shift && a.out, OM_EINVAL, "conv split: null pointer");
     OM_REQUIRE(a.cin % 16 == 0 && a.cin >= 16, OM_EINVAL, "conv split: cin=%d must be a multiple of 16", a.cin);
     OM_REQUIRE(a.ks == 1 || a.ks == 3, OM_EINVAL, "conv split: ksize=%d not supported", a.ks);
     OM_REQUIRE(a.stride == 1 || a.stride == 2, OM_EINVAL, "conv split: stride=%d not supported", a.stride);
-    OM_REQUIRE(a.in_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
+    OM_REQUIRE((a.nseg > 0 || (a.in_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0)) &&
                    (reinterpret_cast<uintptr_t>(a.w) & 15) == 0,
                OM_EINVAL, "conv split: input view / weights must be 16-byte aligned");
     OM_REQUIRE(a.cout_pad % 32 == 0 && a.cout <= a.cout_pad, OM_EINVAL, "conv split: cout_pad=%d", a.cout_pad);
@@ -593,6 +626,32 @@ int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream) {
     p.vec_io = (a.out_mode != 2 && a.out_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
                 (!a.res || (a.res_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)))
                    ? 1 : 0;
+    p.nseg = 0; p.nimg = a.B;
+    for (int g = 0; g < 4; ++g) { p.seg_ptr[g] = p.in; p.seg_stride_h[g] = 0; p.seg_shift[g] = 0; p.seg_end[g] = 0x7FFFFFFF; }
+    if (a.nseg > 0) {
+        // gathered input: 1x1, whole 32-channel chunks per segment, every segment's resolution a power-of-two fraction of this one
+        OM_REQUIRE(a.nseg <= 4 && a.ks == 1 && a.stride == 1 && a.cout_pad % 128 == 0, OM_EINVAL,
+                   "conv split: a gathered input needs a 1x1 stride-1 layer with cout_pad %% 128 == 0 and at most 4 segments (nseg=%d ks=%d "
+                   "stride=%d cout_pad=%d)", a.nseg, a.ks, a.stride, a.cout_pad);
+        int end = 0;
+        for (int g = 0; g < a.nseg; ++g) {
+            const int up = a.seg_up[g];
+            int sh = 0;
+            while ((1 << sh) < up) ++sh;
+            OM_REQUIRE(a.seg_ptr[g] && up >= 1 && (1 << sh) == up && a.H % up == 0 && a.W % up == 0 && a.seg_channels[g] > 0 &&
+                           a.seg_channels[g] % 32 == 0 && a.seg_pix_stride[g] % 4 == 0 && a.seg_pix_stride[g] >= a.seg_channels[g] &&
+                           (reinterpret_cast<uintptr_t>(a.seg_ptr[g]) & 15) == 0,
+                       OM_EINVAL, "conv split: segment %d (channels=%d pix_stride=%d up=%d) of a gathered input", g, a.seg_channels[g],
+                       a.seg_pix_stride[g], up);
+            end += a.seg_channels[g] / 32;
+            p.seg_ptr[g] = reinterpret_cast<const _Float16*>(a.seg_ptr[g]);
+            p.seg_stride_h[g] = 2 * a.seg_pix_stride[g]; p.seg_shift[g] = sh; p.seg_end[g] = end;
+        }
+        OM_REQUIRE(end * 32 == a.cin, OM_EINVAL, "conv split: the segments hold %d channels, the layer reads %d", end * 32, a.cin);
+        p.nseg = a.nseg;
+        p.in = p.seg_ptr[0];
+        return launch_tile_split<128, 128, 64, 64, true, true>(p, a.cout_pad, 2, stream);
+    }
     int bm, bn;
     conv_tile_for_split(p.M, a.cout_pad, &bm, &bn);
     if (a.force_bm || a.force_bn) {      // unit-test entry: this call's tile shape

@@ -57,6 +57,11 @@ struct ConvArgs {
     int* status = nullptr;  // the forward's status word (include/orienmask_hip.h: OM_STATUS_*), OR-ed by the split-operand kernels
                             // and the stream-K form; nullptr = not reported
     int force_bm = 0, force_bn = 0;   // unit-test entries: tile shape of conv_igemm_split.hip for THIS call (0 = the chooser's)
+    // gathered input (conv_igemm_split.hip, 1x1 layers): the cin channels are the concatenation of nseg tensors, segment g stored
+    // at 1 / seg_up[g] of this layer's resolution and read nearest-up-sampled; nseg = 0: the plain view `in`
+    int nseg = 0;
+    const float* seg_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+    int seg_channels[4] = {0, 0, 0, 0}, seg_pix_stride[4] = {0, 0, 0, 0}, seg_up[4] = {1, 1, 1, 1};
 };
 
 constexpr int SK_SLOTS = 1024;                          // most resident workgroups of a stream-K launch (4 per CU)

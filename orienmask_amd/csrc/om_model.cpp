@@ -53,6 +53,11 @@ struct LayerDef {
     bool stem = false;
     int in_div = 1;      // spatial divisor of the input
     int out_mode = 0, up = 1;
+    // Up-sampling on read (split-operand mode, find_gathers()): an up-sampling producer (out_mode 1) also owns `side`, a buffer at
+    // its OWN resolution; the 1x1 layer that reads the concat buffer lists, in channel order, where each slice really is.
+    int side = -1;
+    struct Seg { int producer; View view; int channels, up; };      // producer: layer index whose `side` holds the slice, or -1: `view`
+    std::vector<Seg> gather;
 };
 
 }  // namespace om
@@ -223,7 +228,53 @@ struct om_model {
         o = cbl("orien_head.3", o, 256, 128, 1, 4);
         o = cbl("orien_head.4", o, 128, 256, 3, 4);
         add("orien_head.5", 256, A * 6, 1, 1, false, o, 4, View{om::BUF_ORIENS, 0}, nullptr, 2, 1);
+        find_gathers();
     }
+
+    // The reference up-samples the routes and skips (F.interpolate, nearest) and concatenates them with a same-resolution feature
+    // (orienmask_yolo_fpnplus.py:78-86).  The plain form here lets the producer store its output replicated up x up into its slice
+    // of the concat buffer; skip32 alone then writes 64 copies of every value (151 MB at bs=32, 544^2) which neck4.0 reads back.
+    // In split-operand mode the producer stores ONE copy at its own resolution (`side`) and the consuming 1x1 layer reads the
+    // slices where they are, up-sampling in its operand addresses (conv_igemm_split.hip: GATHER): same products, same order.
+    void find_gathers() {
+        for (size_t c = 0; c < layers.size(); ++c) {
+            om::LayerDef& C = layers[c];
+            if (C.in.buf < 0 || C.in.ch_off != 0 || C.info.ksize != 1 || C.info.stride != 1 || C.info.cin != bufs[C.in.buf].C ||
+                C.info.cout_pad % 128 != 0 || C.out_mode != 0)
+                continue;
+            std::vector<om::LayerDef::Seg> segs;
+            bool any_up = false, ok = true;
+            for (size_t w = 0; w < c; ++w) {
+                const om::LayerDef& P = layers[w];
+                if (P.out.buf != C.in.buf) continue;
+                if (P.out_mode == 2 || P.info.cout % 32 != 0) ok = false;
+                any_up |= P.out_mode == 1;
+                segs.push_back({P.out_mode == 1 ? (int)w : -1, P.out, P.info.cout, P.out_mode == 1 ? P.up : 1});
+            }
+            std::sort(segs.begin(), segs.end(), [](const om::LayerDef::Seg& a, const om::LayerDef::Seg& b) { return a.view.ch_off < b.view.ch_off; });
+            int at = 0;
+            for (const auto& sg : segs) { ok = ok && sg.view.ch_off == at; at += sg.channels; }
+            if (!ok || !any_up || at != C.info.cin || segs.size() > 4) continue;
+            // the side copy REPLACES the up-sampled slice: nobody else may read it (the same-resolution slices stay where they are)
+            auto reads_upsampled = [&](const om::View& v, int channels) {
+                if (v.buf != C.in.buf) return false;
+                for (const auto& sg : segs)
+                    if (sg.producer >= 0 && v.ch_off < sg.view.ch_off + sg.channels && sg.view.ch_off < v.ch_off + channels) return true;
+                return false;
+            };
+            for (size_t r = 0; r < layers.size(); ++r)
+                if (r != c && (reads_upsampled(layers[r].in, layers[r].info.cin) ||
+                               (layers[r].has_res && reads_upsampled(layers[r].res, layers[r].info.cout))))
+                    ok = false;
+            if (!ok) continue;
+            for (auto& sg : segs)
+                if (sg.producer >= 0) layers[sg.producer].side = new_buf(layers[sg.producer].in_div, layers[sg.producer].info.cout);
+            C.gather = segs;
+        }
+    }
+    // split operands, fp32 tensors, activations not kept for om_layer_output_view (which reports a slice of the concat buffer)
+    bool upsample_on_read = true;      // om_model_set_upsample_on_read
+    bool gather_active(bool f16) const { return !f16 && precision == 1 && !keep_all && upsample_on_read; }
 
     // F(2x4,3x3) needs enough tiles to fill the chip: measured at 544^2, bs=4 is 4 % faster with F(2x2) and bs=8 is 4 % faster
     // with F(2x4); the switch is on the number of 1/32-scale cells in the batch (289 per 544^2 image).
@@ -274,7 +325,7 @@ struct om_model {
         const int nb = (int)bufs.size(), nl = (int)layers.size();
         struct Item { size_t bytes; int first, last; size_t off; };
         std::vector<Item> items(nb + nl);
-        for (int i = 0; i < nb; ++i) items[i] = {om::align_up(buf_floats(i, B, H, W) * esz, 256), nl, -1, 0};
+        for (int i = 0; i < nb; ++i) items[i] = {om::align_up(buf_floats(i, B, H, W) * esz, 256), nl, -1, 0};      // never touched: not placed
         for (int l = 0; l < nl; ++l) {
             const om::LayerDef& L = layers[l];
             auto touch = [&](int buf) {
@@ -284,6 +335,11 @@ struct om_model {
             };
             touch(L.in.buf); touch(L.out.buf);
             if (L.has_res) touch(L.res.buf);
+            if (gather_active(f16)) {
+                if (L.side >= 0) touch(L.side);
+                for (const auto& sg : L.gather)
+                    if (sg.producer >= 0) touch(layers[sg.producer].side);
+            }
             items[nb + l] = {f16 ? 0 : om::align_up(layer_scratch_floats(L, B, H, W) * sizeof(float), 256), l, l, 0};
         }
         if (keep_all)
@@ -393,6 +449,12 @@ int om_model_set_precision(om_model* m, int mode) {
 }
 
 int om_model_get_precision(const om_model* m) { return m ? m->precision : OM_EINVAL; }
+
+int om_model_set_upsample_on_read(om_model* m, int enable) {
+    OM_REQUIRE(m, OM_EINVAL, "om_model_set_upsample_on_read: null model");
+    m->upsample_on_read = enable != 0;
+    return OM_OK;
+}
 
 static size_t forward_workspace_bytes(const om_model* m, int B, int H, int W, bool f16) {
     if (!m || B <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32) return 0;
@@ -547,6 +609,20 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
                 if (m->precision == 1 && li.wino_planes != 24) {
                     a.w = m->weights_split + li.wsplit_off;
                     a.scale = m->weights_split + li.wsplit_scale_off;
+                    if (m->gather_active(f16)) {
+                        if (L.side >= 0) {          // up-sampling producer: one copy at its own resolution, read up-sampled
+                            a.out = reinterpret_cast<float*>(base[L.side]);
+                            a.out_pix_stride = m->pix_stride(L.side); a.out_mode = 0; a.up = 1;
+                        }
+                        a.nseg = (int)L.gather.size();
+                        for (int g = 0; g < a.nseg; ++g) {
+                            const om::LayerDef::Seg& sg = L.gather[g];
+                            const int side = sg.producer >= 0 ? m->layers[sg.producer].side : -1;
+                            a.seg_ptr[g] = side >= 0 ? reinterpret_cast<const float*>(base[side]) : static_cast<const float*>(ptr_of(sg.view));
+                            a.seg_pix_stride[g] = side >= 0 ? m->pix_stride(side) : m->pix_stride(sg.view.buf);
+                            a.seg_channels[g] = sg.channels; a.seg_up[g] = sg.up;
+                        }
+                    }
                     rc = om::launch_conv_igemm_split(a, stream);
                 } else {
                     rc = om::launch_conv_igemm(a, stream);
@@ -655,6 +731,7 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
     if (m->precision == 1 && L.info.wino_planes != 24) {
         om::conv_tile_for_split(B * Ho * Wo, L.info.cout_pad, bm, bn);
         *algo = 7;
+        if (m->gather_active(false) && !L.gather.empty()) { *bm = 128; *bn = 128; *algo = 11; }      // up-sampling on read
         return OM_OK;
     }
     om::conv_tile_for(B * Ho * Wo, L.info.cout_pad, bm, bn);
@@ -745,6 +822,31 @@ int om_conv2d_split(const float* in, int B, int H, int W, int cin, int in_pix_st
     a.ks = ksize; a.stride = stride; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
     a.out_pix_stride = out_pix_stride; a.out_mode = out_mode; a.up = up;
     a.force_bm = tile_bm; a.force_bn = tile_bn; a.status = status_dev;
+    static int* g_ticket = nullptr;      // unit-test entry only (see om_conv2d_mode)
+    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), om::SYNC_WORDS * sizeof(int)));
+    if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;
+    a.ticket = g_ticket;
+    return om::launch_conv_igemm_split(a, static_cast<hipStream_t>(stream));
+}
+
+int om_conv2d_split_gather(int nseg, const float* const* seg_ptr, const int* seg_channels, const int* seg_pix_stride,
+                           const int* seg_up, int B, int H, int W, const void* w_split, const float* scale_split, const float* shift,
+                           int cout, int leaky, float* out, int out_pix_stride, int32_t* status_dev, om_stream stream) {
+    OM_REQUIRE(B > 0 && H > 0 && W > 0 && nseg >= 1 && nseg <= 4 && seg_ptr && seg_channels && seg_pix_stride && seg_up, OM_EINVAL,
+               "om_conv2d_split_gather: bad shape / null segment table (nseg=%d)", nseg);
+    om::ConvArgs a;
+    a.in = nullptr; a.w = static_cast<const float*>(w_split); a.scale = scale_split; a.shift = shift; a.res = nullptr; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.cin = 0; a.in_pix_stride = 0;
+    a.nseg = nseg;
+    for (int g = 0; g < nseg; ++g) {
+        a.seg_ptr[g] = seg_ptr[g]; a.seg_channels[g] = seg_channels[g]; a.seg_pix_stride[g] = seg_pix_stride[g]; a.seg_up[g] = seg_up[g];
+        a.cin += seg_channels[g];
+    }
+    OM_REQUIRE(a.cin > 0 && a.cin % 32 == 0, OM_EINVAL, "om_conv2d_split_gather: %d input channels", a.cin);
+    a.Ho = H; a.Wo = W; a.cout = cout; a.cout_pad = om::round_up(cout, 32);
+    a.ks = 1; a.stride = 1; a.leaky = leaky; a.res_pix_stride = 0;
+    a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1;
+    a.status = status_dev;
     static int* g_ticket = nullptr;      // unit-test entry only (see om_conv2d_mode)
     if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), om::SYNC_WORDS * sizeof(int)));
     if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;

@@ -57,6 +57,7 @@ SIGNATURES = {
     "om_model_load_weights_split": (_i, [_vp, _vp, _sz]),
     "om_model_set_precision": (_i, [_vp, _i]),
     "om_model_get_precision": (_i, [_vp]),
+    "om_model_set_upsample_on_read": (_i, [_vp, _i]),
     "om_conv2d_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "om_conv2d_winograd24_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp, _vp]),
     "om_conv2d_wino14_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
@@ -88,6 +89,8 @@ SIGNATURES = {
     "om_conv2d_mode": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "om_conv2d_stem": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "om_conv2d_stem2_split": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
+    "om_conv2d_split_gather": (_i, [_i, ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), _i, _i, _i,
+                                    _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
     "om_preprocess": (_i, [_vp, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                            _i, _i, _i, _i, _f, _vp, _vp]),
     "om_pad_nchw": (_i, [_vp, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),

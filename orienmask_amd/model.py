@@ -246,6 +246,16 @@ class OrienMaskYOLOFPNPlus(nn.Module):
                        "om_model_load_weights_split")
         self._packed_split = blob
 
+    def set_upsample_on_read(self, enable=True):
+        """precision 'f32_split' only: True (default) = the routes and skips store one copy at their own resolution and the 1x1 layer
+        behind each concat (neck16.0 / neck8.0 / neck4.0) reads them up-sampled; False = they store their output replicated into
+        the concat buffer (what 'f32' and 'f16' do).  Bit-identical outputs; for A/B measurements and the test of that claim.
+        Drops the cached workspaces (their layout differs)."""
+        _lib.check(_lib.load().om_model_set_upsample_on_read(self._ensure_handle(), 1 if enable else 0), "om_model_set_upsample_on_read")
+        self._workspace.clear()
+        self._slot_workspaces.clear()
+        return self
+
     def set_streams(self, n):
         """Run forward() as n independent sub-batches on n side HIP streams (batch divisible by n, else one launch).
         Tile-queue tails and per-tile prologues of one sub-batch overlap the other's kernels: +9 % forward throughput in
@@ -426,7 +436,8 @@ class OrienMaskYOLOFPNPlus(nn.Module):
             fmt = {0: "conv_stem_kernel", 1: "conv_igemm_f32_kernel<%d,%d>", 2: "wino_gemm_kernel<%d,%d>",
                    3: "wino_fused_kernel<%d,%d>", 5: "wino24_gemm_kernel<%d,%d>", 6: "wino24_gemm_kernel<%d,%d,split>",
                    7: "conv_igemm_split_kernel<%d,%d>", 8: "wino14_split_kernel<%d,%d>",
-                   9: "conv_stem2_split_kernel<%d,%d>", 10: "(in the previous layer's kernel)"}[algo.value]
+                   9: "conv_stem2_split_kernel<%d,%d>", 10: "(in the previous layer's kernel)",
+                   11: "conv_igemm_split_kernel<%d,%d,gather>"}[algo.value]
             out.append((l["name"], fmt % ((bm.value, bn.value) if algo.value not in (0, 10) else ())))
         return out
 

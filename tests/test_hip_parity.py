@@ -321,6 +321,80 @@ def test_conv_split_wide_rows_equal_narrow(dev, case):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("case", [
+    # (B, H, W, cout, [(channels, up, pixel stride), ...]): neck4.0's four slices; neck16.0's route + feature (the feature a slice of
+    # a wider buffer); one segment; a partial last M tile with three segments
+    (2, 136, 136, 128, [(64, 8, 64), (64, 4, 64), (64, 2, 64), (64, 1, 256)]),
+    (3, 34, 34, 256, [(256, 2, 256), (512, 1, 768)]),
+    (1, 16, 16, 128, [(32, 4, 32)]),
+    (5, 12, 20, 128, [(32, 1, 32), (96, 4, 96), (32, 2, 48)]),
+])
+def test_conv_split_gather_equals_materialised_concat(dev, case):
+    """om_conv2d_split_gather (the 1x1 layer reading up-sampled slices where their producers stored them: what om_forward runs for
+    neck16.0 / neck8.0 / neck4.0 in split-operand mode) against om_conv2d_split over torch's nearest up-sample + cat of the same
+    slices (orienmask_yolo_fpnplus.py:78-86): the same products in the same order -- bit-identical."""
+    from orienmask_amd.pack import conv_weights_split
+    B, H, W, cout, segs = case
+    L = omlib.load()
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    cin = sum(c for c, _, _ in segs)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    ws, e = conv_weights_split(w, cout)
+    wd = ws.to(dev)
+    sp = torch.pow(torch.tensor(2.0), -e.float()).to(dev)
+    hp = (torch.randn(cout, generator=g) * 0.2).to(dev)
+    bufs, views, parts = [], [], []
+    for c, up, ps in segs:
+        buf = torch.randn(B, H // up, W // up, ps, generator=g).to(dev)
+        off = ps - c                                       # the slice sits at the END of its buffer's pixel
+        bufs.append(buf)
+        views.append(buf.view(-1)[off:])
+        parts.append(buf[..., off:].repeat_interleave(up, 1).repeat_interleave(up, 2))
+    cat = torch.cat(parts, -1).contiguous()
+    assert cat.shape == (B, H, W, cin)
+    want = torch.full((B, H, W, cout), float("nan"), device=dev)
+    omlib.check(L.om_conv2d_split(_p(cat), B, H, W, cin, cin, _p(wd), _p(sp), _p(hp), cout, 1, 1, 1, None, 0, _p(want), cout, 0, 1,
+                                  0, 0, None, omlib.current_stream_ptr(dev)), "om_conv2d_split")
+    got = torch.full((B, H, W, cout), float("nan"), device=dev)
+    n = len(segs)
+    ptrs = (ctypes.c_void_p * n)(*[v.data_ptr() for v in views])
+    ints = lambda vals: (ctypes.c_int * n)(*vals)
+    omlib.check(L.om_conv2d_split_gather(n, ptrs, ints([c for c, _, _ in segs]), ints([ps for _, _, ps in segs]),
+                                         ints([up for _, up, _ in segs]), B, H, W, _p(wd), _p(sp), _p(hp), cout, 1, _p(got), cout,
+                                         None, omlib.current_stream_ptr(dev)), "om_conv2d_split_gather")
+    torch.cuda.synchronize()
+    assert torch.isfinite(want).all()
+    assert torch.equal(got, want)
+    # refusals: a segment that is not whole 32-channel chunks, an up factor that does not divide the map
+    bad = L.om_conv2d_split_gather(1, ptrs, ints([48] + [32] * (n - 1)), ints([ps for _, _, ps in segs]), ints([1] * n), B, H, W,
+                                   _p(wd), _p(sp), _p(hp), cout, 1, _p(got), cout, None, omlib.current_stream_ptr(dev))
+    assert bad != 0
+
+
+def test_forward_gather_equals_replicated_concat(dev):
+    """Split-operand forward: the up-sampling-on-read form (routes and skips stored once at their own resolution, neck16.0 / neck8.0 /
+    neck4.0 gathering them) against the replicated-concat form of the same library (set_upsample_on_read(False): what the other
+    precisions run) -- all four heads bit-identical, bs=3 at 544x544 and a 64x96 image; keeping the activations
+    (om_layer_output_view reports slices of the concat buffers) also selects the replicated form."""
+    sd = synth.synth_state_dict(11, obj_bias=-16.0, head_gain=4.0)
+    for shape, seed in (((3, 544, 544), 31), ((2, 64, 96), 32)):
+        x = synth.synth_image_batch(seed, *shape).to(dev)
+        net = _hip_model(sd, dev).set_precision("f32_split")
+        kinds = dict(net.layer_kernels(*shape))
+        assert "gather" in kinds["neck4.0"] and "gather" in kinds["neck8.0"] and "gather" in kinds["neck16.0"]
+        with torch.no_grad():
+            got = [(a.clone(), b.clone()) for a, b in net(x)]
+            net.set_upsample_on_read(False)
+            assert "gather" not in dict(net.layer_kernels(*shape))["neck4.0"]
+            want = [(a.clone(), b.clone()) for a, b in net(x)]
+            net.set_upsample_on_read(True).keep_activations(True)
+            assert "gather" not in dict(net.layer_kernels(*shape))["neck4.0"]
+        torch.cuda.synchronize()
+        for (ga, gb), (wa, wb) in zip(got, want):
+            assert torch.isfinite(wa).all() and torch.isfinite(wb).all()
+            assert torch.equal(ga, wa) and torch.equal(gb, wb)
+
+
 @pytest.mark.parametrize("mode", ["upsample", "nchw"])
 def test_conv_split_output_modes(dev, mode):
     """The split-operand kernel's other two epilogues: nearest up-sampling into a channel slice of a concat buffer, and the
