@@ -339,7 +339,9 @@ int om_recover_masks_rle(const uint8_t* mask, int K, int H, int W, int crop_top,
  * reference's call sites eval/orienmask_yolo_postprocess.py:127-136 (csrc/ref_math.h).  func: 0 = glibc expf (torch's
  * scalar loop), 1 = Sleef expf_u10 (torch's vectorised loop), 2 / 3 = sigmoid through either, 4 = sigmoid of a
  * [rows][num_classes] array exactly as predict[..., 5:].sigmoid() evaluates it (classes below (C/32)*32 vectorised, the
- * row tail scalar), 5 = correctly rounded expf. */
+ * row tail scalar), 5 = correctly rounded expf, 6 = the mask predicate's building block (post.hip: abs_minus_bits): y[i] = the IEEE
+ * difference |x[i]| - x[i ^ 1] (n even), whose SIGN decides |d| < t in post_mask_kernel -- the test checks the signs of the
+ * infinite and NaN cases on the device. */
 int om_ref_math(const float* x, long long n, int func, int num_classes, float* y, om_stream stream);
 
 /* ---- NMS: the reference's native export nms(dets[n,5], threshold) -> keep (eval/src/nms_cpu.cpp:65-75,

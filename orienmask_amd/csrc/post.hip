@@ -10,9 +10,14 @@
 //
 //   post_decode_kernel  grid (tiles, B)   conf = sigmoid(cls) * sigmoid(obj) for every
 //                       (candidate, class) pair; keys (float bits, 0 = below threshold) to the
-//                       workspace, per-tile pass counts, level-1 radix histogram.
-//   post_select_kernel  grid (B), 1024 thr  exact top-nms_pre by 3-level radix select on the key
-//                       bits (ties -> lowest pair index), index-ordered compaction, bitonic sort,
+//                       workspace, per-tile pass counts, level-1 radix histogram -- and the pairs that
+//                       pass, as (key, pair) words, appended to a per-image list (chip-wide compaction:
+//                       a few hundred to a few thousand of the 1.46 M pairs of a 544^2 image pass).
+//   post_select_kernel  grid (B), 1024 thr  the list, when it holds every passing pair (<= 4096), is
+//                       sorted in LDS: its head is the exact top-nms_pre (ties -> lowest pair index).
+//                       Otherwise (dense heads): 3-level radix select on the key bits over the image's
+//                       whole key array (three passes of 5.8 MB by one workgroup), index-ordered
+//                       compaction, bitonic sort.  Then
 //                       box decode of the <= nms_pre survivors, 64-bit suppression bit-matrix in LDS
 //                       (one u64 = one row segment of the reference's 64-wide CUDA tiling), serial
 //                       wave-level reduction, top-nms_post, per-detection mask constants.
@@ -35,6 +40,7 @@ constexpr int SEL_LDS_MASK_N = 512;     // up to this many candidates the suppre
                                         // it lives in the workspace (what the reference's CUDA backend always does)
 constexpr int L1_BINS = 2048;           // key >> 19
 constexpr int MASK_PX = 16;             // pixels per thread in the mask kernel
+constexpr int SEL_LIST_MAX = 4096;      // passing pairs per image the compacted list holds (= the u64 words of the LDS bit-matrix)
 
 struct PostParams {
     om_post_cfg cfg;
@@ -46,6 +52,8 @@ struct PostParams {
     unsigned* keys;        // [B][ntiles*DEC_TILE]
     int* tile_count;       // [B][ntiles]
     unsigned* hist1;       // [B][L1_BINS]
+    unsigned* list_count;  // [B] passing pairs of the image (zeroed with hist1); may exceed SEL_LIST_MAX: the list is then incomplete
+    unsigned long long* list;   // [B][SEL_LIST_MAX] (key << 32) | ~pair of the passing pairs, in no particular order
     float* det_par;        // [B][nms_post][8]
     unsigned long long* nms_mask;   // [B][SEL_MAXN * SEL_MAXN / 64], used when nms_pre > SEL_LDS_MASK_N
     float* out_bbox;
@@ -60,8 +68,10 @@ __device__ __forceinline__ void locate(const PostParams& p, int cand, int& s, in
     s = (cand >= p.cand_off[1]) + (cand >= p.cand_off[2]);
     const int local = cand - p.cand_off[s];
     const int hw = p.cfg.grid_h[s] * p.cfg.grid_w[s];
-    a = local / hw;
-    pix = local - a * hw;
+    // anchors_per_scale <= 3 (fill_params): the quotient local / hw by two compares instead of a 32-bit division
+    const int a1 = local >= hw, a2 = local >= 2 * hw;
+    a = a1 + a2;
+    pix = local - (a1 ? hw : 0) - (a2 ? hw : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -88,17 +98,21 @@ __global__ __launch_bounds__(256) void post_decode_kernel(const PostParams p) {
     }
     __syncthreads();
     unsigned* keys = p.keys + (size_t)b * p.ntiles * DEC_TILE + (size_t)tile * DEC_TILE;
+    unsigned long long* const list = p.list + (size_t)b * SEL_LIST_MAX;
     int cnt = 0;
+    // (candidate, class) of this thread's first pair by one division; the next pair is 256 further: + (256 / C, 256 % C) with a carry
+    const int dq = 256 / C, dr = 256 - dq * C;
+    int cand = (tile * DEC_TILE + tid) / C, cls = (tile * DEC_TILE + tid) - cand * C;
 #pragma unroll 2
     for (int j = 0; j < DEC_TILE / 256; ++j) {
         const int pair = tile * DEC_TILE + j * 256 + tid;
         unsigned key = 0;
         if (pair < p.npairs) {
-            const int cand = pair / C, cls = pair - cand * C;
             int s, a, pix;
             locate(p, cand, s, a, pix);
             const int hw = p.cfg.grid_h[s] * p.cfg.grid_w[s];
-            const float* q = p.bbox[s] + ((size_t)b * hw + pix) * p.cfg.bbox_pix_stride + a * per;
+            // b * hw + pix < 2^24 pixels per scale in the batch (om_postprocess checks), strides and a * per far below: 24-bit multiplies
+            const float* q = p.bbox[s] + (size_t)__umul24(__umul24(b, hw) + pix, p.cfg.bbox_pix_stride) + __umul24(a, per);
             const float conf = sigmoid_class_ref(q[5 + cls], cls, C, s_tab) * s_obj[cand - cand_first];
             if (conf > p.cfg.conf_thresh) {
                 key = __float_as_uint(conf);
@@ -107,6 +121,19 @@ __global__ __launch_bounds__(256) void post_decode_kernel(const PostParams p) {
             }
         }
         keys[j * 256 + tid] = key;
+        cand += dq; cls += dr;
+        if (cls >= C) { cls -= C; ++cand; }
+        // the passing pairs of this wave, appended to the image's list: one atomic per wave that has any
+        const unsigned long long pass = __ballot(key != 0);
+        if (pass) {
+            unsigned at = 0;
+            if ((tid & 63) == __ffsll((long long)pass) - 1) at = atomicAdd(&p.list_count[b], (unsigned)__popcll(pass));
+            at = __shfl(at, __ffsll((long long)pass) - 1);
+            if (key != 0) {
+                const unsigned slot = at + (unsigned)__popcll(pass & ((1ull << (tid & 63)) - 1ull));
+                if (slot < (unsigned)SEL_LIST_MAX) list[slot] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)pair);
+            }
+        }
     }
     // workgroup total
     for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d);
@@ -160,16 +187,17 @@ __device__ __forceinline__ void find_bin_from_top(const unsigned* hist, int nbin
     __syncthreads();
 }
 
-// Descending bitonic sort of n_pad (power of two, <= 1024) u64 values in LDS.
+// Descending bitonic sort of n_pad (power of two, any multiple of the workgroup or below it) u64 values in LDS.
 __device__ __forceinline__ void bitonic_sort_desc(unsigned long long* v, int n_pad) {
-    const int i = threadIdx.x;
     for (int k = 2; k <= n_pad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            const int partner = i ^ j;
-            if (i < n_pad && partner > i) {
-                const unsigned long long a = v[i], c = v[partner];
-                const bool desc = (i & k) == 0;
-                if (desc ? (a < c) : (a > c)) { v[i] = c; v[partner] = a; }
+            for (int i = threadIdx.x; i < n_pad; i += SEL_THREADS) {
+                const int partner = i ^ j;
+                if (partner > i) {
+                    const unsigned long long a = v[i], c = v[partner];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (a < c) : (a > c)) { v[i] = c; v[partner] = a; }
+                }
             }
             __syncthreads();
         }
@@ -276,17 +304,47 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
     const int nchunks = (p.ntiles + 1) / 2;       // chunk = 2 tiles = 4096 keys, 4 per thread
 
     // ---- how many pairs passed the threshold
-    int total;
-    {
-        int c = 0;
-        for (int t = tid; t < p.ntiles; t += SEL_THREADS) c += tcount[t];
-        block_scan_excl(c, s_wave, total);
-    }
+    const int total = (int)min(p.list_count[b], 0x7FFFFFFFu);
     if (total == 0) {
         if (tid == 0) p.out_count[b] = 0;
         return;
     }
+    const int n = total > nms_pre ? nms_pre : total;
+    // case A (more than nms_pre passed): the reference's list IS the sorted top-k, so list position = pi.
+    // case B: the reference's list is the index-ordered one, NMS visits it through the argsort.
+    const bool caseA = total > nms_pre;
+    const bool from_list = total <= SEL_LIST_MAX;      // the compacted list holds every passing pair
 
+    if (from_list) {
+        // ---- the image's passing pairs, (key << 32) | ~pair, sorted descending in LDS: score descending, ties by pair index
+        // ascending -- postprocess.py:102-122 (index-ordered nonzero(), then topk / argsort) visits them in exactly this order,
+        // and the first n are the selection (ties at the cut -> lowest pair index)
+        unsigned long long* const s_list = s_mask;      // the bit-matrix is built after the list is consumed
+        int l_pad = 64;
+        while (l_pad < total) l_pad <<= 1;
+        const unsigned long long* glist = p.list + (size_t)b * SEL_LIST_MAX;
+        for (int i = tid; i < l_pad; i += SEL_THREADS) s_list[i] = i < total ? glist[i] : 0ull;
+        __syncthreads();
+        bitonic_sort_desc(s_list, l_pad);
+        unsigned long long mine = 0ull;
+        int pos = tid;
+        if (tid < n) {
+            mine = s_list[tid];
+            if (!caseA) {      // list position = rank of the pair index among the n pairs (the index-ordered list of case B)
+                const unsigned my_lo = (unsigned)mine;
+                pos = 0;
+                for (int i = 0; i < n; ++i) pos += (unsigned)s_list[i] > my_lo;      // ~pair larger <=> pair smaller
+            }
+        }
+        __syncthreads();
+        if (tid < n) {
+            const unsigned key = (unsigned)(mine >> 32);
+            s_key[pos] = key;
+            s_pair[pos] = (int)(0xFFFFFFFFu - (unsigned)mine);
+            s_comp[tid] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)pos);
+        }
+        __syncthreads();
+    } else {
     // ---- exact threshold key T and number r of ties to take (3-level radix select on the bits)
     unsigned T = 0;      // take every key > T, plus the first r keys == T in index order
     int r = 0, above = total;
@@ -340,7 +398,6 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
         r = nms_pre - above;
         __syncthreads();
     }
-    const int n = total > nms_pre ? nms_pre : total;
 
     // ---- index-ordered compaction (row-major (candidate, class) order, postprocess.py:102)
     {
@@ -386,9 +443,7 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
         s_comp[tid] = tid < n ? (((unsigned long long)s_key[tid] << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)tid)) : 0ull;
     __syncthreads();
     bitonic_sort_desc(s_comp, n_pad);
-    // case A (more than nms_pre passed): the reference's list IS the sorted top-k, so list position = pi.
-    // case B: the reference's list is the index-ordered one, NMS visits it through the argsort.
-    const bool caseA = total > nms_pre;
+    }      // !from_list
 
     // ---- decode the survivors' boxes (postprocess.py:126-139) in visiting order
     if (tid < n) {
@@ -522,6 +577,17 @@ __device__ __forceinline__ float bil_row(float v0, float v1, float w0, float w1)
 //   both patterns are below 2^31, so the unsigned difference has its top bit set exactly when bits(a) < bits(t).
 // fp32 denormals are preserved in this library's kernels (.amdhsa_float_denorm_mode_32 3), like on the reference's CPU, so the
 // integer order also agrees for them.  The subtraction is inline asm so that the compiler cannot turn it back into a compare.
+//
+//
+// Round 3: six vector instructions per pixel and detection instead of nine (the kernel is bound by them: ~150 per 16-byte store)
+// for every detection whose thresholds are FINITE.  For a number t >= 0,  |d| < t  <=>  the IEEE difference |d| - t is negative:
+// a floating-point subtraction rounds monotonically and returns zero only for equal operands (denormal results are kept, see
+// above), inf - t = +inf, and a NaN d gives a NaN whose sign bit is clear (|NaN| carries no sign) -- "not inside", like the
+// compare.  So sign(|dx| - tx) AND sign(|dy| - ty) is the predicate: two subtractions with the absolute-value source modifier,
+// one AND, and the sign shifted into a per-four-pixels bit register by v_alignbit.  Inline asm so that the compiler cannot turn
+// the sign tests back into compares.  A threshold of +inf (a box size that overflowed) keeps the integer form above: inf - inf is
+// a NaN with the sign SET on this hardware (measured: tests/test_hip_parity.py::test_mask_predicate_sign_form), which would
+// read as "inside".
 __device__ __forceinline__ unsigned threshold_bits(float t) {
     const unsigned u = __float_as_uint(t);
     return u <= 0x7f800000u ? u : 0u;
@@ -533,6 +599,16 @@ __device__ __forceinline__ unsigned sub_u32_opaque(unsigned a, unsigned b) {
 }
 __device__ __forceinline__ unsigned inside_bit(unsigned ax, unsigned tx, unsigned ay, unsigned ty) {
     return (sub_u32_opaque(ax, tx) & sub_u32_opaque(ay, ty)) >> 31;
+}
+__device__ __forceinline__ unsigned abs_minus_bits(float d, float t) {      // bits(|d| - t)
+    unsigned r;
+    asm("v_sub_f32_e64 %0, |%1|, %2" : "=v"(r) : "v"(d), "v"(t));
+    return r;
+}
+__device__ __forceinline__ unsigned shift_in_sign(unsigned acc, unsigned m) {      // (acc << 1) | (m >> 31)
+    unsigned r;
+    asm("v_alignbit_b32 %0, %1, %2, 31" : "=v"(r) : "v"(acc), "v"(m));
+    return r;
 }
 
 __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
@@ -655,13 +731,26 @@ __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
             const float4 d = s_det[i];                                     // uniform: one LDS broadcast
             const int k = s_slot[i];
             const float cx = d.x, cy = d.y;
-            const unsigned tx = __float_as_uint(d.z), ty = __float_as_uint(d.w);
+            const float tx = d.z, ty = d.w;      // threshold_bits: numbers >= 0 or +inf
             unsigned packed[4] = {0, 0, 0, 0};
+            if (__float_as_uint(tx) == 0x7f800000u || __float_as_uint(ty) == 0x7f800000u) {      // uniform; see abs_minus_bits
 #pragma unroll
-            for (int e = 0; e < MASK_PX; ++e) {
-                // inside = (|Px - cx| < tx) && (|Py - cy| < ty), evaluated on the bit patterns (see inside_bit)
-                const unsigned ax = __float_as_uint(Px[e] - cx) & 0x7fffffffu, ay = __float_as_uint(Py[e] - cy) & 0x7fffffffu;
-                packed[e >> 2] |= inside_bit(ax, tx, ay, ty) << ((e & 3) * 8);
+                for (int e = 0; e < MASK_PX; ++e) {
+                    const unsigned ax = __float_as_uint(Px[e] - cx) & 0x7fffffffu, ay = __float_as_uint(Py[e] - cy) & 0x7fffffffu;
+                    packed[e >> 2] |= inside_bit(ax, __float_as_uint(tx), ay, __float_as_uint(ty)) << ((e & 3) * 8);
+                }
+            } else
+#pragma unroll
+            for (int w4 = 0; w4 < MASK_PX / 4; ++w4) {
+                // inside = (|Px - cx| < tx) && (|Py - cy| < ty) by the signs of |d| - t (see abs_minus_bits); pixel 4 w4 + e -> bit e
+                unsigned bits = 0;
+#pragma unroll
+                for (int e = 3; e >= 0; --e) {
+                    const int px = 4 * w4 + e;
+                    bits = shift_in_sign(bits, abs_minus_bits(Px[px] - cx, tx) & abs_minus_bits(Py[px] - cy, ty));
+                }
+                // bit e -> byte e: the four shifted copies of a 4-bit value do not overlap (e + 7 k are distinct), so no carries
+                packed[w4] = __umul24(bits, 0x00204081u) & 0x01010101u;
             }
             uint4 o;
             o.x = packed[0]; o.y = packed[1]; o.z = packed[2]; o.w = packed[3];
@@ -802,6 +891,7 @@ __global__ void ref_math_kernel(const float* x, long long n, int func, int C, fl
         case 2: r = sigmoid_scalar_ref(v); break;
         case 3: r = sigmoid_vector_ref(v); break;
         case 4: r = sigmoid_class_ref(v, (int)(i % C), C); break;      // x is [rows][C] class logits
+        case 6: r = __uint_as_float(abs_minus_bits(v, x[i ^ 1])); break;   // the mask predicate's |x[i]| - x[i ^ 1], bit pattern returned
         default: r = expf_cr(v); break;
     }
     y[i] = r;
@@ -836,14 +926,15 @@ static int fill_params(const om_post_cfg* cfg, PostParams& p) {
     return OM_OK;
 }
 
-struct PostWs { size_t keys, tile_count, hist1, det_par, nms_mask, total; };
+struct PostWs { size_t keys, tile_count, hist1, list, det_par, nms_mask, total; };
 
 static PostWs post_ws_layout(const PostParams& p, int B) {
     PostWs w;
     size_t off = 0;
     w.keys = off; off += align_up((size_t)B * p.ntiles * DEC_TILE * sizeof(unsigned), 256);
     w.tile_count = off; off += align_up((size_t)B * p.ntiles * sizeof(int), 256);
-    w.hist1 = off; off += align_up((size_t)B * L1_BINS * sizeof(unsigned), 256);
+    w.hist1 = off; off += align_up(((size_t)B * L1_BINS + B) * sizeof(unsigned), 256);      // + list_count[B], zeroed together
+    w.list = off; off += align_up((size_t)B * SEL_LIST_MAX * sizeof(unsigned long long), 256);
     w.det_par = off; off += align_up((size_t)B * p.cfg.nms_post * 8 * sizeof(float), 256);
     w.nms_mask = off;
     if (p.cfg.nms_pre > SEL_LDS_MASK_N) off += align_up((size_t)B * SEL_MAXN * (SEL_MAXN / 64) * sizeof(unsigned long long), 256);
@@ -877,17 +968,24 @@ int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbo
                OM_EINVAL, "om_postprocess: workspace must be 256-byte and out_mask 16-byte aligned");
     OM_REQUIRE((long long)B * cfg->num_scales * cfg->anchors_per_scale < 65536, OM_EINVAL,
                "om_postprocess: B * scales * anchors_per_scale must be < 65536 (the mask kernel's grid.y)");
+    for (int sc = 0; sc < 3; ++sc)      // post_decode_kernel addresses the heads with 24-bit multiplies and 32-bit element offsets
+        OM_REQUIRE((long long)B * cfg->grid_h[sc] * cfg->grid_w[sc] < (1ll << 24) && cfg->bbox_pix_stride < (1 << 24) &&
+                       (long long)B * cfg->grid_h[sc] * cfg->grid_w[sc] * cfg->bbox_pix_stride < (1ll << 31),
+                   OM_EINVAL, "om_postprocess: B=%d x grid %dx%d x pixel stride %d is beyond the decode kernel's 32-bit offsets", B,
+                   cfg->grid_h[sc], cfg->grid_w[sc], cfg->bbox_pix_stride);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     char* base = static_cast<char*>(workspace);
     p.bbox[0] = bbox32; p.bbox[1] = bbox16; p.bbox[2] = bbox8; p.oriens = oriens; p.B = B;
     p.keys = reinterpret_cast<unsigned*>(base + w.keys);
     p.tile_count = reinterpret_cast<int*>(base + w.tile_count);
     p.hist1 = reinterpret_cast<unsigned*>(base + w.hist1);
+    p.list_count = p.hist1 + (size_t)B * om::L1_BINS;
+    p.list = reinterpret_cast<unsigned long long*>(base + w.list);
     p.det_par = reinterpret_cast<float*>(base + w.det_par);
     p.nms_mask = reinterpret_cast<unsigned long long*>(base + w.nms_mask);
     p.out_bbox = out_bbox; p.out_cls = out_cls; p.out_mask = out_mask; p.out_count = out_count; p.out_keep = out_keep;
 
-    if (int rc = om::launch_zero_words(p.hist1, (size_t)B * om::L1_BINS, stream)) return rc;
+    if (int rc = om::launch_zero_words(p.hist1, (size_t)B * om::L1_BINS + B, stream)) return rc;
     hipLaunchKernelGGL(om::post_decode_kernel, dim3(p.ntiles, B), dim3(256), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(om::post_select_kernel, dim3(B), dim3(om::SEL_THREADS), 0, stream, p);
@@ -915,7 +1013,8 @@ int om_post_kernel_occupancy(int which, int* threads, int* vgprs, int* lds_bytes
 }
 
 int om_ref_math(const float* x, long long n, int func, int num_classes, float* y, om_stream stream_) {
-    OM_REQUIRE(x && y && n >= 0 && func >= 0 && func <= 5 && num_classes >= 1, OM_EINVAL, "om_ref_math: bad argument");
+    OM_REQUIRE(x && y && n >= 0 && func >= 0 && func <= 6 && num_classes >= 1 && (func != 6 || n % 2 == 0), OM_EINVAL,
+               "om_ref_math: bad argument");
     if (n == 0) return OM_OK;
     hipLaunchKernelGGL(om::ref_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), x, n,
                        func, num_classes, y);

@@ -1010,6 +1010,67 @@ def test_ref_math_bit_exact(dev):
     torch.set_num_threads(nthreads)
 
 
+def test_mask_predicate_sign_form(dev):
+    """post_mask_kernel decides |d| < t for FINITE thresholds by the SIGN of the IEEE difference |d| - t (six vector instructions
+    per pixel instead of nine).  For every pair below, incl. infinite and NaN d of both signs, zeros and denormals: sign set <=>
+    numpy's abs(d) < t.  The one exception, which is why an infinite threshold takes the kernel's integer form: inf - inf is a NaN
+    with the sign SET on this hardware."""
+    L = omlib.load()
+    inf, nan = np.inf, np.nan
+    nnan = np.array([0xffc00001], dtype=np.uint32).view(np.float32)[0]
+    den = np.float32(1e-45)
+    d = np.array([0.5, -0.5, 0.25, -0.75, 0.0, -0.0, 0.0, inf, -inf, inf, -inf, nan, nnan, nan, nnan, 1.0, den, -den, 2 * den, 3.0e38,
+                  -3.4028235e38, 1.0000001, 1.0, 0.99999994], dtype=np.float32)
+    t = np.array([0.5, 0.5, 0.5, 0.5, 0.0, 0.0, den, inf, inf, 1.0, 1.0, 1.0, 1.0, inf, inf, inf, 2 * den, den, den, inf,
+                  inf, 1.0, 1.0, 1.0], dtype=np.float32)
+    rng = np.random.Generator(np.random.PCG64(9))
+    d = np.concatenate([d, rng.normal(0, 1, 4096).astype(np.float32)])
+    t = np.concatenate([t, np.abs(rng.normal(0, 1, 4096)).astype(np.float32)])
+    t[-64:] = np.abs(d[-64:])                      # equal magnitudes: not inside
+    xy = np.stack([d, t], 1).reshape(-1).copy()
+    xd = torch.from_numpy(xy).to(dev)
+    out = torch.empty_like(xd)
+    omlib.check(L.om_ref_math(_p(xd), xd.numel(), 6, 1, _p(out), omlib.current_stream_ptr(dev)), "om_ref_math")
+    bits = out.cpu().numpy().view(np.uint32)[0::2]
+    with np.errstate(invalid="ignore"):
+        want = np.abs(d) < t
+    finite_t = np.isfinite(t) | ~np.isinf(d)            # every case but (|d| = inf, t = inf)
+    got = bits >> 31 == 1
+    assert np.array_equal(got[finite_t], want[finite_t]), (d[finite_t][got[finite_t] != want[finite_t]], t[finite_t][got[finite_t] != want[finite_t]])
+    assert got[~finite_t].all() and not want[~finite_t].any() and (~finite_t).sum() == 2      # the documented exception
+
+
+def test_postprocess_overflowed_box_width(dev):
+    """A box whose width overflows to +inf (tw = 100 on the best candidate): its mask thresholds are infinite, which
+    post_mask_kernel evaluates in the integer form (test_mask_predicate_sign_form); NMS sees infinite corners.  Same detections,
+    same order, identical masks as the oracle; the infinite width reported as such."""
+    size = (160, 192)
+    pc = post_cfg(size)
+    heads = synth.synth_heads(103, 2, pc["grid_size"], regime="sparse")
+    bb = heads[2][0]
+    t = bb[0].view(3, 85, *bb.shape[-2:])
+    conf = torch.sigmoid(t[:, 5:]).amax(1) * torch.sigmoid(t[:, 4])
+    a, y, x = np.unravel_index(int(conf.argmax()), conf.shape)
+    t[a, 2, y, x] = 100.0
+    oracle = R.PostProcessOracle(pc["grid_size"], pc["image_size"], pc["anchors"], pc["anchor_mask"], 80,
+                                 conf_thresh=pc["conf_thresh"])
+    want = oracle(heads)
+    post = _hip_post(size, dev)
+    got = post(tuple((b.to(dev), o.to(dev)) for b, o in heads))
+    assert torch.isinf(want[0]["bbox"][:, 2]).sum() == 1
+    for b, (r, w) in enumerate(zip(got, want)):
+        gb, wb = r["bbox"].cpu().numpy(), w["bbox"].numpy()
+        assert gb.shape == wb.shape and torch.equal(r["cls"].cpu(), w["cls"]) and torch.equal(post.last_keep[b].cpu().long(), w["keep"])
+        assert np.array_equal(np.isinf(gb), np.isinf(wb))
+        assert np.array_equal(gb[:, [0, 1, 4]], wb[:, [0, 1, 4]])
+        fin = np.isfinite(wb[:, 2:4])
+        assert _ulps(gb[:, 2:4][fin], wb[:, 2:4][fin]).max() <= 2
+        assert torch.equal(r["mask"].cpu(), w["mask"].bool()), b
+        k = int(np.flatnonzero(np.isinf(wb[:, 2]))[0]) if b == 0 else None
+        if k is not None:
+            assert w["mask"][k].any() and w["mask"][k].any(0).sum() > 1      # a mask that exists, wider than one column
+
+
 def test_postprocess_full_size_batch_properties(dev):
     """bs=32 at 544x544 (BASELINE.json configs[2]): per-image results equal the single-image run
     bit for bit; counts bounded; masks only inside [0,1]."""
