@@ -9,8 +9,9 @@
 // nms_kernel.cu:105-139) and materialises ~1 GB of temporaries per image; here it is three launches:
 //
 //   post_decode_kernel  grid (tiles, B)   conf = sigmoid(cls) * sigmoid(obj) for every
-//                       (candidate, class) pair; keys (float bits, 0 = below threshold) to the
-//                       workspace, per-tile pass counts, level-1 radix histogram -- and the pairs that
+//                       (candidate, class) pair; keys (float bits, 0 = below threshold) of the tiles
+//                       that have a passing pair to the workspace, per-tile pass counts, level-1 radix
+//                       histogram -- and the pairs that
 //                       pass, as (key, pair) words, appended to a per-image list (chip-wide compaction:
 //                       a few hundred to a few thousand of the 1.46 M pairs of a 544^2 image pass).
 //   post_select_kernel  grid (B), 1024 thr  the list, when it holds every passing pair (<= 4096), is
@@ -28,6 +29,8 @@
 // All comparisons that decide indices use IEEE fp32 operations in the reference's order; this file
 // is compiled with -ffp-contract=off and the only fused multiply-adds are the explicit fmaf calls of
 // the bilinear taps (the placement torch's CPU kernel compiles to; see oracle/orienmask_ref.py).
+#include <type_traits>
+
 #include "om_common.h"
 #include "ref_math.h"
 
@@ -40,6 +43,7 @@ constexpr int SEL_LDS_MASK_N = 512;     // up to this many candidates the suppre
                                         // it lives in the workspace (what the reference's CUDA backend always does)
 constexpr int L1_BINS = 2048;           // key >> 19
 constexpr int MASK_PX = 16;             // pixels per thread in the mask kernel
+constexpr int DEC_VISITS = 10;          // visits per thread and sweep of the decode kernel: (DEC_TILE / C + 2) * max(CV, CS) <= 2560 for C <= 251
 constexpr int SEL_LIST_MAX = 4096;      // passing pairs per image the compacted list holds (= the u64 words of the LDS bit-matrix)
 
 struct PostParams {
@@ -82,48 +86,71 @@ __global__ __launch_bounds__(256) void post_decode_kernel(const PostParams p) {
     __shared__ int wcnt[4];
     __shared__ unsigned long long s_tab[32];     // glibc's 2^(k/32) table (ref_math.h), indexed per lane
     __shared__ float s_obj[DEC_TILE + 2];       // sigmoid(objectness) of the candidates this tile touches
+    __shared__ __attribute__((aligned(16))) unsigned s_keys[DEC_TILE];      // the tile's keys; they reach memory only if one of them passed
+    __shared__ int s_any;
     const int tid = threadIdx.x, b = blockIdx.y, tile = blockIdx.x;
-    for (int i = tid; i < L1_BINS; i += 256) hist[i] = 0;
     if (tid < 32) s_tab[tid] = kExp2fTab[tid];
+    if (tid == 0) s_any = 0;
     __syncthreads();
     const int C = p.cfg.num_classes, per = 5 + C;
-    // sigmoid(obj) once per candidate (postprocess.py:128: a strided view -> torch's scalar loop -> glibc expf)
-    const int cand_first = (tile * DEC_TILE) / C;
-    const int cand_last = min(p.ncand - 1, (tile * DEC_TILE + DEC_TILE - 1) / C);
-    for (int i = tid; i <= cand_last - cand_first; i += 256) {
-        int s, a, pix;
-        locate(p, cand_first + i, s, a, pix);
-        const int hw = p.cfg.grid_h[s] * p.cfg.grid_w[s];
-        s_obj[i] = sigmoid_scalar_ref(p.bbox[s][((size_t)b * hw + pix) * p.cfg.bbox_pix_stride + a * per + 4], s_tab);
-    }
-    __syncthreads();
-    unsigned* keys = p.keys + (size_t)b * p.ntiles * DEC_TILE + (size_t)tile * DEC_TILE;
+    const int P0 = tile * DEC_TILE, P1 = min(P0 + DEC_TILE, p.npairs);      // this tile's pairs
+    const int cand_first = P0 / C;
+    const int cand_last = min(p.ncand - 1, (P0 + DEC_TILE - 1) / C);
+    const int ncand_t = cand_last - cand_first + 1;
     unsigned long long* const list = p.list + (size_t)b * SEL_LIST_MAX;
     int cnt = 0;
-    // (candidate, class) of this thread's first pair by one division; the next pair is 256 further: + (256 / C, 256 % C) with a carry
-    const int dq = 256 / C, dr = 256 - dq * C;
-    int cand = (tile * DEC_TILE + tid) / C, cls = (tile * DEC_TILE + tid) - cand * C;
-#pragma unroll 2
-    for (int j = 0; j < DEC_TILE / 256; ++j) {
-        const int pair = tile * DEC_TILE + j * 256 + tid;
+    // One (candidate, class) pair in two steps, so that a sweep can have ALL its loads in flight before the first sigmoid (a
+    // workgroup is a few microseconds of work behind one dependent load per visit: the kernel was bound by exactly that latency).
+    // fetch: the class logit, or 0 for a lane whose pair is not this tile's;  finish: confidence, threshold, key into LDS, histogram,
+    // and the wave's passing pairs appended to the image's list (one atomic per wave that has any).  Called by whole waves.
+    // A candidate whose objectness is not above the threshold cannot pass in any class: conf = fl(sigmoid(cls) * sigmoid(obj)) with
+    // sigmoid(cls) <= 1, and rounding is monotone, so conf <= sigmoid(obj) <= conf_thresh (a NaN is "not above" either way).  Its
+    // class logits are neither loaded nor evaluated -- on real heads that is nearly every candidate (background cells), and in
+    // the vectorised sweep a wave is one candidate, so the skip is a whole-wave branch.
+    const float thr = p.cfg.conf_thresh;
+    auto in_tile = [&](int cand_l, int cls, bool live) {
+        const int pair = (cand_first + cand_l) * C + cls;
+        return live && pair >= P0 && pair < P1 && s_obj[cand_l] > thr;
+    };
+    // The per-scale constants by STATIC index into the parameter block (scalar loads, once) and selects: p.bbox[s] with a run-time s
+    // is a memory load per visit, and the logit's load then waits for it -- one dependent round trip per visit again.
+    const int off1 = p.cand_off[1], off2 = p.cand_off[2];
+    const int hw0 = p.cfg.grid_h[0] * p.cfg.grid_w[0], hw1 = p.cfg.grid_h[1] * p.cfg.grid_w[1], hw2 = p.cfg.grid_h[2] * p.cfg.grid_w[2];
+    const float* const bb0 = p.bbox[0];
+    const float* const bb1 = p.bbox[1];
+    const float* const bb2 = p.bbox[2];
+    const int pstride = p.cfg.bbox_pix_stride;
+    typedef const __attribute__((address_space(1))) float* global_f32;      // (the blend below loses the pointers' address space)
+    auto logit_ptr = [&](int cand) -> global_f32 {      // element 0 of the candidate's 5 + C values
+        // blends by masks (cand >= off2 implies cand >= off1), not selects: the compiler turns a select chain over the three scales
+        // into a table in scratch memory indexed by the scale -- a dependent load per visit, which is what this kernel must not have
+        const int m1 = -(int)(cand >= off1), m2 = -(int)(cand >= off2);
+        const int local = cand - (off1 & m1) - ((off2 - off1) & m2);
+        const int hw = hw0 + ((hw1 - hw0) & m1) + ((hw2 - hw1) & m2);
+        const global_f32 base = (global_f32)(reinterpret_cast<uintptr_t>(bb0) +
+                                             ((reinterpret_cast<uintptr_t>(bb1) - reinterpret_cast<uintptr_t>(bb0)) & (uintptr_t)(long long)m1) +
+                                             ((reinterpret_cast<uintptr_t>(bb2) - reinterpret_cast<uintptr_t>(bb1)) & (uintptr_t)(long long)m2));
+        const bool a1 = local >= hw, a2 = local >= 2 * hw;      // anchors_per_scale <= 3
+        const int pix = local - (a1 ? hw : 0) - (a2 ? hw : 0);
+        // b * hw + pix < 2^24 pixels per scale in the batch (om_postprocess checks), strides and a * per far below: 24-bit multiplies
+        return base + (size_t)__umul24(__umul24(b, hw) + pix, pstride) + __umul24((int)a1 + (int)a2, per);
+    };
+    auto fetch = [&](int cand_l, int cls, bool live) -> float {
+        if (!in_tile(cand_l, cls, live)) return 0.f;
+        return logit_ptr(cand_first + cand_l)[5 + cls];
+    };
+    auto finish = [&](int cand_l, int cls, bool live, float x, auto vector_path) {
+        const int pair = (cand_first + cand_l) * C + cls;
         unsigned key = 0;
-        if (pair < p.npairs) {
-            int s, a, pix;
-            locate(p, cand, s, a, pix);
-            const int hw = p.cfg.grid_h[s] * p.cfg.grid_w[s];
-            // b * hw + pix < 2^24 pixels per scale in the batch (om_postprocess checks), strides and a * per far below: 24-bit multiplies
-            const float* q = p.bbox[s] + (size_t)__umul24(__umul24(b, hw) + pix, p.cfg.bbox_pix_stride) + __umul24(a, per);
-            const float conf = sigmoid_class_ref(q[5 + cls], cls, C, s_tab) * s_obj[cand - cand_first];
-            if (conf > p.cfg.conf_thresh) {
+        if (in_tile(cand_l, cls, live)) {
+            const float conf = (decltype(vector_path)::value ? sigmoid_vector_ref(x) : sigmoid_scalar_ref(x, s_tab)) * s_obj[cand_l];
+            if (conf > thr) {
                 key = __float_as_uint(conf);
                 atomicAdd(&hist[key >> 19], 1u);
                 ++cnt;
+                s_keys[pair - P0] = key;
             }
         }
-        keys[j * 256 + tid] = key;
-        cand += dq; cls += dr;
-        if (cls >= C) { cls -= C; ++cand; }
-        // the passing pairs of this wave, appended to the image's list: one atomic per wave that has any
         const unsigned long long pass = __ballot(key != 0);
         if (pass) {
             unsigned at = 0;
@@ -134,7 +161,56 @@ __global__ __launch_bounds__(256) void post_decode_kernel(const PostParams p) {
                 if (slot < (unsigned)SEL_LIST_MAX) list[slot] = ((unsigned long long)key << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)pair);
             }
         }
+    };
+    // torch evaluates a row of C class logits with its vectorised sigmoid (Sleef) for the first CV = (C / 32) * 32 classes and
+    // with the scalar one (glibc) for the tail (ref_math.h: sigmoid_class_ref).  In pair order every wave would hold classes of
+    // both kinds and execute both functions; the tile's pairs are therefore visited in two sweeps, the vectorised classes of
+    // its candidates (whole waves: CV is a multiple of 32, the sweep is padded to one of 64) and then the scalar tails.  One
+    // division per thread and sweep; the next visit is 256 items further: + (256 / n, 256 % n) with a carry.
+    // A sweep has at most DEC_VISITS visits per thread (n_c <= DEC_TILE / C + 2 candidates: the host checks the bound).
+    const int CV = C & ~31, CS = C - CV;
+    float xv[DEC_VISITS], xs[DEC_VISITS];
+    // (plain unrolled loops with compile-time indices: the arrays must stay in registers)
+#define OM_DEC_STEP(n_per) { cand_l += dq; cls += dr; if (cls >= (n_per)) { cls -= (n_per); ++cand_l; } }
+#define OM_DEC_FETCH(n_per, cls0, x)                                                              \
+    if ((n_per) != 0) {                                                                           \
+        const int n = ncand_t * (n_per), dq = 256 / (n_per), dr = 256 - dq * (n_per);             \
+        int cand_l = tid / (n_per), cls = tid - cand_l * (n_per);                                 \
+        _Pragma("unroll") for (int v = 0; v < DEC_VISITS; ++v) {                                  \
+            x[v] = fetch(cand_l, (cls0) + cls, tid + 256 * v < n);                                \
+            OM_DEC_STEP(n_per)                                                                    \
+        }                                                                                         \
     }
+#define OM_DEC_FINISH(n_per, cls0, x, vector_path)                                                \
+    if ((n_per) != 0) {                                                                           \
+        const int n = ncand_t * (n_per), n_pad = (n + 63) & ~63, dq = 256 / (n_per), dr = 256 - dq * (n_per); \
+        int cand_l = tid / (n_per), cls = tid - cand_l * (n_per);                                 \
+        _Pragma("unroll") for (int v = 0; v < DEC_VISITS; ++v) {                                  \
+            if (tid + 256 * v < n_pad) finish(cand_l, (cls0) + cls, tid + 256 * v < n, x[v], vector_path);   /* wave-uniform */ \
+            OM_DEC_STEP(n_per)                                                                    \
+        }                                                                                         \
+    }
+    // sigmoid(obj) once per candidate (postprocess.py:128: a strided view -> torch's scalar loop -> glibc expf)
+    for (int i = tid; i < ncand_t; i += 256) {
+        const float so = sigmoid_scalar_ref(logit_ptr(cand_first + i)[4], s_tab);
+        s_obj[i] = so;
+        if (so > thr) s_any = 1;
+    }
+    __syncthreads();
+    if (!s_any) {      // no candidate of this tile can pass (the usual case on real heads): no keys, no histogram
+        if (tid == 0) p.tile_count[b * p.ntiles + tile] = 0;
+        return;
+    }
+    for (int i = tid; i < L1_BINS; i += 256) hist[i] = 0;
+    for (int i = tid; i < DEC_TILE; i += 256) s_keys[i] = 0;      // pairs beyond npairs (last tile) stay 0
+    __syncthreads();
+    OM_DEC_FETCH(CV, 0, xv)
+    OM_DEC_FETCH(CS, CV, xs)
+    OM_DEC_FINISH(CV, 0, xv, std::true_type{})
+    OM_DEC_FINISH(CS, CV, xs, std::false_type{})
+#undef OM_DEC_FINISH
+#undef OM_DEC_FETCH
+#undef OM_DEC_STEP
     // workgroup total
     for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d);
     if ((tid & 63) == 0) wcnt[tid >> 6] = cnt;
@@ -142,6 +218,9 @@ __global__ __launch_bounds__(256) void post_decode_kernel(const PostParams p) {
     const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     if (tid == 0) p.tile_count[b * p.ntiles + tile] = total;
     if (total) {
+        // the select kernel's radix passes (dense heads only) read the keys of the tiles with tile_count > 0, nothing else
+        uint4* keys = reinterpret_cast<uint4*>(p.keys + (size_t)b * p.ntiles * DEC_TILE + (size_t)tile * DEC_TILE);
+        for (int i = tid; i < DEC_TILE / 4; i += 256) keys[i] = reinterpret_cast<const uint4*>(s_keys)[i];
         unsigned* g = p.hist1 + (size_t)b * L1_BINS;
         for (int i = tid; i < L1_BINS; i += 256)
             if (hist[i]) atomicAdd(&g[i], hist[i]);
@@ -362,7 +441,7 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
         for (int ch = 0; ch < nchunks; ++ch) {
             const int t0 = ch * 2, t1i = min(ch * 2 + 1, p.ntiles - 1);
             if (tcount[t0] + tcount[t1i] == 0) continue;
-            if (ch * 4096 + tid * 4 < p.ntiles * DEC_TILE) {
+            if (ch * 4096 + tid * 4 < p.ntiles * DEC_TILE && tcount[ch * 2 + (tid >> 9)] > 0) {      // a tile without a pass has no keys in memory
                 const uint4 k4 = *reinterpret_cast<const uint4*>(keys + (size_t)ch * 4096 + tid * 4);
                 const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
@@ -383,7 +462,7 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
         for (int ch = 0; ch < nchunks; ++ch) {
             const int t0 = ch * 2, t1i = min(ch * 2 + 1, p.ntiles - 1);
             if (tcount[t0] + tcount[t1i] == 0) continue;
-            if (ch * 4096 + tid * 4 < p.ntiles * DEC_TILE) {
+            if (ch * 4096 + tid * 4 < p.ntiles * DEC_TILE && tcount[ch * 2 + (tid >> 9)] > 0) {      // a tile without a pass has no keys in memory
                 const uint4 k4 = *reinterpret_cast<const uint4*>(keys + (size_t)ch * 4096 + tid * 4);
                 const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
@@ -406,7 +485,7 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
             const int t0 = ch * 2, t1i = min(ch * 2 + 1, p.ntiles - 1);
             if (tcount[t0] + tcount[t1i] == 0) continue;
             unsigned kk[4] = {0, 0, 0, 0};
-            if (ch * 4096 + tid * 4 < p.ntiles * DEC_TILE) {
+            if (ch * 4096 + tid * 4 < p.ntiles * DEC_TILE && tcount[ch * 2 + (tid >> 9)] > 0) {
                 const uint4 k4 = *reinterpret_cast<const uint4*>(keys + (size_t)ch * 4096 + tid * 4);
                 kk[0] = k4.x; kk[1] = k4.y; kk[2] = k4.z; kk[3] = k4.w;
             }
@@ -923,6 +1002,11 @@ static int fill_params(const om_post_cfg* cfg, PostParams& p) {
     OM_REQUIRE(npairs < (1ll << 30), OM_EINVAL, "postprocess: too many (candidate, class) pairs");
     p.npairs = (int)npairs;
     p.ntiles = (p.npairs + DEC_TILE - 1) / DEC_TILE;
+    {      // post_decode_kernel: a sweep visits (candidates of a tile) x (vectorised or scalar classes) items, DEC_VISITS per thread
+        const int C = cfg->num_classes, CV = C & ~31, CS = C - CV;
+        OM_REQUIRE(((DEC_TILE - 1) / C + 2) * (CV > CS ? CV : CS) + 63 <= 256 * DEC_VISITS, OM_EINVAL,
+                   "postprocess: num_classes=%d needs more than %d visits per decode thread", C, DEC_VISITS);
+    }
     return OM_OK;
 }
 

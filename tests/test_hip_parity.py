@@ -1040,6 +1040,27 @@ def test_mask_predicate_sign_form(dev):
     assert got[~finite_t].all() and not want[~finite_t].any() and (~finite_t).sum() == 2      # the documented exception
 
 
+def test_postprocess_radix_path_skips_tiles_without_keys(dev):
+    """conf_thresh = 1e-5 on clustered heads: ~34 000 pairs of an image pass (more than the compacted list holds, so the select kernel
+    takes its three-pass radix path over the key array) while some 2048-pair tiles have no passing pair -- the decode kernel does
+    not write those tiles' keys.  The workspace is first filled with the keys of an all-pass run (dense heads), so a tile read by
+    mistake would inject stale keys.  Same candidates, classes, order and masks as the oracle."""
+    size = (160, 192)
+    pc = post_cfg(size)
+    post = _hip_post(size, dev, conf_thresh=1e-5)
+    dense = synth.synth_heads(105, 3, pc["grid_size"], regime="dense")
+    post(tuple((b.to(dev), o.to(dev)) for b, o in dense))
+    heads = synth.synth_heads(102, 3, pc["grid_size"], regime="clustered")
+    oracle = R.PostProcessOracle(pc["grid_size"], pc["image_size"], pc["anchors"], pc["anchor_mask"], 80, conf_thresh=1e-5)
+    want = oracle(heads)
+    got = post(tuple((b.to(dev), o.to(dev)) for b, o in heads))
+    for b, (r, w) in enumerate(zip(got, want)):
+        assert r["bbox"].shape[0] == w["bbox"].shape[0] > 0, b
+        assert torch.equal(r["cls"].cpu(), w["cls"])
+        assert torch.equal(post.last_keep[b].cpu().long(), w["keep"])
+        _check_detections(r, w["bbox"].numpy(), w["cls"].numpy(), w["mask"].numpy(), ("radix path", b), exact_decode=True)
+
+
 def test_postprocess_overflowed_box_width(dev):
     """A box whose width overflows to +inf (tw = 100 on the best candidate): its mask thresholds are infinite, which
     post_mask_kernel evaluates in the integer form (test_mask_predicate_sign_form); NMS sees infinite corners.  Same detections,
