@@ -32,6 +32,15 @@ namespace om {
 #define OM_SPLIT_WIDE 1        // 128 x 128 tiles with 128-byte operand rows (conv_igemm_split_wide_kernel) where cin % 32 == 0
 #endif
 
+#ifndef OM_SPLIT_TRACE
+#define OM_SPLIT_TRACE 0       // measurement builds only: s_memtime stamps per tile of the wide kernel (tools/split_trace.py)
+#endif
+#if OM_SPLIT_TRACE
+static unsigned long long* g_split_trace = nullptr;
+extern "C" void om_debug_split_trace(void* buf) { g_split_trace = static_cast<unsigned long long*>(buf); }
+#define SPLIT_STAMP(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
+#endif
+
 struct IgemmSParams {
     const _Float16* in;   // the fp32 activations, addressed in halfs (pixel stride and channel counts doubled)
     const _Float16* w;    // packed hi/lo weights: [cout_pad][taps][cin / 16][4][8] halfs
@@ -55,6 +64,9 @@ struct IgemmSParams {
     // resolution -- the nearest-neighbour up-sampling of the reference's routes and skips (orienmask_yolo_fpnplus.py:78-86,
     // F.interpolate + torch.cat) happens in the operand addresses instead of in replicated stores
     int nseg, nimg;
+#if OM_SPLIT_TRACE
+    unsigned long long* trace;      // [workgroup < 16][tile < 16][8]
+#endif
     const _Float16* seg_ptr[4];
     int seg_stride_h[4], seg_shift[4], seg_end[4];
 };
@@ -64,9 +76,16 @@ constexpr int split_blocks_per_cu() { return BM * BN >= 256 * 128 ? 2 : (BM * BN
 
 // fp32 epilogue of a finished BM x BN tile (accumulators in the transposed 32x32 layout: pixel = lane & 31,
 // channel = 8*(r>>2) + 4*(lane>>5) + (r&3)): one wave-row (WM pixels x BN channels) at a time through LDS.
-template <int BM, int BN, int WM, int WN>
+//
+// FAST (launch_conv_igemm_split: plain NHWC output, no residual, 16-byte aligned views, cout == cout_pad -- every 1x1 and
+// stride-2 layer of the forward but the up-sampling producers and the two heads): the row sweeps contain NO load.  In the
+// generic form the residual's conditional loads sit in the sweep loop, and the compiler's wait-count bookkeeping then waits for
+// vmcnt(0) at the top of every sweep -- which, loads and stores sharing one in-order counter, is the round trip of the PREVIOUS
+// sweep's stores: eight store round trips per tile, 10-18 k cycles of a 40 k-cycle 1x1 tile (tools/split_trace.py,
+// profiles/r03_experiments.md section 14; the same serialisation as conv_wino14.hip's first epilogue).
+template <int BM, int BN, int WM, int WN, bool FAST = false>
 __device__ __forceinline__ void split_epilogue(const IgemmSParams& p, f32x4* smem, const f32x16 (&acc)[WM / 32][WN / 32],
-                                               int m0, int n0, int tid, int wm, int wn, int fi, int fk) {
+                                               int m0, int n0, int tid, int wm, int wn, int fi, int fk, float (&sc)[8], float (&sh)[8]) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int CH8 = BN / 8;
     constexpr int RP = 256 / CH8;
@@ -76,9 +95,10 @@ __device__ __forceinline__ void split_epilogue(const IgemmSParams& p, f32x4* sme
     const int n = n0 + n8 * 8;
     const int nvalid = p.cout - n;
     const bool vec = p.vec_io && nvalid >= 8;
-    float sc[8], sh[8];
+    if constexpr (!FAST) {      // FAST: requested by the kernel before its k loop (split_scale_shift)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { sc[k] = p.scale[n + k]; sh[k] = p.shift[n + k]; }   // padded to cout_pad
+        for (int k = 0; k < 8; ++k) { sc[k] = p.scale[n + k]; sh[k] = p.shift[n + k]; }   // padded to cout_pad
+    }
     // RANGE GUARD of the split representation (include/orienmask_hip.h: OM_STATUS_SPLIT_RANGE).  An activation beyond fp16's
     // range converts to hi = +-inf, lo = -+inf, whose products sum to NaN in every output channel of that pixel (also against
     // zero weights: 0 * inf), so "this tile stores a non-finite value" is exactly "an operand left the representable range, or the
@@ -103,7 +123,28 @@ __device__ __forceinline__ void split_epilogue(const IgemmSParams& p, f32x4* sme
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // LDS-only barrier: the previous pass's stores keep flying
         __builtin_amdgcn_s_barrier();
-        if (p.out_mode != 2) {
+        if constexpr (FAST) {
+#pragma unroll
+            for (int ps = 0; ps < (WM + RP - 1) / RP; ++ps) {
+                const int ml = ps * RP + r0;
+                const int m = m0 + pass * WM + ml;
+                if (ml >= WM) continue;
+                const f32x4 v0 = sC[ml * CH + ((2 * n8) ^ (ml & 7))];
+                const f32x4 v1 = sC[ml * CH + ((2 * n8 + 1) ^ (ml & 7))];
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float t = fmaf(v[k], sc[k], sh[k]);
+                    v[k] = p.leaky ? (t > 0.f ? t : t * 0.1f) : t;
+                    nonfinite = fmaf(t, 0.f, nonfinite);
+                }
+                if (m < p.M) {
+                    float* o = p.out + (size_t)m * p.out_pix_stride + n;
+                    *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                }
+            }
+        } else if (p.out_mode != 2) {
 #pragma unroll 2
             for (int ps = 0; ps < (WM + RP - 1) / RP; ++ps) {
                 const int ml = ps * RP + r0;
@@ -177,6 +218,16 @@ __device__ __forceinline__ void split_epilogue(const IgemmSParams& p, f32x4* sme
     if (p.status && nonfinite != nonfinite) atomicOr(p.status, OM_STATUS_SPLIT_RANGE);
 }
 
+// the epilogue's per-channel constants of this thread (split_epilogue: n = n0 + (tid % (BN / 8)) * 8), requested before the k loop
+template <int BN>
+__device__ __forceinline__ void split_scale_shift(const IgemmSParams& p, int n0, int tid, float (&sc)[8], float (&sh)[8]) {
+    const int n = n0 + (tid % (BN / 8)) * 8;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(p.scale + n), a1 = *reinterpret_cast<const f32x4*>(p.scale + n + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.shift + n), b1 = *reinterpret_cast<const f32x4*>(p.shift + n + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sc[k] = a0[k]; sc[4 + k] = a1[k]; sh[k] = b0[k]; sh[4 + k] = b1[k]; }
+}
+
 // hi = fp16(x) (round to nearest even), lo = fp16(x - hi) for the eight channels a lane holds of one pixel
 __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& hi, f16x8& lo) {
 #pragma unroll
@@ -191,7 +242,7 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& 
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool FAST = false>
 __global__ __launch_bounds__(256, (split_blocks_per_cu<BM, BN>())) void conv_igemm_split_kernel(const IgemmSParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NWN = BN / WN;
@@ -359,7 +410,9 @@ __global__ __launch_bounds__(256, (split_blocks_per_cu<BM, BN>())) void conv_ige
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
 
-        split_epilogue<BM, BN, WM, WN>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk);
+        float sc[8], sh[8];      // (four blocks per CU: no registers to hold them across the k loop)
+        if constexpr (FAST) split_scale_shift<BN>(p, n0, tid, sc, sh);
+        split_epilogue<BM, BN, WM, WN, FAST>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk, sc, sh);
     }
 }
 
@@ -374,7 +427,7 @@ __global__ __launch_bounds__(256, (split_blocks_per_cu<BM, BN>())) void conv_ige
 // GATHER: the A rows come from up to four tensors at their own resolutions (IgemmSParams::nseg; 1x1 layers only).  The row
 // offsets are recomputed when the k loop crosses into the next segment (at most three times per tile); everything else is the
 // same instruction stream, and the products are summed in the same order as over the materialised concat (bit-identical).
-template <int BM, int BN, int WM, int WN, bool GATHER = false>
+template <int BM, int BN, int WM, int WN, bool GATHER = false, bool FAST = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const IgemmSParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NWN = BN / WN;
@@ -396,11 +449,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
     const int scol = lcol ^ ((lrow >> 1) & 7);     // logical chunk this lane fetches (the LDS image stays lane-linear)
     const int fi = lane & 31, fk = lane >> 5;
     const int fsw = (fi >> 1) & 7;
+#if OM_SPLIT_TRACE
+    int n_traced = 0;
+#endif
 
+    // The tile queue's NEXT ticket is drawn while this tile's k loop runs and handed over through LDS before the epilogue (its
+    // value must not be consumed behind the epilogue's stores: loads, atomics and stores retire through one in-order counter).
+    if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     for (;;) {
-        if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+#if OM_SPLIT_TRACE
+        unsigned long long ts0, ts1, ts2, ts3, twait = 0, wa, wb;
+        SPLIT_STAMP(ts0);
+#endif
         int tile = *s_ticket;
         if (tile >= p.total_tiles) break;
         tile = __builtin_amdgcn_readfirstlane(tile);
@@ -493,6 +555,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
             }
         };
 
+        float sc[8], sh[8];
+        if constexpr (FAST) split_scale_shift<BN>(p, n0, tid, sc, sh);
         f32x16 acc[TM][TN];
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -538,8 +602,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
 #pragma unroll
         for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 1, 1 < nstages);
         advance();
+        int next_ticket = 0;
+        if (tid == 0) next_ticket = atomicAdd(p.ticket, 1);      // newer than stage 1's pieces: the wait below still covers stage 0
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NP) : "memory");
         __builtin_amdgcn_s_barrier();
+#if OM_SPLIT_TRACE
+        SPLIT_STAMP(ts1);
+#endif
         read_raw(0, 0);
         convert();
         int buf = 0;
@@ -548,8 +617,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
             multiply();                              // k-step (s, 0)
             convert();                               // operands of (s, 1); my reads of `buf` are complete
             // stage s + 1 (requested one stage ago) has landed; every wave is done reading `buf`: it takes stage s + 2
+#if OM_SPLIT_TRACE
+            SPLIT_STAMP(wa);
+#endif
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+#if OM_SPLIT_TRACE
+            SPLIT_STAMP(wb);
+            twait += wb - wa;
+#endif
             const bool live2 = s + 2 < nstages;
 #pragma unroll
             for (int piece = 0; piece < NP; ++piece) issue_piece(piece, buf, live2);
@@ -560,9 +636,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
             buf ^= 1;
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (tid == 0) *s_ticket = next_ticket;      // every wave read the current ticket many barriers ago
         __syncthreads();
+#if OM_SPLIT_TRACE
+        SPLIT_STAMP(ts2);
+#endif
 
-        split_epilogue<BM, BN, WM, WN>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk);
+        split_epilogue<BM, BN, WM, WN, FAST>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk, sc, sh);
+#if OM_SPLIT_TRACE
+        SPLIT_STAMP(ts3);
+        if (p.trace && blockIdx.x < 16 && n_traced < 16 && tid == 0) {
+            unsigned long long* t = p.trace + ((size_t)blockIdx.x * 16 + n_traced) * 8;
+            t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = ts3; t[4] = twait; t[5] = (unsigned long long)tile;
+        }
+        ++n_traced;
+#endif
     }
 }
 
@@ -574,8 +662,15 @@ static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hi
     OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "conv split: %lld tiles out of range", total);
     p.total_tiles = (int)total;
     const long long grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
-    if constexpr (WIDE) hipLaunchKernelGGL((conv_igemm_split_wide_kernel<BM, BN, WM, WN, GATHER>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    // the epilogue without loads in its row sweeps (split_epilogue: FAST) wherever the layer allows it
+    const bool fast = p.out_mode == 0 && !p.res && p.vec_io && p.cout == cout_pad;
+    if constexpr (WIDE) {
+        if (fast) hipLaunchKernelGGL((conv_igemm_split_wide_kernel<BM, BN, WM, WN, GATHER, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_igemm_split_wide_kernel<BM, BN, WM, WN, GATHER, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    } else {
+        if (fast) hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, WN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    }
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }
@@ -627,6 +722,9 @@ int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream) {
                 (!a.res || (a.res_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)))
                    ? 1 : 0;
     p.nseg = 0; p.nimg = a.B;
+#if OM_SPLIT_TRACE
+    p.trace = g_split_trace;
+#endif
     for (int g = 0; g < 4; ++g) { p.seg_ptr[g] = p.in; p.seg_stride_h[g] = 0; p.seg_shift[g] = 0; p.seg_end[g] = 0x7FFFFFFF; }
     if (a.nseg > 0) {
         // gathered input: 1x1, whole 32-channel chunks per segment, every segment's resolution a power-of-two fraction of this one
