@@ -25,7 +25,7 @@ namespace om {
 template <int BM, int BN>
 constexpr int c3_blocks_per_cu() { return BM * BN >= 256 * 128 ? 2 : (BM * BN >= 128 * 128 ? 3 : 4); }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool FAST = false>
 __global__ __launch_bounds__(256, (c3_blocks_per_cu<BM, BN>())) void conv3x3_f16_kernel(const IgemmHParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NWN = BN / WN;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, (c3_blocks_per_cu<BM, BN>())) void conv3x3_f16
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
 
-        f16_epilogue<BM, BN, WM, WN>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk);
+        f16_epilogue<BM, BN, WM, WN, FAST>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk);
     }
 }
 
@@ -217,7 +217,11 @@ static int launch_c3(IgemmHParams p, int cout_pad, hipStream_t stream) {
     p.total_tiles = (int)total;
     const long long slots = 256ll * c3_blocks_per_cu<BM, BN>();
     const long long grid = total < slots ? total : slots;
-    hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    // the epilogue without loads in its row sweeps (f16_epilogue: FAST) wherever the layer allows it
+    if (p.out_mode == 0 && !p.out_f32 && !p.res && p.vec_io && p.cout == cout_pad)
+        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WM, WN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }

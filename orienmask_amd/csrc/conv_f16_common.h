@@ -33,7 +33,11 @@ struct IgemmHParams {
 // LDS in fp32 (16-byte chunk index swizzled with m & 7), then 8 channels per thread: scale/shift, LeakyReLU, residual,
 // one 16-byte fp16 store (fp32 for the head tensors; NCHW fp32 for the orientation head).  `smem` must hold
 // WM * BN / 4 f32x4 and be free of live operands; all 256 threads call it.
-template <int BM, int BN, int WM, int WN>
+//
+// FAST (the launchers: fp16 NHWC output, no residual, 16-byte aligned view, cout == cout_pad): row sweeps without any load.  With
+// the residual's conditional loads in the sweep loop the compiler waits for vmcnt(0) at the top of every sweep, i.e. for the
+// PREVIOUS sweep's stores (one in-order counter for loads and stores): conv_igemm_split.hip's epilogue, DESIGN.md 3.5.
+template <int BM, int BN, int WM, int WN, bool FAST = false>
 __device__ __forceinline__ void f16_epilogue(const IgemmHParams& p, f32x4* smem, const f32x16 (&acc)[WM / 32][WN / 32],
                                              int m0, int n0, int tid, int wm, int wn, int fi, int fk) {
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -71,7 +75,24 @@ __device__ __forceinline__ void f16_epilogue(const IgemmHParams& p, f32x4* smem,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // phase 2
-        if (p.out_mode != 2) {
+        if constexpr (FAST) {
+#pragma unroll
+            for (int ps = 0; ps < (WM + RP - 1) / RP; ++ps) {
+                const int ml = ps * RP + r0;
+                const int m = m0 + pass * WM + ml;
+                if (ml >= WM) continue;
+                const f32x4 v0 = sC[ml * CH + ((2 * n8) ^ (ml & 7))];
+                const f32x4 v1 = sC[ml * CH + ((2 * n8 + 1) ^ (ml & 7))];
+                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                f16x8 hv;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float t = fmaf(v[k], sc[k], sh[k]);
+                    hv[k] = (_Float16)(p.leaky ? (t > 0.f ? t : t * 0.1f) : t);
+                }
+                if (m < p.M) *reinterpret_cast<f16x8*>(static_cast<_Float16*>(p.out) + (size_t)m * p.out_pix_stride + n) = hv;
+            }
+        } else if (p.out_mode != 2) {
 #pragma unroll 2
             for (int ps = 0; ps < (WM + RP - 1) / RP; ++ps) {
                 const int ml = ps * RP + r0;

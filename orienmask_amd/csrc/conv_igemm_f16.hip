@@ -42,7 +42,7 @@ namespace om {
 template <int BM, int BN>
 constexpr int f16_blocks_per_cu() { return BM * BN >= 256 * 128 ? 2 : (BM * BN >= 128 * 128 ? 3 : 4); }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool FAST = false>
 __global__ __launch_bounds__(256, (f16_blocks_per_cu<BM, BN>())) void conv_igemm_f16_kernel(const IgemmHParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NWN = BN / WN;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, (f16_blocks_per_cu<BM, BN>())) void conv_igemm
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
 
-        f16_epilogue<BM, BN, WM, WN>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk);
+        f16_epilogue<BM, BN, WM, WN, FAST>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk);
     }
 }
 
@@ -256,7 +256,11 @@ static int launch_tile_f16(IgemmHParams p, int cout_pad, int blocks_per_cu, hipS
     p.total_tiles = (int)total;
     long long grid = total;
     grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
-    hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    // the epilogue without loads in its row sweeps (f16_epilogue: FAST) wherever the layer allows it
+    if (p.out_mode == 0 && !p.out_f32 && !p.res && p.vec_io && p.cout == cout_pad)
+        hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }
