@@ -25,7 +25,7 @@ namespace om {
 template <int BM, int BN>
 constexpr int c3_blocks_per_cu() { return BM * BN >= 256 * 128 ? 2 : (BM * BN >= 128 * 128 ? 3 : 4); }
 
-template <int BM, int BN, int WM, int WN, bool FAST = false>
+template <int BM, int BN, int WM, int WN, int FAST = 0>
 __global__ __launch_bounds__(256, (c3_blocks_per_cu<BM, BN>())) void conv3x3_f16_kernel(const IgemmHParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NWN = BN / WN;
@@ -218,10 +218,10 @@ static int launch_c3(IgemmHParams p, int cout_pad, hipStream_t stream) {
     const long long slots = 256ll * c3_blocks_per_cu<BM, BN>();
     const long long grid = total < slots ? total : slots;
     // the epilogue without loads in its row sweeps (f16_epilogue: FAST) wherever the layer allows it
-    if (p.out_mode == 0 && !p.out_f32 && !p.res && p.vec_io && p.cout == cout_pad)
-        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WM, WN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    const bool fast = p.out_mode == 0 && !p.out_f32 && p.vec_io && p.cout == cout_pad;
+    if (fast && !p.res) hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WM, WN, 1>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    else if (fast) hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WM, WN, 2>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv3x3_f16_kernel<BM, BN, WM, WN, 0>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }

@@ -37,7 +37,9 @@ struct IgemmHParams {
 // FAST (the launchers: fp16 NHWC output, no residual, 16-byte aligned view, cout == cout_pad): row sweeps without any load.  With
 // the residual's conditional loads in the sweep loop the compiler waits for vmcnt(0) at the top of every sweep, i.e. for the
 // PREVIOUS sweep's stores (one in-order counter for loads and stores): conv_igemm_split.hip's epilogue, DESIGN.md 3.5.
-template <int BM, int BN, int WM, int WN, bool FAST = false>
+// FAST = 2: the same with a residual (fp16 NHWC, 16-byte aligned): its rows are requested RG sweeps at a time BEFORE those
+// sweeps' stores, so a pass waits for the previous stores WM / RP / RG times instead of once per sweep.
+template <int BM, int BN, int WM, int WN, int FAST = 0>
 __device__ __forceinline__ void f16_epilogue(const IgemmHParams& p, f32x4* smem, const f32x16 (&acc)[WM / 32][WN / 32],
                                              int m0, int n0, int tid, int wm, int wn, int fi, int fk) {
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -75,22 +77,37 @@ __device__ __forceinline__ void f16_epilogue(const IgemmHParams& p, f32x4* smem,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // phase 2
-        if constexpr (FAST) {
+        if constexpr (FAST != 0) {
+            constexpr int NPS = (WM + RP - 1) / RP, RG = FAST == 2 ? (NPS % 4 == 0 ? 4 : NPS % 2 == 0 ? 2 : 1) : NPS;
 #pragma unroll
-            for (int ps = 0; ps < (WM + RP - 1) / RP; ++ps) {
-                const int ml = ps * RP + r0;
-                const int m = m0 + pass * WM + ml;
-                if (ml >= WM) continue;
-                const f32x4 v0 = sC[ml * CH + ((2 * n8) ^ (ml & 7))];
-                const f32x4 v1 = sC[ml * CH + ((2 * n8 + 1) ^ (ml & 7))];
-                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                f16x8 hv;
+            for (int g0 = 0; g0 < NPS; g0 += RG) {
+                [[maybe_unused]] f16x8 rv[RG];
+                if constexpr (FAST == 2) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float t = fmaf(v[k], sc[k], sh[k]);
-                    hv[k] = (_Float16)(p.leaky ? (t > 0.f ? t : t * 0.1f) : t);
+                    for (int q = 0; q < RG; ++q) {      // unconditional requests of clamped rows (a row beyond M repeats the last one)
+                        int m = m0 + pass * WM + (g0 + q) * RP + r0;
+                        m = m < p.M ? m : p.M - 1;
+                        rv[q] = *reinterpret_cast<const f16x8*>(p.res + (size_t)m * p.res_pix_stride + n);
+                    }
                 }
-                if (m < p.M) *reinterpret_cast<f16x8*>(static_cast<_Float16*>(p.out) + (size_t)m * p.out_pix_stride + n) = hv;
+#pragma unroll
+                for (int q = 0; q < RG; ++q) {
+                    const int ml = (g0 + q) * RP + r0;
+                    const int m = m0 + pass * WM + ml;
+                    if (ml >= WM) continue;
+                    const f32x4 v0 = sC[ml * CH + ((2 * n8) ^ (ml & 7))];
+                    const f32x4 v1 = sC[ml * CH + ((2 * n8 + 1) ^ (ml & 7))];
+                    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    f16x8 hv;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float t = fmaf(v[k], sc[k], sh[k]);
+                        t = p.leaky ? (t > 0.f ? t : t * 0.1f) : t;
+                        if constexpr (FAST == 2) t += (float)rv[q][k];
+                        hv[k] = (_Float16)t;
+                    }
+                    if (m < p.M) *reinterpret_cast<f16x8*>(static_cast<_Float16*>(p.out) + (size_t)m * p.out_pix_stride + n) = hv;
+                }
             }
         } else if (p.out_mode != 2) {
 #pragma unroll 2

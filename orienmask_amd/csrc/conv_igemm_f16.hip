@@ -42,7 +42,7 @@ namespace om {
 template <int BM, int BN>
 constexpr int f16_blocks_per_cu() { return BM * BN >= 256 * 128 ? 2 : (BM * BN >= 128 * 128 ? 3 : 4); }
 
-template <int BM, int BN, int WM, int WN, bool FAST = false>
+template <int BM, int BN, int WM, int WN, int FAST = 0>
 __global__ __launch_bounds__(256, (f16_blocks_per_cu<BM, BN>())) void conv_igemm_f16_kernel(const IgemmHParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NWN = BN / WN;
@@ -257,10 +257,10 @@ static int launch_tile_f16(IgemmHParams p, int cout_pad, int blocks_per_cu, hipS
     long long grid = total;
     grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
     // the epilogue without loads in its row sweeps (f16_epilogue: FAST) wherever the layer allows it
-    if (p.out_mode == 0 && !p.out_f32 && !p.res && p.vec_io && p.cout == cout_pad)
-        hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    const bool fast = p.out_mode == 0 && !p.out_f32 && p.vec_io && p.cout == cout_pad;
+    if (fast && !p.res) hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN, 1>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    else if (fast) hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN, 2>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN, 0>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }
