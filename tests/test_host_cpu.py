@@ -377,3 +377,33 @@ def test_pack_state_dict_split_covers_every_layer(built):
             want = blob32[l["w_off"]:l["w_off"] + cout * k2 * cin].reshape(cout, k2 * cin).double()
         amax = want.abs().amax()
         assert float((back - want).abs().max() / amax) < 2.0 ** -20, name
+
+
+def test_upsample_on_read_graph_logic(built):
+    """Host side of the up-sampling-on-read form (om_model.cpp: find_gathers), no GPU: in split-operand mode the three 1x1 layers
+    behind the reference's up-sample + concat (orienmask_yolo_fpnplus.py:78-86) report the gather kernel and nothing else does;
+    the switch, the other precision and kept activations select the replicated form; the workspace size is answered in both
+    forms (the side buffers are small enough to fall into gaps of the live-range layout at this size); the non-Plus model has
+    the same three (its neck4.0 sits behind route8 + x4)."""
+    from orienmask_amd.model import OrienMaskYOLO, OrienMaskYOLOFPNPlus
+    L = omlib.load()
+    net = OrienMaskYOLOFPNPlus(3, 80).set_precision("f32_split")
+    h = net._ensure_handle()
+    kinds = dict(net.layer_kernels(32, 544, 544))
+    gathered = sorted(k for k, v in kinds.items() if "gather" in v)
+    assert gathered == ["neck16.0", "neck4.0", "neck8.0"]
+    ws_gather = L.om_forward_workspace_bytes(h, 32, 544, 544)
+    net.set_upsample_on_read(False)
+    assert not any("gather" in v for _, v in net.layer_kernels(32, 544, 544))
+    ws_replicated = L.om_forward_workspace_bytes(h, 32, 544, 544)
+    assert ws_gather > 0 and ws_replicated > 0
+    net.set_upsample_on_read(True)
+    assert L.om_forward_workspace_bytes(h, 32, 544, 544) == ws_gather
+    net.keep_activations(True)
+    assert not any("gather" in v for _, v in net.layer_kernels(32, 544, 544))
+    net.keep_activations(False)
+    net.set_precision("f32")
+    assert not any("gather" in v for _, v in net.layer_kernels(32, 544, 544))
+    small = OrienMaskYOLO(3, 80).set_precision("f32_split")
+    assert sorted(k for k, v in small.layer_kernels(8, 544, 544) if "gather" in v) == ["neck16.0", "neck4.0", "neck8.0"]
+    assert L.om_model_set_upsample_on_read(None, 1) != 0          # null model: an error code, not a crash
