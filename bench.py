@@ -42,7 +42,7 @@ ANCHOR_MASK = [[6, 7, 8], [3, 4, 5], [0, 1, 2]]
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-PROFILE_TAG = "r03"                # profiles/<tag>_pmc_traffic*.json: the PMC passes whose `traffic` this build may quote
+PROFILE_TAG = "r04"                # profiles/<tag>_pmc_traffic*.json: the PMC passes whose `traffic` this build may quote
 WEIGHT_SEED, OBJ_BIAS, HEAD_GAIN = 3, -16.0, 4.0
 OBJ_BIAS_SPARSE = -18.5     # a few tens of detections per image (-18: 67, -19: 11, -20: 3, <= -24: none)
 
@@ -167,8 +167,73 @@ def measure_neighbours(dev, dets, B):
     return out
 
 
+def resolve_launch(gpus, env, argv, visible_gpus=None):
+    """What `python bench.py --gpus N` means.  Returns ("run", world) when this process is one rank
+    of a job whose size agrees with --gpus, or ("spawn", cmd) when no launcher set WORLD_SIZE and N > 1: the command that
+    re-executes this script as N ranks under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1).  A launcher
+    whose WORLD_SIZE differs from --gpus, N < 1, or N above the visible GPUs is an error -- never a silent N = 1 run."""
+    if gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1 (got %d)" % gpus)
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if world != gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; pass --gpus %d or launch %d ranks"
+                             % (gpus, world, world, gpus))
+        return "run", world
+    if gpus == 1:
+        return "run", 1
+    if visible_gpus is not None and visible_gpus < gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible on this node" % (gpus, visible_gpus))
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return "spawn", cmd
+
+
+def plumbing_only(args, world, rank):
+    """`--plumbing-only`: the launcher / rendezvous / broadcast / max-over-ranks timing of the N > 1 path on gloo with CPU tensors
+    -- what a box without N GPUs can check of `bench.py --gpus N` (tests/test_dist_cpu.py).  No kernel runs; the line says so."""
+    import torch.distributed as dist
+    from orienmask_amd.dist import broadcast_blob
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1 << 20
+    blob = torch.arange(n, dtype=torch.float32) if rank == 0 else None
+    t0 = time.perf_counter()
+    got = broadcast_blob(blob, n, torch.device("cpu"), src=0)
+    bc_ms = (time.perf_counter() - t0) * 1e3
+    ok = bool(got[12345].item() == 12345.0)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))                                   # ranks take different times: the line must carry the max
+    el = time.perf_counter() - t0
+    per_rank = [el]
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64)
+        lst = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(lst, t)
+        per_rank = [v.item() for v in lst]
+    if rank == 0:
+        print(json.dumps(dict(metric="plumbing only (no kernel ran): launcher, rendezvous, broadcast and rank reduction of "
+                                     "bench.py --gpus N on gloo", value=None, unit=None, n_gpus=world, rccl_ranks=world,
+                              broadcast=dict(bytes=n * 4, ms=round(bc_ms, 3), intact=ok),
+                              rank_ms=dict(min=round(min(per_rank) * 1e3, 3), max=round(max(per_rank) * 1e3, 3)),
+                              data="none")))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="no GPU work: run only the N-rank launcher / rendezvous / broadcast / timing reduction on gloo (CPU test of --gpus N)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
@@ -179,10 +244,14 @@ def main():
     ap.add_argument("--no-f16-compare", action="store_true",
                     help="split mode: skip the extra timed region in the fp16-activation configuration (BASELINE configs[4])")
     ap.add_argument("--no-extras", action="store_true", help="skip the preprocess / COCO-format side measurements")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the bs = 1 / bs = 8 latency figures (`small_batches`)")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
-    ap.add_argument("--heads", choices=("dense", "sparse"), default="dense",
+    ap.add_argument("--heads", choices=("dense", "sparse", "allpass"), default="dense",
                     help="head statistics of the seeded weights (SURVEY.md 8d Config 3 asks for both): dense = every image yields "
-                         ">400 candidates and 100 detections (the default, worst case for the postprocess); sparse = a few tens")
+                         ">400 candidates and 100 detections (the default); sparse = a few tens of detections; allpass = SURVEY 8c's "
+                         "dense WORST case, random-init-like heads (objectness bias 0, logits ~0): every one of the 1 456 560 "
+                         "(candidate, class) pairs passes conf_thresh, so the decode evaluates all of them and the select kernel takes "
+                         "its three-pass radix path over 5.8 MB of keys per image")
     ap.add_argument("--obj-bias", type=float, default=None, help="override the objectness bias of the synthetic weights")
     ap.add_argument("--streams", type=int, default=1,
                     help="forward as N sub-batches on N HIP streams in the timed region (model.set_streams); the default 1 is "
@@ -215,9 +284,21 @@ def main():
     if args.in_flight is None:
         args.in_flight = 3 if args.dtype == "f16" else 2
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # --gpus N means N: a launcher's WORLD_SIZE must agree with it; without a launcher and N > 1 this process re-executes
+    # itself as N ranks (one per GPU) under torch.distributed.run and returns their exit code
+    action, what = resolve_launch(args.gpus, os.environ, sys.argv[1:],
+                                  None if args.plumbing_only else (torch.cuda.device_count() if torch.cuda.is_available() else 0))
+    if action == "spawn":
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool: RCCL needs it
+        env.setdefault("OMP_NUM_THREADS", "8")
+        raise SystemExit(subprocess.call(what, env=env))
+    world = what
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.plumbing_only:
+        return plumbing_only(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -239,24 +320,44 @@ def main():
 
     H = W = args.size
     B = args.batch
-    obj_bias = args.obj_bias if args.obj_bias is not None else (OBJ_BIAS if args.heads == "dense" else OBJ_BIAS_SPARSE)
+    obj_bias = args.obj_bias if args.obj_bias is not None else {"dense": OBJ_BIAS, "sparse": OBJ_BIAS_SPARSE, "allpass": 0.0}[args.heads]
+    head_gain = 0.25 if args.heads == "allpass" else HEAD_GAIN
     net = OrienMaskYOLOFPNPlus(3, 80).eval().set_precision(args.dtype)
     f16 = args.dtype == "f16"
     split = args.dtype == "f32_split"
     sd = None
     if rank == 0:
-        sd = synth.synth_state_dict(WEIGHT_SEED, obj_bias=obj_bias, head_gain=HEAD_GAIN)
+        sd = synth.synth_state_dict(WEIGHT_SEED, obj_bias=obj_bias, head_gain=head_gain)
         net.load_state_dict(sd, strict=True)
-    broadcast_packed_weights(net, dev, src=0)                      # one RCCL broadcast, untimed
+    bc_stats = {}
+    broadcast_packed_weights(net, dev, src=0, stats=bc_stats)      # one RCCL broadcast per blob, untimed
     if args.replicated_concat:
         net.set_upsample_on_read(False)
     post = OrienMaskYOLOPostProcess(device=dev, **post_config(H, W))
     x_cpu = synth.synth_image_batch(1000 + rank, B, H, W)
     x = x_cpu.to(dev)
+    # two input batches taken in turn: a step never re-reads the tensor the step before it left in the 256 MiB Infinity Cache
+    xs = [x, synth.synth_image_batch(2000 + rank, B, H, W).to(dev)]
+    step_no = [0]
 
     def step():
+        step_no[0] += 1
         with torch.no_grad():
-            return post(net(x))
+            return post(net(xs[step_no[0] & 1]))
+
+    def batches(n):
+        import itertools
+        return itertools.islice(itertools.cycle(xs), n)
+
+    def over_ranks(seconds):
+        """(max, [per-rank seconds]) of a timed region: the job's time is its slowest rank's"""
+        if not use_dist:
+            return seconds, [seconds]
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        lst = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(lst, t)
+        per = [v.item() for v in lst]
+        return max(per), per
 
     for _ in range(args.warmup):
         dets = step()
@@ -302,10 +403,8 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed, per_rank_serial = over_ranks(elapsed)
+    per_rank = per_rank_serial
     timed_ms, timed_fw = net.profile_read()
     net.profile_enable(False)
     net.set_streams(1)
@@ -317,22 +416,19 @@ def main():
         import itertools
         from orienmask_amd.pipeline import InFlightPipeline
         pipe = InFlightPipeline(net, post, depth=args.in_flight)
-        for dets in pipe.map(itertools.repeat(x, 2 * args.in_flight)):     # allocates the per-slot workspaces, untimed
+        for dets in pipe.map(batches(2 * args.in_flight)):                 # allocates the per-slot workspaces, untimed
             pass
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for dets in pipe.map(itertools.repeat(x, args.steps)):
+        for dets in pipe.map(batches(args.steps)):
             pass
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = t.item()
+        elapsed, per_rank = over_ranks(elapsed)
     # ---- split mode: the same K steps with fp32 operands (v_mfma_f32_32x32x2_f32 everywhere), for comparison
     f32_operands = None
     if split and not args.no_f32_compare:
@@ -346,20 +442,15 @@ def main():
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
-            e_ = time.perf_counter() - t0_
-            if use_dist:
-                t_ = torch.tensor([e_], dtype=torch.float64, device=dev)
-                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
-                e_ = t_.item()
-            return e_
+            return over_ranks(time.perf_counter() - t0_)[0]
         for _ in range(2):
             step()
         e1 = timed(lambda: [step() for _ in range(args.steps)])
         e2 = e1
         if args.in_flight > 1:
-            for _ in pipe.map(itertools.repeat(x, 2 * args.in_flight)):
+            for _ in pipe.map(batches(2 * args.in_flight)):
                 pass
-            e2 = timed(lambda: [None for _ in pipe.map(itertools.repeat(x, args.steps))])
+            e2 = timed(lambda: [None for _ in pipe.map(batches(args.steps))])
         f32_operands = dict(value=round(world * B * args.steps / e2, 2), ms_per_step=round(e2 / args.steps * 1e3, 3),
                             one_batch_in_flight=round(world * B * args.steps / e1, 2),
                             note="the same K steps with precision 'f32': fp32 operands on v_mfma_f32_32x32x2_f32 (157 TFLOP/s "
@@ -376,7 +467,7 @@ def main():
         pipe16 = InFlightPipeline(net, post, depth=3)
         for _ in range(2):
             step()
-        for _ in pipe16.map(itertools.repeat(x, 6)):
+        for _ in pipe16.map(batches(6)):
             pass
         def timed16(fn):
             if use_dist:
@@ -387,22 +478,101 @@ def main():
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
-            e_ = time.perf_counter() - t0_
-            if use_dist:
-                t_ = torch.tensor([e_], dtype=torch.float64, device=dev)
-                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
-                e_ = t_.item()
-            return e_
+            return over_ranks(time.perf_counter() - t0_)[0]
         e1 = timed16(lambda: [step() for _ in range(args.steps)])
-        e3 = timed16(lambda: [None for _ in pipe16.map(itertools.repeat(x, args.steps))])
+        e3 = timed16(lambda: [None for _ in pipe16.map(batches(args.steps))])
+        # this configuration's own roofline: HIP events around every layer of three forwards (untimed), the kernel with the most
+        # time, its executed flops (direct convolution on v_mfma_f32_32x32x16_f16: executed = algorithmic) against the dense
+        # fp16 peak, and the forward's algorithmic bytes (2-byte activations and weights) against HBM
+        net.profile_enable(True)
+        for _ in range(3):
+            with torch.no_grad():
+                net(xs[0])
+        torch.cuda.synchronize()
+        lms16, nfw16 = net.profile_read()
+        net.profile_enable(False)
+        kof16 = dict(net.layer_kernels(B, H, W))
+        kt = {}
+        for name, ms, pre in lms16:
+            wk = arch.layer_work(specs[name], B, H, W)
+            t = kt.setdefault(kof16[name], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            t["ms"] += (ms + pre) / nfw16; t["flops"] += wk["flops"]; t["bytes"] += wk["bytes"] / 2; t["launches"] += 1
+        dom16 = max(kt, key=lambda k: kt[k]["ms"])
+        fwd16_ms = sum(t["ms"] for t in kt.values())
+        d16 = kt[dom16]
+        traffic16 = None
+        try:
+            pmc16 = json.load(open(os.path.join(REPO, "profiles", PROFILE_TAG + "_pmc_traffic_f16.json")))
+            if pmc16.get("_meta", {}).get("lib_sha256") == lib_sha256():
+                keys = [k for k in pmc16 if k.replace(" ", "").startswith(dom16.replace(" ", "").rstrip(">")) and
+                        "hbm_bytes_per_launch_corrected" in pmc16[k]]
+                if keys:
+                    nl = sum(pmc16[k]["launches"] for k in keys)
+                    traffic16 = round(sum(pmc16[k]["hbm_bytes_per_launch_corrected"] * pmc16[k]["launches"] for k in keys) / nl)
+        except Exception:
+            pass
+        f16_roofline = dict(bound="mfma", kernel=dom16, launches_per_step=d16["launches"], kernel_ms_per_step=round(d16["ms"], 3),
+                            achieved=round(d16["flops"] / (d16["ms"] * 1e-3) / 1e12, 2), peak=PEAK_F16_MFMA_TFLOPS, unit="TFLOP/s",
+                            frac=round(d16["flops"] / (d16["ms"] * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                            algorithmic_bytes_per_launch=round(d16["bytes"] / d16["launches"]), traffic=traffic16,
+                            forward_kernels_ms_per_step=round(fwd16_ms, 3),
+                            forward_tflops=round(sum(t["flops"] for t in kt.values()) / (fwd16_ms * 1e-3) / 1e12, 2),
+                            forward_hbm_algorithmic_gbs=round(sum(t["bytes"] for t in kt.values()) / (fwd16_ms * 1e-3) / 1e9, 1),
+                            forward_hbm_frac=round(sum(t["bytes"] for t in kt.values()) / (fwd16_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                            step_hbm_algorithmic_frac=round(sum(t["bytes"] for t in kt.values()) / (e3 / args.steps) / 1e9 / PEAK_HBM_GBS, 4),
+                            measured="HIP events around every layer of three untimed one-batch-at-a-time forwards in this run; "
+                                     "traffic = PMC bytes per launch when profiles/%s_pmc_traffic_f16.json was measured with this "
+                                     "library binary, else null" % PROFILE_TAG)
         f16_config = dict(value=round(world * B * args.steps / e3, 2), ms_per_step=round(e3 / args.steps * 1e3, 3),
-                          batches_in_flight=3, one_batch_in_flight=round(world * B * args.steps / e1, 2),
+                          batches_in_flight=3, one_batch_in_flight=round(world * B * args.steps / e1, 2), roofline=f16_roofline,
                           note="BASELINE configs[4] at this batch size: the same K steps with precision 'f16' (fp16 activations and "
                                "convolution weights, fp32 accumulate, fp32 heads and postprocess; `bench.py --dtype f16` prints its own "
                                "roofline).  Narrower arithmetic than the headline and unpinned against the reference (DESIGN.md 3.3): "
                                "never `value`")
         del pipe16
         net.set_precision(args.dtype)
+    # ---- small batches (the reference's own published metric is bs = 1 FPS: README.md:5, infer.py:143-172): one image / eight
+    # images per step, one at a time (the reference's loop) through the hipGraph of forward + postprocess that infer_loop uses,
+    # eagerly, and with four batches in flight; same weights, same precision
+    small = None
+    if not args.no_small_batch and args.streams == 1:
+        import itertools
+        from orienmask_amd.graph import GraphedPipeline
+        from orienmask_amd.pipeline import InFlightPipeline
+        small = {}
+        for bsz in (1, 8):
+            xsb = [t[:bsz].contiguous() for t in xs]
+            n_it = max(20, args.steps)
+            def time_loop(fn, n):
+                for _ in range(3):
+                    fn(0)
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for i in range(n):
+                    fn(i)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0_) / n
+            with torch.no_grad():
+                eager_s = time_loop(lambda i: post(net(xsb[i & 1])), n_it)
+                gp = GraphedPipeline(net, post, xsb[0])
+                graph_s = time_loop(lambda i: gp(xsb[i & 1]), n_it)
+                del gp
+                pipe4 = InFlightPipeline(net, post, depth=4)
+                for _ in pipe4.map(itertools.islice(itertools.cycle(xsb), 8)):
+                    pass
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for _ in pipe4.map(itertools.islice(itertools.cycle(xsb), 4 * n_it)):
+                    pass
+                torch.cuda.synchronize()
+                fl_s = (time.perf_counter() - t0_) / (4 * n_it)
+                del pipe4
+            small["bs%d" % bsz] = dict(ms_per_step_one_at_a_time_graph=round(graph_s * 1e3, 3), images_per_s_graph=round(bsz / graph_s, 1),
+                                       ms_per_step_one_at_a_time_eager=round(eager_s * 1e3, 3), images_per_s_eager=round(bsz / eager_s, 1),
+                                       images_per_s_four_in_flight=round(bsz / fl_s, 1))
+        small["note"] = ("batches of 1 and 8 images per GPU with this run's weights and precision: one at a time through the captured "
+                         "hipGraph (orienmask_amd.graph.GraphedPipeline, what infer_loop runs for a fixed shape), one at a time eagerly, "
+                         "and with four batches in flight (InFlightPipeline)")
     timed_fw //= max(args.streams, 1)                              # one om_forward per sub-batch
     dom_main_ms = sum(ms for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw      # per step, all launches
     dom_timed_ms = dom_main_ms + sum(pre for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw
@@ -582,14 +752,21 @@ def main():
                     unit="images/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
                     vs_baseline=None, dtype=dtype_out, precision=args.dtype, plugin_default_precision=DEFAULT_PRECISION,
-                    data="synthetic",
+                    data="synthetic (two seeded input batches taken in turn)",
+                    rccl_ranks=world if use_dist else 0,
+                    rank_ms_per_step=dict(min=round(min(per_rank) / args.steps * 1e3, 3), max=round(max(per_rank) / args.steps * 1e3, 3),
+                                          one_batch_in_flight_min=round(min(per_rank_serial) / args.steps * 1e3, 3),
+                                          one_batch_in_flight_max=round(max(per_rank_serial) / args.steps * 1e3, 3)),
+                    weight_broadcast=dict(bytes=bc_stats.get("bytes"), ms=bc_stats.get("ms"), blobs=bc_stats.get("blobs"),
+                                          backend="rccl" if use_dist else "none (single rank: packed on the host, copied to the GPU)",
+                                          note="rank 0's packed weights to every rank, once, before any timed region"),
                     config=dict(workload="OrienMaskYOLOFPNPlus forward + OrienMaskYOLOPostProcess, %d x [3,%d,%d] per GPU "
                                          "(BASELINE configs[2]); seeded random-init weights (seed %d, obj_bias %g, head_gain %g): "
                                          "%s heads (dense: >400 candidates pass conf_thresh per image, NMS, 100 masks per image; "
                                          "sparse: a few tens of detections per image).  Parity of exactly this workload: "
                                          "tests/test_hip_parity.py::test_bench_workload_bs32_detections (these weights' saturated heads tie "
                                          "hundreds of scores at exactly 1.0, so detections are compared as sets per tie group)"
-                                         % (B, H, W, WEIGHT_SEED, obj_bias, HEAD_GAIN, args.heads),
+                                         % (B, H, W, WEIGHT_SEED, obj_bias, head_gain, args.heads),
                                 per_gpu_batch=B, image_size=[H, W], forward_streams=args.streams, batches_in_flight=args.in_flight, detections_per_image=round(sum(int(d_["bbox"].shape[0]) for d_ in dets) / B, 1),
                                 parallelism="batch shard x%d, one RCCL weight broadcast, no collective in the step" % world),
                     one_batch_in_flight=dict(value=round(total_images / elapsed_serial, 2), ms_per_step=round(elapsed_serial / args.steps * 1e3, 3),
@@ -613,6 +790,8 @@ def main():
             line["f32_operands"] = f32_operands
         if f16_config is not None:
             line["f16_config"] = f16_config
+        if small is not None:
+            line["small_batches"] = small
         if not args.no_extras:
             line["extras"] = measure_neighbours(dev, dets, B)
         if world == 1 and not args.no_cpu_baseline:

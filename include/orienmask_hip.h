@@ -99,6 +99,9 @@ typedef struct om_post_cfg {
     int32_t nms_normalized;                     /* batched_nms(normalized=...), eval/function.py:91-92: 1 = class offset
                                                    cls * 2.0; 0 = cls * (max(x, y) + max(w, h) / 2 + 0.5) over the image's
                                                    candidates */
+    int32_t anchors_of_scale[OM_MAX_SCALES];    /* anchors of each scale where they differ (len(anchor_mask[i]),
+                                                   postprocess.py:17-27), 1..3; 0 = anchors_per_scale.  num_scales may be 1..3:
+                                                   the heads of unused scales are not read (pass NULL) */
 } om_post_cfg;
 
 int om_version(void);
@@ -120,8 +123,12 @@ int om_model_load_weights(om_model* m, const void* packed_dev, size_t bytes, int
 /* ---- precision of om_forward's convolutions (no counterpart in the reference, whose convolutions are whatever cuDNN /
  * MKLDNN run) -----------------------------------------------------------------------------------------------------------
  * 0: operands fp32 on v_mfma_f32_32x32x2_f32 (products exact, fp32 accumulate).
- * 1: SPLIT operands, in EVERY convolution but the stem (the F(2x4,3x3) Winograd GEMMs of the stride-1 3x3 layers,
- *    conv_wino24.hip, and the implicit GEMM of the 1x1 / stride-2 / head layers, conv_igemm_split.hip).  Every fp32 operand x
+ * 1: SPLIT operands, in EVERY convolution: the fused F(4,3) kernel of the stride-1 3x3 layers (conv_wino14.hip), the implicit
+ *    GEMM of the 1x1 / stride-2 / head layers (conv_igemm_split.hip), and backbone.conv1 + backbone.conv2.0, which om_forward
+ *    runs as ONE kernel (conv_stem2.hip: conv1's 27-term products on the matrix pipe with hi/lo operands too; equal to
+ *    om_conv2d_stem followed by om_conv2d_split within 2e-6 of the tensor's scale, not bit for bit).  That fusion is off
+ *    while om_model_keep_activations is on, so om_layer_output_view then shows conv1 / conv2.0 from the two-kernel path
+ *    (conv1 with fp32 operands); tests/test_hip_parity.py::test_stem2_split_matches_two_kernels compares the two.  Every fp32 operand x
  *    is carried as hi = fp16(x), lo = fp16(x - hi) and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with
  *    fp32 accumulation (the lo*lo term, <= 2^-22 of the product, is dropped): 5.3x the matrix rate at the same bytes per
  *    element.  Representation error <= 2^-22 |x| for |x| >= 2^-14 * 2^11 and 2^-25 absolute below (measured end to end in
@@ -306,13 +313,31 @@ int om_pad_nchw(const float* in, long long planes, int h, int w, int pad_top, in
 
 /* ---- postprocess -------------------------------------------------------------------------- */
 size_t om_postprocess_workspace_bytes(const om_post_cfg* cfg, int B);
-/* out_bbox [B,nms_post,5] (cx,cy,w,h normalised, score); out_cls [B,nms_post] int64;
+/* Limits of the fused path (the reference has none): nms_pre <= 1024; 1..3 scales of 1..3 anchors; conf_thresh >= 0 (the
+ * decode skips a candidate whose sigmoid(objectness) is not above it before reading its class logits); num_classes such that
+ * (2047 / C + 2) * max(C & ~31, C & 31) + 63 <= 2560 -- every C <= 251, e.g. not LVIS's 1203 -- because a decode thread's visits
+ * per sweep are unrolled (DEC_VISITS in csrc/post.hip); larger class counts return OM_EINVAL with that message.
+ * out_bbox [B,nms_post,5] (cx,cy,w,h normalised, score); out_cls [B,nms_post] int64;
  * out_mask [B,nms_post,image_h,image_w] uint8 0/1 (rows >= out_count[b] are left untouched);
  * out_count [B] int32; out_keep [B,nms_post] int32 position of each detection in the
  * pre-NMS candidate list, may be NULL.  oriens as written by om_forward. */
 int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbox16, const float* bbox8,
                    const float* oriens, int B, float* out_bbox, int64_t* out_cls, uint8_t* out_mask,
                    int32_t* out_count, int32_t* out_keep, void* workspace, size_t ws_bytes, om_stream stream);
+
+/* The same postprocess around a caller-supplied NMS callable -- the reference takes ANY nms_func(dets, cls) -> (dets[keep],
+ * cls[keep], keep) (/root/reference/eval/orienmask_yolo_postprocess.py:9-11,146-148); the fused om_postprocess implements
+ * batched_nms itself.  om_postprocess_candidates: decode, threshold and top-nms_pre (postprocess.py:102-122): cand_dets
+ * [B,nms_pre,5] (cx, cy, w, h, score), cand_cls [B,nms_pre], cand_field [B,nms_pre] (anchor field of the candidate: its
+ * orientation channels are 2 * field, 2 * field + 1), cand_count [B], in the order the reference hands them to self.nms.  The
+ * caller runs its callable per image, applies the top-nms_post of postprocess.py:150-154 and hands the survivors to
+ * om_postprocess_masks: dets [B,nms_post,5], field [B,nms_post], count [B] (device) -> out_mask [B,nms_post,image_h,image_w]
+ * (postprocess.py:156-164).  Same workspace size as om_postprocess. */
+int om_postprocess_candidates(const om_post_cfg* cfg, const float* bbox32, const float* bbox16, const float* bbox8, int B,
+                              float* cand_dets, int64_t* cand_cls, int32_t* cand_field, int32_t* cand_count, void* workspace,
+                              size_t ws_bytes, om_stream stream);
+int om_postprocess_masks(const om_post_cfg* cfg, const float* oriens, int B, const float* dets, const int32_t* field,
+                         const int32_t* count, uint8_t* out_mask, void* workspace, size_t ws_bytes, om_stream stream);
 
 /* measurement: launch geometry and resource use of the three postprocess kernels (which: 0 = post_decode_kernel,
  * 1 = post_select_kernel, 2 = post_mask_kernel) as the runtime reports them for this device: threads per workgroup, VGPRs
@@ -334,6 +359,23 @@ int om_recover_bbox(const float* bbox, int K, int stride, const int32_t* collate
 int om_recover_masks_rle(const uint8_t* mask, int K, int H, int W, int crop_top, int crop_down, int crop_left,
                          int crop_right, int hflip, int vflip, int orig_h, int orig_w, uint32_t* counts, int max_runs,
                          int32_t* n_runs, uint8_t* resized_or_null, om_stream stream);
+/* om_recover_masks_rle_strings: the same conversion for a whole BATCH in one launch, ending on the device with what the
+ *   reference gets from maskUtils.encode(...)['counts'] (/root/reference/eval/coco_eval.py:120-122): pycocotools' rleToString
+ *   of every mask's run lengths (published algorithm of cocoapi common/maskApi.c; the library is absent offline, so the
+ *   STRING is pinned against oracle/rle_ref.c only).  images: HOST array, one entry per image (K may be 0); masks are numbered
+ *   image after image.  counts [sum K][max_runs] scratch for the run lengths, n_runs [sum K] (> max_runs: that mask needs a
+ *   larger buffer, its str_off is -1).  Every mask appends its string to ONE byte buffer: str_cursor[0] = bytes reserved
+ *   (zeroed by the caller), str_cursor[1] = masks whose string did not fit str_capacity; str_off / str_len [sum K].  The host
+ *   then copies the cursor + offsets and bytes[0:cursor] once per batch instead of 30 MB of masks per image. */
+typedef struct om_rle_image {
+    const uint8_t* mask;        /* [K,H,W] u8 0/1, device */
+    int32_t K, H, W;
+    int32_t crop_top, crop_down, crop_left, crop_right;
+    int32_t hflip, vflip, orig_h, orig_w;
+} om_rle_image;
+int om_recover_masks_rle_strings(const om_rle_image* images, int n_images, uint32_t* counts, int max_runs, int32_t* n_runs,
+                                 uint8_t* str_bytes, long long str_capacity, int32_t* str_cursor, int32_t* str_off,
+                                 int32_t* str_len, om_stream stream);
 
 /* ---- unit-test entry: the elementary functions the decode uses, restated bit-exactly from what torch-CPU runs at the
  * reference's call sites eval/orienmask_yolo_postprocess.py:127-136 (csrc/ref_math.h).  func: 0 = glibc expf (torch's

@@ -7,6 +7,12 @@ size and rounded (`_recover_shape_segm`, :191-205) and run-length encoded like
 (``om_recover_bbox`` / ``om_recover_masks_rle``); only the run lengths are copied to the host, where they are
 packed into pycocotools' string form.  pycocotools itself is not available offline: the string packing restates
 its published ``rleToString`` and is unpinned; boxes, resized masks and run lengths are pinned.
+
+Round 4: ``COCOFormatter.to_coco_format`` converts a whole batch with the strings packed ON THE DEVICE
+(``om_recover_masks_rle_strings``): every image's kernels are enqueued without a host read, all masks append their
+strings to one byte buffer, and the host makes three copies per batch (boxes + scores + classes; string offsets;
+the used part of the byte buffer).  ``rle_to_string`` below stays as the slow path of a mask whose runs or string
+overflow the first-guess buffers, and as the single-mask helper ``recover_masks_rle`` uses.
 """
 import ctypes
 
@@ -43,6 +49,14 @@ def _crop_of(sample_info):
         t, d, l, r = sample_info["pad"][:4]
         left += l; right += r; top += t; down += d
     return top, down, left, right
+
+
+def _rle_image(mask_u8, sample_info):
+    """om_rle_image of one image's [K,H,W] uint8 masks."""
+    top, down, left, right = _crop_of(sample_info)
+    return _lib.RleImage(mask_u8.data_ptr(), mask_u8.shape[0], mask_u8.shape[1], mask_u8.shape[2], top, down, left, right,
+                         int(bool(sample_info.get("hflip", False))), int(bool(sample_info.get("vflip", False))),
+                         int(sample_info["height"]), int(sample_info["width"]))
 
 
 def recover_shape_bbox(bbox, sample_info):
@@ -104,24 +118,104 @@ def recover_masks_rle(mask, sample_info, max_runs=None, return_resized=False):
 class COCOFormatter:
     """to_coco_format of COCOMetrics without pycocotools: same result dicts, computed on the device."""
 
+    MAX_RUNS = 8192                 # first-guess run buffer per mask (a 544^2 orientation mask has a few hundred runs)
+    BYTES_PER_MASK = 4096           # first-guess share of the batch's string buffer per mask
+
     def __init__(self, cat2label, with_mask=True):
         self.cat2label = list(cat2label)
         self.with_mask = with_mask
 
+    @staticmethod
+    def _worst_case_strings(items):
+        """[(mask [1,H,W], info)] -> strings, with buffers for the worst case (every pixel its own run, six characters per
+        run): one launch, two host reads."""
+        L = _lib.load()
+        dev = items[0][0].device
+        n = len(items)
+        full = max(int(i["height"]) * int(i["width"]) for _, i in items) + 1
+        cap = min(6 * full * n, (1 << 31) - 2)
+        counts = torch.empty((n, full), dtype=torch.int32, device=dev)
+        hdr = torch.zeros(2 + 3 * n, dtype=torch.int32, device=dev)            # cursor, overflow | off | len | n_runs
+        sbytes = torch.empty(cap, dtype=torch.uint8, device=dev)
+        masks = [m.contiguous().view(torch.uint8) for m, _ in items]
+        imgs = (_lib.RleImage * n)(*[_rle_image(m, i) for m, (_, i) in zip(masks, items)])
+        with torch.cuda.device(dev):
+            _lib.check(L.om_recover_masks_rle_strings(
+                imgs, n, ctypes.c_void_p(counts.data_ptr()), full, ctypes.c_void_p(hdr.data_ptr() + (2 + 2 * n) * 4),
+                ctypes.c_void_p(sbytes.data_ptr()), cap, ctypes.c_void_p(hdr.data_ptr()), ctypes.c_void_p(hdr.data_ptr() + 8),
+                ctypes.c_void_p(hdr.data_ptr() + (2 + n) * 4), _lib.current_stream_ptr(dev)), "om_recover_masks_rle_strings")
+        h = hdr.cpu().tolist()
+        if h[1] or any(o < 0 for o in h[2:2 + n]):
+            raise _lib.OrienMaskHipError("RLE strings of %d masks do not fit %d bytes" % (n, cap))
+        raw = bytes(sbytes[:h[0]].cpu().numpy())
+        return [raw[o:o + ln].decode("ascii") for o, ln in zip(h[2:2 + n], h[2 + n:2 + 2 * n])]
+
     def to_coco_format(self, batch_info, detections):
-        bbox_results, segm_results = [], []
-        for info, det in zip(batch_info, detections):
-            if det["bbox"].numel() == 0:
-                continue
-            scores = det["bbox"][:, -1].tolist()
-            cats = [self.cat2label[c] for c in det["cls"].flatten().tolist()]
-            xywh = recover_shape_bbox(det["bbox"], info).tolist()
-            for box, score, cat in zip(xywh, scores, cats):
-                bbox_results.append({"image_id": info["id"], "category_id": cat, "bbox": box, "score": score})
-            if self.with_mask:
-                for rle, score, cat in zip(recover_masks_rle(det["mask"], info), scores, cats):
-                    segm_results.append({"image_id": info["id"], "category_id": cat, "segmentation": rle, "score": score})
-        out = {"bbox": bbox_results}
+        """/root/reference/eval/coco_eval.py:57-63 for one batch.  Nothing is read back until every image's kernels are
+        enqueued; then boxes / scores / classes come in one copy, the strings in two (offsets, bytes)."""
+        pairs = [(info, det) for info, det in zip(batch_info, detections) if det["bbox"].numel() != 0]
+        out = {"bbox": []}
         if self.with_mask:
-            out["segm"] = segm_results
+            out["segm"] = []
+        if not pairs:
+            return out
+        dev = pairs[0][1]["bbox"].device
+        _lib.require_cuda_tensor(pairs[0][1]["bbox"], "bbox", torch.float32)
+        L = _lib.load()
+        Ks = [int(det["bbox"].shape[0]) for _, det in pairs]
+        N = sum(Ks)
+        starts = [0]
+        for k in Ks:
+            starts.append(starts[-1] + k)
+        xywh = torch.empty((N, 4), dtype=torch.float32, device=dev)
+        st = _lib.current_stream_ptr(dev)
+        with torch.cuda.device(dev):
+            for (info, det), s0, K in zip(pairs, starts, Ks):
+                b = det["bbox"].contiguous()
+                cp, pd = info.get("collate_pad"), info.get("pad")
+                cp_arr = (ctypes.c_int32 * 6)(*[int(v) for v in cp]) if cp is not None else None
+                pd_arr = (ctypes.c_int32 * 6)(*[int(v) for v in pd]) if pd is not None else None
+                _lib.check(L.om_recover_bbox(ctypes.c_void_p(b.data_ptr()), K, b.shape[1], cp_arr, pd_arr,
+                                             int(bool(info.get("hflip", False))), int(bool(info.get("vflip", False))),
+                                             int(info["height"]), int(info["width"]),
+                                             ctypes.c_void_p(xywh.data_ptr() + s0 * 16), st), "om_recover_bbox")
+            if self.with_mask:
+                cap = N * self.BYTES_PER_MASK
+                hdr = torch.zeros(2 + 3 * N, dtype=torch.int32, device=dev)   # cursor, overflow | off[N] | len[N] | n_runs[N]
+                sbytes = torch.empty(cap, dtype=torch.uint8, device=dev)
+                counts = torch.empty((N, self.MAX_RUNS), dtype=torch.int32, device=dev)
+                masks = []                                                      # keep the uint8 views alive until the launch
+                imgs = (_lib.RleImage * len(pairs))()
+                for i, (info, det) in enumerate(pairs):
+                    _lib.require_cuda_tensor(det["mask"], "mask")
+                    masks.append(det["mask"].contiguous().view(torch.uint8))
+                    imgs[i] = _rle_image(masks[-1], info)
+                _lib.check(L.om_recover_masks_rle_strings(
+                    imgs, len(pairs), ctypes.c_void_p(counts.data_ptr()), self.MAX_RUNS, ctypes.c_void_p(hdr.data_ptr() + (2 + 2 * N) * 4),
+                    ctypes.c_void_p(sbytes.data_ptr()), cap, ctypes.c_void_p(hdr.data_ptr()), ctypes.c_void_p(hdr.data_ptr() + 8),
+                    ctypes.c_void_p(hdr.data_ptr() + (2 + N) * 4), st), "om_recover_masks_rle_strings")
+        # ---- the batch's host reads
+        meta = torch.cat([xywh, torch.cat([det["bbox"][:, -1:] for _, det in pairs]),
+                          torch.cat([det["cls"].reshape(-1, 1).to(torch.float32) for _, det in pairs])], dim=1).cpu()
+        boxes = meta[:, :4].tolist()
+        scores = meta[:, 4].tolist()
+        cats = [self.cat2label[int(c)] for c in meta[:, 5].tolist()]
+        ids = [info["id"] for (info, _), K in zip(pairs, Ks) for _ in range(K)]
+        out["bbox"] = [{"image_id": i, "category_id": c, "bbox": b, "score": s} for i, c, b, s in zip(ids, cats, boxes, scores)]
+        if self.with_mask:
+            h = hdr.cpu().tolist()
+            used = min(h[0], cap)
+            raw = bytes(sbytes[:used].cpu().numpy()) if used > 0 else b""
+            offs, lens = h[2:2 + N], h[2 + N:2 + 2 * N]
+            sizes = [[int(info["height"]), int(info["width"])] for (info, _), K in zip(pairs, Ks) for _ in range(K)]
+            strings = [raw[o:o + n].decode("ascii") if o >= 0 else None for o, n in zip(offs, lens)]
+            if any(s is None for s in strings):
+                # masks with more runs than MAX_RUNS, or a batch whose strings outgrew the buffer: those masks again, in one
+                # launch, with worst-case buffers (still packed on the device)
+                todo = [(s0 + k, det["mask"][k:k + 1], info) for (info, det), s0, K in zip(pairs, starts, Ks) for k in range(K)
+                        if strings[s0 + k] is None]
+                for (idx, _, _), text in zip(todo, self._worst_case_strings([(m, i) for _, m, i in todo])):
+                    strings[idx] = text
+            out["segm"] = [{"image_id": i, "category_id": c, "segmentation": {"size": sz, "counts": cs}, "score": s}
+                           for i, c, sz, cs, s in zip(ids, cats, sizes, strings, scores)]
         return out

@@ -35,6 +35,9 @@ namespace om {
 #ifndef OM_SPLIT_TRACE
 #define OM_SPLIT_TRACE 0       // measurement builds only: s_memtime stamps per tile of the wide kernel (tools/split_trace.py)
 #endif
+#if (OM_SPLIT_TRACE) && !defined(OM_MEASUREMENT_BUILD)
+#error "measurement switches (wrong numerics / trace stores) are only for ab/ variants: build them with tools/build_variant.sh, which defines OM_MEASUREMENT_BUILD and never writes orienmask_amd/lib/"
+#endif
 #if OM_SPLIT_TRACE
 static unsigned long long* g_split_trace = nullptr;
 extern "C" void om_debug_split_trace(void* buf) { g_split_trace = static_cast<unsigned long long*>(buf); }

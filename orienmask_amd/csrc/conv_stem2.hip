@@ -17,6 +17,9 @@
 //      store).
 // LDS: weights 73 728 + activations 17 x 36 x 128 = 78 336 + patch 7 980 bytes: one 512-thread workgroup per CU, tiles by a
 // static stride (every tile costs the same).
+#if defined(OM_S2_TRACE) && !defined(OM_MEASUREMENT_BUILD)
+#error "OM_S2_TRACE writes time stamps through the status word and disables the range guard: only for ab/ variants (tools/build_variant.sh defines OM_MEASUREMENT_BUILD and never writes orienmask_amd/lib/)"
+#endif
 #include "om_common.h"
 
 namespace om {

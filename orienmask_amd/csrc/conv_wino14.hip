@@ -53,8 +53,16 @@ typedef unsigned u32x4v __attribute__((__vector_size__(4 * sizeof(unsigned))));
 #ifndef OM_W14_TRACE
 #define OM_W14_TRACE 0         // measurement builds only: s_memtime stamps of one tile's groups (tools/wino14_trace.py)
 #endif
+#if (OM_W14_ABLATE || OM_W14_TRACE) && !defined(OM_MEASUREMENT_BUILD)
+#error "measurement switches (wrong numerics / trace stores) are only for ab/ variants: build them with tools/build_variant.sh, which defines OM_MEASUREMENT_BUILD and never writes orienmask_amd/lib/"
+#endif
+#ifndef W14_RING
+#define W14_RING 3             // weight-ring slots.  4: blocks of (R + 2) * Ct <= 144 entries (two V buffers of 110 592 B leave room for a
+#endif                         // fourth 12 KiB slot), a group's first fragments are read BEFORE the barrier that starts it (no LDS round
+                               // trip between the barrier and the group's first matrix instruction) and its weights still have two
+                               // groups to land (requested three groups ahead)
 constexpr int W14_BM = 128, W14_BN = 64;
-constexpr int W14_EMAX = 160;                 // LDS entries per plane: (R + 2) * Ct <= 160
+constexpr int W14_EMAX = W14_RING == 4 ? 144 : 160;      // LDS entries per plane: (R + 2) * Ct <= W14_EMAX
 constexpr int W14_VPLANE = W14_EMAX * 4;      // f32x4 units (16 B) per plane
 constexpr int W14_VBUF = 6 * W14_VPLANE;      // one transformed chunk: 61440 B
 constexpr int W14_UGRP = 3 * W14_BN * 4;      // one (j; ky = 0..2) weight group: 12288 B
@@ -65,11 +73,15 @@ constexpr int W14_UGRP = 3 * W14_BN * 4;      // one (j; ky = 0..2) weight group
 #define W14_QUEUE 0            // per-XCD tile queues: 0 = M blocks partitioned (N-tile siblings share the input behind one L2),
 #endif                         // 1 = N tiles partitioned (an XCD streams one or two N tiles' weights: they stay in its L2)
 #ifndef W14_B_ACROSS
-#define W14_B_ACROSS 0         // 1: the first weight fragments of a group are read before the barrier that starts it (its weights
-#endif                         // landed a group earlier); 0: after it -- the requests get two groups to land
+#define W14_B_ACROSS (W14_RING == 4)   // 1: the first weight fragments of a group are read before the barrier that starts it (its weights
+#endif                         // landed a group earlier); 0: after it -- the requests get two groups to land (three-slot ring)
 #ifndef W14_DMA_AFTER
 #define W14_DMA_AFTER 0        // the weight request follows the matrix instructions of this kernel row of the group
 #endif
+#ifndef W14_DMA_WAVES
+#define W14_DMA_WAVES 0        // who requests a weight group's twelve 1-KiB pieces: 0 = every consumer wave one, waves 0-3 a second one;
+#endif                         // 1 = waves 0-3 three each (they reach the group barrier ~280 cycles before waves 4-7: a request that
+                               // stalls on a full vector-memory queue costs them slack instead of matrix-instruction issue)
 constexpr int W14_THREADS = 768;              // waves 0-7: consumers (LDS reads + matrix instructions), 8-11: producers
 
 struct Wino14Params {
@@ -286,8 +298,8 @@ __device__ __forceinline__ void wino14_epilogue(const Wino14Params& p, const f32
 // MODE: the epilogue's form -- 0 buffer-descriptor stores, no residual; 1 the same with a residual; 2 any view, any cout
 template <int MODE>
 __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino14Params p) {
-    __shared__ f32x4 smem[2 * W14_VBUF + 3 * W14_UGRP + 1];      // ONE LDS object (conv_igemm.hip); last 16 B: two ticket words
-    int* const s_ticket = reinterpret_cast<int*>(smem + 2 * W14_VBUF + 3 * W14_UGRP);
+    __shared__ f32x4 smem[2 * W14_VBUF + W14_RING * W14_UGRP + 1];      // ONE LDS object (conv_igemm.hip); last 16 B: two ticket words
+    int* const s_ticket = reinterpret_cast<int*>(smem + 2 * W14_VBUF + W14_RING * W14_UGRP);
     f32x4* const s_u = smem + 2 * W14_VBUF;
 
     const int tid = threadIdx.x;
@@ -388,6 +400,8 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
             // a pixel outside the image (or a pad row) gets an offset beyond the descriptor's range: the load returns zeros
             int off = ((xok[k] >> x) & 1u) ? xbase[k] + x * p.in_ps * 4 + c * 64 : (int)0x80000000;
             if (OM_W14_ABLATE & 512) off = lane * 16 + (k * 6 + x) * 1024;      // measurement: every request hits the same 18 KiB
+            if ((OM_W14_ABLATE & 16384) && (c & 1)) off = (int)0x80000000;     // measurement: half the input requests (odd chunks none)
+            if ((OM_W14_ABLATE & 32768) && (x == 0 || x == 5)) off = (int)0x80000000;   // measurement: no halo pixels (4 of 6 requests)
             return off;
         };
         // pixels [x0, x1) of an item
@@ -589,10 +603,11 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
     // weight-group DMA: a group's 192 rows of 64 bytes are twelve 1-KiB pieces of 16 rows; wave w requests piece w, waves 0-3
     // also piece 8 + w
     const int drow = lane >> 2, dcol = lane & 3;
-    int dvo[2];
+    constexpr int W14_NPIECE = W14_DMA_WAVES ? 3 : 2, W14_PSTEP = W14_DMA_WAVES ? 4 : 8;
+    int dvo[W14_NPIECE];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = 16 * (wave + 8 * i) + drow;
+    for (int i = 0; i < W14_NPIECE; ++i) {
+        const int row = 16 * (wave + W14_PSTEP * i) + drow;
         dvo[i] = row * 64 + ((dcol ^ ((row >> 2) & 3)) * 16);      // swizzle on the SOURCE chunk: the LDS image stays lane-linear
     }
     const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.u), 0, p.u_bytes, 0x00020000);
@@ -612,11 +627,21 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
     // weight group g = 6 c + j of N tile tn: 12 KiB at ((tn * nch + c) * 6 + j) * 12288 bytes of the packed blob
     auto issue_group = [&](int ubase, int g) {
         if (!(OM_W14_ABLATE & 8) && g < ngroups) {
-            const int slot = g % 3;
+            const int slot = g % W14_RING;
             const int soff = ubase + (g - g % 6 + w14_plane(g % 6)) * (W14_UGRP * 16);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14_UGRP + wave * 64), 16, dvo[0], soff, 0, 0);
+            // measurement (65536): every second weight group is not requested (the DMA writes zeros for out-of-range offsets)
+            const int oob = ((OM_W14_ABLATE & 65536) && (g & 1)) ? (int)0x80000000 : 0;
+            if (W14_DMA_WAVES) {
+                if (wave < 4) {
+#pragma unroll
+                    for (int i = 0; i < W14_NPIECE; ++i)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14_UGRP + (wave + 4 * i) * 64), 16, dvo[i] | oob, soff, 0, 0);
+                }
+            } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14_UGRP + wave * 64), 16, dvo[0] | oob, soff, 0, 0);
             if (wave < 4)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14_UGRP + (wave + 8) * 64), 16, dvo[1], soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14_UGRP + (wave + 8) * 64), 16, dvo[1] | oob, soff, 0, 0);
+            }
         }
     };
     Wino14Tile tl;
@@ -626,6 +651,7 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
         const int ubase = tl.tile_n * p.nch * 6 * (W14_UGRP * 16);
         issue_group(ubase, 0);
         issue_group(ubase, 1);
+        if (W14_RING == 4) issue_group(ubase, 2);
     }
     while (tile < p.total_tiles) {
         const int ubase = tl.tile_n * p.nch * 6 * (W14_UGRP * 16);
@@ -687,14 +713,14 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
             // (six explicit instances, not a loop the optimizer may decline to unroll: acc[] must stay in registers)
             auto group = [&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                const int slot = g % 3, slot1 = slot == 2 ? 0 : slot + 1;
+                const int slot = g % W14_RING, slot1 = slot == W14_RING - 1 ? 0 : slot + 1;
 #if OM_W14_TRACE
                 unsigned long long ta, tb = 0, tc = 0, td;
                 W14_STAMP(ta);
 #endif
                 // groups g and g + 1 are in LDS; every wave has left group g - 1: its slot takes group g + 2 (requested below),
                 // which has to land by the end of this group
-                if (W14_DMA_AFTER < 0) issue_group(ubase, g + 2);
+                if (W14_DMA_AFTER < 0) issue_group(ubase, g + W14_RING - 1);
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     if constexpr (OM_W14_ABLATE & 2048) continue;       // idle consumers: the producers' own speed
@@ -712,11 +738,16 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
                     for (int i = 0; i < 4; ++i) ca[i] = na[i];
                     // the request (60-200 cycles of issue) behind the first matrix instructions, not in front of them
                     if (ky == W14_DMA_AFTER) {
-                        issue_group(ubase, g + 2);
+                        issue_group(ubase, g + W14_RING - 1);
                     }
                 }
                 // my pieces of weight group g + 2 have landed; my reads of this group's slot and plane are done
-                if (W14_B_ACROSS || g + 2 >= ngroups) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (OM_W14_ABLATE & 131072) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // measurement: late weights are not waited for
+                else if ((W14_B_ACROSS && W14_RING == 3) || g + W14_RING - 1 >= ngroups) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else if (W14_DMA_WAVES) {
+                    if (wave < 4) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // these waves requested nothing
+                }
                 else if (wave < 4) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");      // all but the pieces requested in this group
                 else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
 #if OM_W14_TRACE
@@ -748,6 +779,7 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
                 const int ub = tn.tile_n * p.nch * 6 * (W14_UGRP * 16);
                 issue_group(ub, 0);
                 issue_group(ub, 1);
+                if (W14_RING == 4) issue_group(ub, 2);
             }
         });
 #if OM_W14_TRACE

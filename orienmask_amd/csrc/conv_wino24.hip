@@ -17,6 +17,9 @@
 // scale, against 3.6e-7 for F(2x2) and 2.4e-7 for MKLDNN's direct fp32 -- the F(4,3) matrices carry the constants
 // 4, 5, 2 (input), 1/4, 1/6, 1/12, 1/24 (weights, applied on the host in float64) and 2, 4, 8 (output; exact scalings).
 // Far inside the 1e-4 parity budget; the full-size F(4x4,3x3) would be at 4.8e-6 and needs 16 output accumulators.
+#if (defined(OM_EXP_V_RESIDENT) || defined(OM_EXP_U_RESIDENT)) && !defined(OM_MEASUREMENT_BUILD)
+#error "OM_EXP_*_RESIDENT read stale operands (upper-bound experiments): only for ab/ variants (tools/build_variant.sh defines OM_MEASUREMENT_BUILD and never writes orienmask_amd/lib/)"
+#endif
 #include <cstdlib>
 
 #include "om_common.h"

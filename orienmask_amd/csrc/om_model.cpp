@@ -287,8 +287,9 @@ struct om_model {
 
     // split-operand mode: conv1 (the stem) and conv2.0 run as ONE kernel (conv_stem2.hip) when the second is the 32 -> 64 3x3
     // stride-2 layer reading the first one's output -- unless every activation is kept for om_layer_output_view
-    bool stem2_fused(size_t index) const {
-        if (precision != 1 || keep_all || index != 0 || layers.size() < 2 || !layers[0].stem) return false;
+    // (never in the fp16-activation forward, whatever the precision mode says: its buffers hold 2-byte elements)
+    bool stem2_fused(size_t index, bool f16 = false) const {
+        if (f16 || precision != 1 || keep_all || index != 0 || layers.size() < 2 || !layers[0].stem) return false;
         const om::LayerDef& a = layers[0];
         const om::LayerDef& b = layers[1];
         return a.info.cout == 32 && b.info.cin == 32 && b.info.cout == 64 && b.info.cout_pad == 64 && b.info.ksize == 3 &&
@@ -533,7 +534,7 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
             continue;
         }
-        if (L.stem && m->stem2_fused(&L - m->layers.data())) {
+        if (L.stem && m->stem2_fused(&L - m->layers.data(), f16)) {
             // split-operand mode: conv1 and conv2.0 as one kernel (conv_stem2.hip) -- conv1's activation never reaches memory
             const om::LayerDef& N = m->layers[(&L - m->layers.data()) + 1];
             if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));

@@ -65,6 +65,14 @@ struct PostParams {
     uint8_t* out_mask;
     int32_t* out_count;
     int32_t* out_keep;
+    // anchors per scale (om_post_cfg.anchors_of_scale, or anchors_per_scale for every scale) and their prefix sums: anchor FIELD
+    // a_off[s] + a owns orientation channels 2 * field and 2 * field + 1 (the heads' orientation maps concatenated, scale after scale)
+    int a_cnt[OM_MAX_SCALES];
+    int a_off[OM_MAX_SCALES + 1];
+    // om_postprocess_candidates: the select kernel stops after the candidate list (for a caller-supplied NMS callable)
+    float* cand_dets;      // [B][nms_pre][5] in the reference's LIST order (postprocess.py:102-122); NULL: the fused path
+    int64_t* cand_cls;     // [B][nms_pre]
+    int32_t* cand_field;   // [B][nms_pre] anchor field of the candidate
 };
 
 // candidate index -> (scale, anchor slot, pixel)
@@ -76,6 +84,49 @@ __device__ __forceinline__ void locate(const PostParams& p, int cand, int& s, in
     const int a1 = local >= hw, a2 = local >= 2 * hw;
     a = a1 + a2;
     pix = local - (a1 ? hw : 0) - (a2 ? hw : 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Index-deciding comparisons without compare instructions (round 4; DESIGN.md 3.2, tools/hazard_probe).
+// On MI355X a dense run of VALU compares into SGPR pairs that SALU combines (v_cmp_*_e64 -> s_and_b64 / s_or_b64 ->
+// v_cndmask) returned STALE lane masks while a co-resident wave of another kernel issued gfx950's wide-K matrix instructions;
+// single compares through VCC and divergent branches never did (profiles/r02_experiments.md section 6).  Whatever decides an
+// INDEX here -- which pair passes conf_thresh, which box suppresses which, the order of the sort -- is therefore evaluated on
+// bit patterns in VGPRs: a predicate is bit 0 of an unsigned, conjunctions are ANDs, and the only compare left is the "!= 0" of
+// the branch that consumes the result (the VCC / exec-mask class).  The subtraction is inline asm so that the compiler cannot
+// fold the borrow test back into a compare.  Bit-identical to the IEEE comparisons for every operand (NaN: false; -0 == +0).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned sub_u32_opaque(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_sub_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a < b for any two 32-bit unsigned values: the borrow out of a - b
+__device__ __forceinline__ unsigned lt_u32_bit(unsigned a, unsigned b) {
+    return ((~a & b) | ((~a | b) & sub_u32_opaque(a, b))) >> 31;
+}
+__device__ __forceinline__ unsigned eq_u32_bit(unsigned a, unsigned b) {
+    const unsigned x = a ^ b;
+    return ((x | sub_u32_opaque(0u, x)) >> 31) ^ 1u;
+}
+// a < b for non-negative ints below 2^31 (pair indices, keys of confidences <= 1): the sign of the difference
+__device__ __forceinline__ unsigned lt_i31_bit(int a, int b) { return sub_u32_opaque((unsigned)a, (unsigned)b) >> 31; }
+// float -> unsigned key with the IEEE order of the numbers (sign-magnitude -> biased two's complement; -0 and +0 share a key)
+__device__ __forceinline__ unsigned f32_order_key(float x) {
+    const int b = __float_as_int(x), sg = b >> 31;
+    return (unsigned)(((b & 0x7fffffff) ^ sg) - sg) ^ 0x80000000u;
+}
+__device__ __forceinline__ unsigned f32_is_num_bit(float x) { return lt_u32_bit(__float_as_uint(x) & 0x7fffffffu, 0x7f800001u); }
+__device__ __forceinline__ unsigned f32_gt_bit(float a, float t) {      // a > t
+    return lt_u32_bit(f32_order_key(t), f32_order_key(a)) & f32_is_num_bit(a) & f32_is_num_bit(t);
+}
+__device__ __forceinline__ unsigned f32_ge_bit(float a, float t) {      // a >= t
+    return (lt_u32_bit(f32_order_key(a), f32_order_key(t)) ^ 1u) & f32_is_num_bit(a) & f32_is_num_bit(t);
+}
+// a < b for two 64-bit sort words (key << 32 | ~position)
+__device__ __forceinline__ unsigned lt_u64_bit(unsigned long long a, unsigned long long b) {
+    const unsigned ah = (unsigned)(a >> 32), bh = (unsigned)(b >> 32);
+    return lt_u32_bit(ah, bh) | (eq_u32_bit(ah, bh) & lt_u32_bit((unsigned)a, (unsigned)b));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -108,9 +159,9 @@ __global__ __launch_bounds__(256) void post_decode_kernel(const PostParams p) {
     // class logits are neither loaded nor evaluated -- on real heads that is nearly every candidate (background cells), and in
     // the vectorised sweep a wave is one candidate, so the skip is a whole-wave branch.
     const float thr = p.cfg.conf_thresh;
-    auto in_tile = [&](int cand_l, int cls, bool live) {
+    auto in_tile = [&](int cand_l, int cls, bool live) -> unsigned {
         const int pair = (cand_first + cand_l) * C + cls;
-        return live && pair >= P0 && pair < P1 && s_obj[cand_l] > thr;
+        return (live ? 1u : 0u) & (lt_i31_bit(pair, P0) ^ 1u) & lt_i31_bit(pair, P1) & f32_gt_bit(s_obj[cand_l], thr);
     };
     // The per-scale constants by STATIC index into the parameter block (scalar loads, once) and selects: p.bbox[s] with a run-time s
     // is a memory load per visit, and the logit's load then waits for it -- one dependent round trip per visit again.
@@ -144,7 +195,7 @@ __global__ __launch_bounds__(256) void post_decode_kernel(const PostParams p) {
         unsigned key = 0;
         if (in_tile(cand_l, cls, live)) {
             const float conf = (decltype(vector_path)::value ? sigmoid_vector_ref(x) : sigmoid_scalar_ref(x, s_tab)) * s_obj[cand_l];
-            if (conf > thr) {
+            if (f32_gt_bit(conf, thr)) {
                 key = __float_as_uint(conf);
                 atomicAdd(&hist[key >> 19], 1u);
                 ++cnt;
@@ -194,7 +245,7 @@ __global__ __launch_bounds__(256) void post_decode_kernel(const PostParams p) {
     for (int i = tid; i < ncand_t; i += 256) {
         const float so = sigmoid_scalar_ref(logit_ptr(cand_first + i)[4], s_tab);
         s_obj[i] = so;
-        if (so > thr) s_any = 1;
+        if (f32_gt_bit(so, thr)) s_any = 1;
     }
     __syncthreads();
     if (!s_any) {      // no candidate of this tile can pass (the usual case on real heads): no keys, no histogram
@@ -274,8 +325,8 @@ __device__ __forceinline__ void bitonic_sort_desc(unsigned long long* v, int n_p
                 const int partner = i ^ j;
                 if (partner > i) {
                     const unsigned long long a = v[i], c = v[partner];
-                    const bool desc = (i & k) == 0;
-                    if (desc ? (a < c) : (a > c)) { v[i] = c; v[partner] = a; }
+                    const unsigned desc = sub_u32_opaque((unsigned)(i & k), 1u) >> 31;      // (i & k) == 0
+                    if ((desc & lt_u64_bit(a, c)) | ((desc ^ 1u) & lt_u64_bit(c, a))) { v[i] = c; v[partner] = a; }
                 }
             }
             __syncthreads();
@@ -303,7 +354,7 @@ __device__ __forceinline__ unsigned long long nms_mask_word(const float* sx1, co
             const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
             const float inter = w * h;
             const float ovr = inter / (ia + sarea[pj] - inter);
-            if (strict ? (ovr > thr) : (ovr >= thr)) bits |= 1ull << jj;
+            bits |= (unsigned long long)(strict ? f32_gt_bit(ovr, thr) : f32_ge_bit(ovr, thr)) << jj;
         }
     }
     return bits;
@@ -412,7 +463,7 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
             if (!caseA) {      // list position = rank of the pair index among the n pairs (the index-ordered list of case B)
                 const unsigned my_lo = (unsigned)mine;
                 pos = 0;
-                for (int i = 0; i < n; ++i) pos += (unsigned)s_list[i] > my_lo;      // ~pair larger <=> pair smaller
+                for (int i = 0; i < n; ++i) pos += (int)lt_u32_bit(my_lo, (unsigned)s_list[i]);      // ~pair larger <=> pair smaller
             }
         }
         __syncthreads();
@@ -446,7 +497,7 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
                 const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (kk[e] != 0 && (kk[e] >> 19) == t1) atomicAdd(&hist[(kk[e] >> 8) & 0x7FFu], 1u);
+                    if ((eq_u32_bit(kk[e], 0u) ^ 1u) & eq_u32_bit(kk[e] >> 19, t1)) atomicAdd(&hist[(kk[e] >> 8) & 0x7FFu], 1u);
             }
         }
         __syncthreads();
@@ -467,7 +518,7 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
                 const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (kk[e] != 0 && (kk[e] >> 8) == hi) atomicAdd(&hist[kk[e] & 0xFFu], 1u);
+                    if ((eq_u32_bit(kk[e], 0u) ^ 1u) & eq_u32_bit(kk[e] >> 8, hi)) atomicAdd(&hist[kk[e] & 0xFFu], 1u);
             }
         }
         __syncthreads();
@@ -492,8 +543,8 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
             int ngt = 0, neq = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                ngt += kk[e] > T;
-                neq += (T != 0 && kk[e] == T);
+                ngt += (int)lt_u32_bit(T, kk[e]);
+                neq += (int)((eq_u32_bit(T, 0u) ^ 1u) & eq_u32_bit(kk[e], T));
             }
             int tot;
             const int ex = block_scan_excl(ngt | (neq << 16), s_wave, tot);
@@ -501,10 +552,10 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int pair = ch * 4096 + tid * 4 + e;
-                if (kk[e] > T) {
+                if (lt_u32_bit(T, kk[e])) {
                     if (pg < SEL_MAXN) { s_key[pg] = kk[e]; s_pair[pg] = pair; }
                     ++pg;
-                } else if (T != 0 && kk[e] == T) {
+                } else if ((eq_u32_bit(T, 0u) ^ 1u) & eq_u32_bit(kk[e], T)) {
                     if (pe < r) { s_key[above + pe] = kk[e]; s_pair[above + pe] = pair; }
                     ++pe;
                 }
@@ -544,6 +595,18 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
         const float bw = expf_cr(q[2]) * (p.cfg.anchor_w[aid] / (float)p.cfg.image_w);
         const float bh = expf_cr(q[3]) * (p.cfg.anchor_h[aid] / (float)p.cfg.image_h);
         s_bx[tid] = bx; s_by[tid] = by; s_bw[tid] = bw; s_bh[tid] = bh;
+        if (p.cand_dets) {      // the candidate list itself, at its LIST position: what the reference hands to self.nms
+            const size_t o = (size_t)b * nms_pre + pos;
+            float* cd = p.cand_dets + o * 5;
+            cd[0] = bx; cd[1] = by; cd[2] = bw; cd[3] = bh;
+            cd[4] = __uint_as_float((unsigned)(s_comp[tid] >> 32));
+            p.cand_cls[o] = pair - cand * C;
+            p.cand_field[o] = p.a_off[s] + a;
+        }
+    }
+    if (p.cand_dets) {
+        if (tid == 0) p.out_count[b] = n;
+        return;
     }
     // class offset, function.py:91-96: cls * (max_coordinate + 0.5); max_coordinate = 1.5 when normalized, else
     // dets[:, :2].max() + dets[:, 2:4].max() / 2 over the candidates of this image
@@ -633,7 +696,7 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
         dp[3] = (p.cfg.orien_thresh * bh) * nH;
         dp[4] = (p.cfg.anchor_w[aid] / (float)p.cfg.image_w) * nW;      // grid_anchors, postprocess.py:21-25
         dp[5] = (p.cfg.anchor_h[aid] / (float)p.cfg.image_h) * nH;
-        dp[6] = __int_as_float((s * p.cfg.anchors_per_scale + a) * 2);  // first orientation channel
+        dp[6] = __int_as_float((p.a_off[s] + a) * 2);                   // first orientation channel
         dp[7] = __int_as_float(s);
     }
 }
@@ -671,11 +734,6 @@ __device__ __forceinline__ unsigned threshold_bits(float t) {
     const unsigned u = __float_as_uint(t);
     return u <= 0x7f800000u ? u : 0u;
 }
-__device__ __forceinline__ unsigned sub_u32_opaque(unsigned a, unsigned b) {
-    unsigned r;
-    asm("v_sub_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 __device__ __forceinline__ unsigned inside_bit(unsigned ax, unsigned tx, unsigned ay, unsigned ty) {
     return (sub_u32_opaque(ax, tx) & sub_u32_opaque(ay, ty)) >> 31;
 }
@@ -697,7 +755,7 @@ __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
     // One thread = a block of 16 x (up to) 4 output pixels that share their two source rows: output rows
     // 4j-2 .. 4j+1 interpolate between source rows j-1 and j (phases 0.125, 0.375, 0.625, 0.875), so the 24 loads
     // and the horizontal taps are done once per block instead of once per row.
-    const int nfields = p.cfg.num_scales * p.cfg.anchors_per_scale;
+    const int nfields = p.a_off[p.cfg.num_scales];
     const int b = blockIdx.y / nfields, field = blockIdx.y - b * nfields;
     // The detections of this (image, anchor field), compacted into LDS once per workgroup: {cx, cy, bits(tx), bits(ty)} and
     // the output slot k; the loop over them below touches no global memory but its own stores.
@@ -731,7 +789,7 @@ __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
     const int item = blockIdx.x * 256 + threadIdx.x;
     if (item >= (oh + 1) * groups) return;
     const int jy = item / groups, g = item - jy * groups;      // source rows jy-1 and jy
-    const int s = field / p.cfg.anchors_per_scale;
+    const int s = (field >= p.a_off[1]) + (field >= p.a_off[2]);       // a_off is padded with the total for unused scales
     const float nW = (float)p.cfg.grid_w[s], nH = (float)p.cfg.grid_h[s];
     const float* px = p.oriens + ((size_t)b * nfields * 2 + field * 2) * oh * ow;
     const float* py = px + (size_t)oh * ow;
@@ -844,6 +902,30 @@ __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
 // Everything that grows with n lives in the workspace, so n is bounded only by NMS_MAXN (the reference has no bound).
 // ------------------------------------------------------------------------------------------------
 constexpr int NMS_MAXN = 1 << 16;
+
+// om_postprocess_masks: the mask constants of detections chosen OUTSIDE the fused path (a caller-supplied NMS callable),
+// postprocess.py:156-164 -- the same arithmetic as the end of post_select_kernel.
+__global__ void post_detpar_kernel(const PostParams p, const float* dets, const int32_t* field) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.B * p.cfg.nms_post) return;
+    const int b = i / p.cfg.nms_post, k = i - b * p.cfg.nms_post;
+    float* dp = p.det_par + (size_t)i * 8;
+    if (k >= p.out_count[b]) return;
+    const int f = field[i];
+    const int s = (f >= p.a_off[1]) + (f >= p.a_off[2]);
+    const int a = f - p.a_off[s];
+    const int aid = p.cfg.anchor_mask[s][a];
+    const float bx = dets[(size_t)i * 5 + 0], by = dets[(size_t)i * 5 + 1], bw = dets[(size_t)i * 5 + 2], bh = dets[(size_t)i * 5 + 3];
+    const float nW = (float)p.cfg.grid_w[s], nH = (float)p.cfg.grid_h[s];
+    dp[0] = nW * bx;
+    dp[1] = nH * by;
+    dp[2] = (p.cfg.orien_thresh * bw) * nW;
+    dp[3] = (p.cfg.orien_thresh * bh) * nH;
+    dp[4] = (p.cfg.anchor_w[aid] / (float)p.cfg.image_w) * nW;
+    dp[5] = (p.cfg.anchor_h[aid] / (float)p.cfg.image_h) * nH;
+    dp[6] = __int_as_float(f * 2);
+    dp[7] = __int_as_float(s);
+}
 
 struct NmsWs { size_t comp, x1, y1, x2, y2, area, keep_flag, keep_pos, mask, total; };
 
@@ -977,27 +1059,42 @@ __global__ void ref_math_kernel(const float* x, long long n, int func, int C, fl
 }
 
 static int fill_params(const om_post_cfg* cfg, PostParams& p) {
-    OM_REQUIRE(cfg->num_scales == 3 && cfg->anchors_per_scale >= 1 && cfg->anchors_per_scale <= 3, OM_EINVAL,
-               "postprocess: %d scales x %d anchors not supported", cfg->num_scales, cfg->anchors_per_scale);
+    OM_REQUIRE(cfg->num_scales >= 1 && cfg->num_scales <= OM_MAX_SCALES, OM_EINVAL, "postprocess: %d scales (1..%d supported)",
+               cfg->num_scales, OM_MAX_SCALES);
+    int a_max = 0;
+    for (int s = 0; s < OM_MAX_SCALES; ++s) {
+        const int a = s >= cfg->num_scales ? 0 : cfg->anchors_of_scale[s] > 0 ? cfg->anchors_of_scale[s] : cfg->anchors_per_scale;
+        OM_REQUIRE(s >= cfg->num_scales || (a >= 1 && a <= 3), OM_EINVAL, "postprocess: scale %d has %d anchors (1..3 supported)", s, a);
+        p.a_cnt[s] = a;
+        a_max = a > a_max ? a : a_max;
+    }
+    p.a_off[0] = 0;
+    for (int s = 0; s < OM_MAX_SCALES; ++s) p.a_off[s + 1] = p.a_off[s] + p.a_cnt[s];
+    p.cand_dets = nullptr; p.cand_cls = nullptr; p.cand_field = nullptr;
     OM_REQUIRE(cfg->image_h % 32 == 0 && cfg->image_w % 32 == 0 && cfg->image_h > 0 && cfg->image_w > 0, OM_EINVAL,
                "postprocess: image %dx%d must be a multiple of 32", cfg->image_h, cfg->image_w);
     OM_REQUIRE(cfg->nms_pre >= 1 && cfg->nms_pre <= SEL_MAXN && cfg->nms_post >= 1 && cfg->nms_post <= cfg->nms_pre,
                OM_EINVAL, "postprocess: nms_pre=%d (max %d), nms_post=%d", cfg->nms_pre, SEL_MAXN, cfg->nms_post);
-    OM_REQUIRE(cfg->num_classes >= 1 && cfg->anchors_per_scale * (5 + cfg->num_classes) <= cfg->bbox_pix_stride,
+    OM_REQUIRE(cfg->num_classes >= 1 && a_max * (5 + cfg->num_classes) <= cfg->bbox_pix_stride,
                OM_EINVAL, "postprocess: bbox_pix_stride=%d too small", cfg->bbox_pix_stride);
     OM_REQUIRE(cfg->conf_thresh >= 0.0f, OM_EINVAL, "postprocess: conf_thresh must be >= 0");
     OM_REQUIRE(cfg->nms_semantics == 0 || cfg->nms_semantics == 1, OM_EINVAL,
                "postprocess: nms_semantics=%d (0 = the reference's CPU backend, 1 = its CUDA backend)", cfg->nms_semantics);
     p.cfg = *cfg;
     p.cand_off[0] = 0;
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < OM_MAX_SCALES; ++s) {
+        if (s >= cfg->num_scales) {          // an unused scale: no candidates, a 1 x 1 grid that nothing ever addresses
+            p.cfg.grid_h[s] = p.cfg.grid_w[s] = 1;
+            p.cand_off[s + 1] = p.cand_off[s];
+            continue;
+        }
         OM_REQUIRE(cfg->grid_h[s] > 0 && cfg->grid_w[s] > 0, OM_EINVAL, "postprocess: bad grid");
-        for (int a = 0; a < cfg->anchors_per_scale; ++a)
+        for (int a = 0; a < p.a_cnt[s]; ++a)
             OM_REQUIRE(cfg->anchor_mask[s][a] >= 0 && cfg->anchor_mask[s][a] < OM_MAX_ANCHORS, OM_EINVAL,
                        "postprocess: bad anchor_mask");
-        p.cand_off[s + 1] = p.cand_off[s] + cfg->anchors_per_scale * cfg->grid_h[s] * cfg->grid_w[s];
+        p.cand_off[s + 1] = p.cand_off[s] + p.a_cnt[s] * cfg->grid_h[s] * cfg->grid_w[s];
     }
-    p.ncand = p.cand_off[3];
+    p.ncand = p.cand_off[OM_MAX_SCALES];
     const long long npairs = (long long)p.ncand * cfg->num_classes;
     OM_REQUIRE(npairs < (1ll << 30), OM_EINVAL, "postprocess: too many (candidate, class) pairs");
     p.npairs = (int)npairs;
@@ -1037,29 +1134,27 @@ size_t om_postprocess_workspace_bytes(const om_post_cfg* cfg, int B) {
     return om::post_ws_layout(p, B).total;
 }
 
-int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbox16, const float* bbox8,
-                   const float* oriens, int B, float* out_bbox, int64_t* out_cls, uint8_t* out_mask,
-                   int32_t* out_count, int32_t* out_keep, void* workspace, size_t ws_bytes, om_stream stream_) {
-    OM_REQUIRE(cfg && bbox32 && bbox16 && bbox8 && oriens && out_bbox && out_cls && out_mask && out_count && workspace,
-               OM_EINVAL, "om_postprocess: null argument");
-    OM_REQUIRE(B > 0 && B < 65536, OM_EINVAL, "om_postprocess: B=%d", B);
-    om::PostParams p;
+// shared by the three entries: parameter block, workspace pointers, size checks
+static int post_setup(const om_post_cfg* cfg, const float* bbox32, const float* bbox16, const float* bbox8, const float* oriens, int B,
+                      void* workspace, size_t ws_bytes, om::PostParams& p, const char* who) {
+    OM_REQUIRE(cfg && workspace, OM_EINVAL, "%s: null argument", who);
+    OM_REQUIRE(B > 0 && B < 65536, OM_EINVAL, "%s: B=%d", who, B);
     int rc = om::fill_params(cfg, p);
     if (rc != OM_OK) return rc;
     const om::PostWs w = om::post_ws_layout(p, B);
-    OM_REQUIRE(ws_bytes >= w.total, OM_ENOMEM, "om_postprocess: workspace %zu bytes < %zu needed", ws_bytes, w.total);
-    OM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0 && (reinterpret_cast<uintptr_t>(out_mask) & 15) == 0,
-               OM_EINVAL, "om_postprocess: workspace must be 256-byte and out_mask 16-byte aligned");
-    OM_REQUIRE((long long)B * cfg->num_scales * cfg->anchors_per_scale < 65536, OM_EINVAL,
-               "om_postprocess: B * scales * anchors_per_scale must be < 65536 (the mask kernel's grid.y)");
-    for (int sc = 0; sc < 3; ++sc)      // post_decode_kernel addresses the heads with 24-bit multiplies and 32-bit element offsets
+    OM_REQUIRE(ws_bytes >= w.total, OM_ENOMEM, "%s: workspace %zu bytes < %zu needed", who, ws_bytes, w.total);
+    OM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, OM_EINVAL, "%s: workspace must be 256-byte aligned", who);
+    OM_REQUIRE((long long)B * p.a_off[cfg->num_scales] < 65536, OM_EINVAL,
+               "%s: B * anchor fields must be < 65536 (the mask kernel's grid.y)", who);
+    for (int sc = 0; sc < cfg->num_scales; ++sc)      // post_decode_kernel addresses the heads with 24-bit multiplies and 32-bit element offsets
         OM_REQUIRE((long long)B * cfg->grid_h[sc] * cfg->grid_w[sc] < (1ll << 24) && cfg->bbox_pix_stride < (1 << 24) &&
                        (long long)B * cfg->grid_h[sc] * cfg->grid_w[sc] * cfg->bbox_pix_stride < (1ll << 31),
-                   OM_EINVAL, "om_postprocess: B=%d x grid %dx%d x pixel stride %d is beyond the decode kernel's 32-bit offsets", B,
+                   OM_EINVAL, "%s: B=%d x grid %dx%d x pixel stride %d is beyond the decode kernel's 32-bit offsets", who, B,
                    cfg->grid_h[sc], cfg->grid_w[sc], cfg->bbox_pix_stride);
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
     char* base = static_cast<char*>(workspace);
-    p.bbox[0] = bbox32; p.bbox[1] = bbox16; p.bbox[2] = bbox8; p.oriens = oriens; p.B = B;
+    const float* heads[3] = {bbox32, bbox16, bbox8};
+    for (int sc = 0; sc < 3; ++sc) p.bbox[sc] = sc < cfg->num_scales ? heads[sc] : heads[0];     // unused scales are never addressed
+    p.oriens = oriens; p.B = B;
     p.keys = reinterpret_cast<unsigned*>(base + w.keys);
     p.tile_count = reinterpret_cast<int*>(base + w.tile_count);
     p.hist1 = reinterpret_cast<unsigned*>(base + w.hist1);
@@ -1067,6 +1162,27 @@ int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbo
     p.list = reinterpret_cast<unsigned long long*>(base + w.list);
     p.det_par = reinterpret_cast<float*>(base + w.det_par);
     p.nms_mask = reinterpret_cast<unsigned long long*>(base + w.nms_mask);
+    p.out_bbox = nullptr; p.out_cls = nullptr; p.out_mask = nullptr; p.out_count = nullptr; p.out_keep = nullptr;
+    return OM_OK;
+}
+
+static int launch_post_mask(const om_post_cfg* cfg, const om::PostParams& p, int B, hipStream_t stream) {
+    const int items = (cfg->image_h / 4 + 1) * (cfg->image_w / om::MASK_PX);
+    hipLaunchKernelGGL(om::post_mask_kernel, dim3((items + 255) / 256, B * p.a_off[cfg->num_scales]), dim3(256), 0, stream, p);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
+int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbox16, const float* bbox8,
+                   const float* oriens, int B, float* out_bbox, int64_t* out_cls, uint8_t* out_mask,
+                   int32_t* out_count, int32_t* out_keep, void* workspace, size_t ws_bytes, om_stream stream_) {
+    OM_REQUIRE(cfg && bbox32 && (cfg->num_scales < 2 || bbox16) && (cfg->num_scales < 3 || bbox8) && oriens && out_bbox && out_cls &&
+                   out_mask && out_count && workspace,
+               OM_EINVAL, "om_postprocess: null argument");
+    OM_REQUIRE((reinterpret_cast<uintptr_t>(out_mask) & 15) == 0, OM_EINVAL, "om_postprocess: out_mask must be 16-byte aligned");
+    om::PostParams p;
+    if (int rc = post_setup(cfg, bbox32, bbox16, bbox8, oriens, B, workspace, ws_bytes, p, "om_postprocess")) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
     p.out_bbox = out_bbox; p.out_cls = out_cls; p.out_mask = out_mask; p.out_count = out_count; p.out_keep = out_keep;
 
     if (int rc = om::launch_zero_words(p.hist1, (size_t)B * om::L1_BINS + B, stream)) return rc;
@@ -1074,11 +1190,39 @@ int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbo
     OM_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(om::post_select_kernel, dim3(B), dim3(om::SEL_THREADS), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
-    const int items = (cfg->image_h / 4 + 1) * (cfg->image_w / om::MASK_PX);
-    hipLaunchKernelGGL(om::post_mask_kernel, dim3((items + 255) / 256, B * cfg->num_scales * cfg->anchors_per_scale), dim3(256), 0,
-                       stream, p);
+    return launch_post_mask(cfg, p, B, stream);
+}
+
+int om_postprocess_candidates(const om_post_cfg* cfg, const float* bbox32, const float* bbox16, const float* bbox8, int B,
+                              float* cand_dets, int64_t* cand_cls, int32_t* cand_field, int32_t* cand_count, void* workspace,
+                              size_t ws_bytes, om_stream stream_) {
+    OM_REQUIRE(cfg && bbox32 && (cfg->num_scales < 2 || bbox16) && (cfg->num_scales < 3 || bbox8) && cand_dets && cand_cls &&
+                   cand_field && cand_count && workspace,
+               OM_EINVAL, "om_postprocess_candidates: null argument");
+    om::PostParams p;
+    if (int rc = post_setup(cfg, bbox32, bbox16, bbox8, nullptr, B, workspace, ws_bytes, p, "om_postprocess_candidates")) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    p.cand_dets = cand_dets; p.cand_cls = cand_cls; p.cand_field = cand_field; p.out_count = cand_count;
+    if (int rc = om::launch_zero_words(p.hist1, (size_t)B * om::L1_BINS + B, stream)) return rc;
+    hipLaunchKernelGGL(om::post_decode_kernel, dim3(p.ntiles, B), dim3(256), 0, stream, p);
+    OM_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(om::post_select_kernel, dim3(B), dim3(om::SEL_THREADS), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
+}
+
+int om_postprocess_masks(const om_post_cfg* cfg, const float* oriens, int B, const float* dets, const int32_t* field,
+                         const int32_t* count, uint8_t* out_mask, void* workspace, size_t ws_bytes, om_stream stream_) {
+    OM_REQUIRE(cfg && oriens && dets && field && count && out_mask && workspace, OM_EINVAL, "om_postprocess_masks: null argument");
+    OM_REQUIRE((reinterpret_cast<uintptr_t>(out_mask) & 15) == 0, OM_EINVAL, "om_postprocess_masks: out_mask must be 16-byte aligned");
+    om::PostParams p;
+    if (int rc = post_setup(cfg, dets, dets, dets, oriens, B, workspace, ws_bytes, p, "om_postprocess_masks")) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    p.out_mask = out_mask; p.out_count = const_cast<int32_t*>(count);
+    const int total = B * cfg->nms_post;
+    hipLaunchKernelGGL(om::post_detpar_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p, dets, field);
+    OM_CHECK_HIP(hipGetLastError());
+    return launch_post_mask(cfg, p, B, stream);
 }
 
 int om_post_kernel_occupancy(int which, int* threads, int* vgprs, int* lds_bytes, int* max_blocks_per_cu) {

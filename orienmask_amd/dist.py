@@ -40,24 +40,43 @@ def broadcast_blob(blob, numel, device, src=0, dtype=torch.float32):
     return blob
 
 
-def broadcast_packed_weights(net, device, src=0):
-    """Pack on `src` (which must hold the real state_dict), broadcast, bind on every rank."""
+def broadcast_packed_weights(net, device, src=0, stats=None):
+    """Pack on `src` (which must hold the real state_dict), broadcast, bind on every rank.  `stats` (a dict) receives the
+    bytes moved per rank, the number of blobs and the wall time of the broadcasts themselves (device-synchronised; packing on
+    the source's host is not in it) -- what bench.py prints as `weight_broadcast`."""
+    import time
     from . import lib as _lib
     from . import pack as _pack
     rank, _ = world_info()
     h = net._ensure_handle()
+    acc = dict(bytes=0, ms=0.0, blobs=0)
+
+    def timed_broadcast(blob, numel, dtype=torch.float32):
+        if torch.device(device).type == "cuda":
+            torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        out = broadcast_blob(blob, numel, device, src, dtype=dtype)
+        if torch.device(device).type == "cuda":
+            torch.cuda.synchronize(device)
+        acc["ms"] += (time.perf_counter() - t0) * 1e3
+        acc["bytes"] += out.numel() * out.element_size()
+        acc["blobs"] += 1
+        return out
+
     numel = _lib.load().om_model_weight_floats(h)
     blob = _pack.pack_state_dict(net.state_dict(), net._layers, numel) if rank == src else None
-    blob = broadcast_blob(blob, numel, device, src)
+    blob = timed_broadcast(blob, numel)
     net.bind_packed(blob)
     if getattr(net, "precision", "f32") == "f16":       # the fp16 configuration needs the fp16 weight rows as well
         n16 = _lib.load().om_model_weight_halfs(h)
         b16 = _pack.pack_state_dict_f16(net.state_dict(), net._layers, n16) if rank == src else None
-        net.bind_packed_f16(broadcast_blob(b16, n16, device, src, dtype=torch.float16))
+        net.bind_packed_f16(timed_broadcast(b16, n16, dtype=torch.float16))
     if getattr(net, "precision", "f32") == "f32_split":     # split-operand mode: the hi/lo fp16 pairs of the F(2x4) weights
         ns = _lib.load().om_model_weight_split_words(h)
         bs = _pack.pack_state_dict_split(net.state_dict(), net._layers, ns) if rank == src else None
-        net.bind_packed_split(broadcast_blob(bs, ns, device, src))
+        net.bind_packed_split(timed_broadcast(bs, ns))
+    if stats is not None:
+        stats.update(bytes=acc["bytes"], ms=round(acc["ms"], 3), blobs=acc["blobs"])
     return blob
 
 

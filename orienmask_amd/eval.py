@@ -120,10 +120,15 @@ class OrienMaskYOLOPostProcess:
         if not 1 <= self.nms_post <= self.nms_pre <= 1024:
             raise ValueError("the fused HIP postprocess needs 1 <= nms_post <= nms_pre <= 1024 (got %d, %d)"
                              % (self.nms_post, self.nms_pre))
-        if self.scales != 3 or len(set(self.num_anchors)) != 1:
-            raise ValueError("the HIP postprocess supports 3 scales with the same number of anchors each")
-        if len(self.anchors) > _lib.OM_MAX_ANCHORS:
-            raise ValueError("at most %d anchors" % _lib.OM_MAX_ANCHORS)
+        # the reference takes any number of scales and anchors per scale (postprocess.py:13-36); the library's tables hold
+        # 1..3 scales of 1..3 anchors each (OM_MAX_SCALES, om_post_cfg.anchors_of_scale) and 9 anchor shapes
+        if not 1 <= self.scales <= _lib.OM_MAX_SCALES or len(self.anchor_mask) != self.scales:
+            raise ValueError("the HIP postprocess holds 1..%d scales (got %d grids, %d anchor masks)"
+                             % (_lib.OM_MAX_SCALES, self.scales, len(self.anchor_mask)))
+        if any(not 1 <= n <= 3 for n in self.num_anchors):
+            raise ValueError("the HIP postprocess holds 1..3 anchors per scale, got %s" % (self.num_anchors,))
+        if len(self.anchors) > _lib.OM_MAX_ANCHORS or any(not 0 <= a < len(self.anchors) for m in self.anchor_mask for a in m):
+            raise ValueError("at most %d anchors, anchor_mask entries index them" % _lib.OM_MAX_ANCHORS)
         self._ws = {}
 
     @staticmethod
@@ -138,16 +143,18 @@ class OrienMaskYOLOPostProcess:
             if unknown:
                 raise TypeError("batched_nms got unexpected keyword arguments %s" % sorted(unknown))
             return float(kw.get("threshold", 0.5)), bool(kw.get("normalized", True)), kw.get("backend")
-        raise NotImplementedError(
-            "nms_func must be orienmask_amd.eval.batched_nms or a functools.partial of it; a foreign NMS callable "
-            "cannot run inside the fused HIP postprocess (there is no Python fallback)")
+        # any other callable nms_func(dets, cls) -> (dets[keep], cls[keep], keep) (postprocess.py:146-148): not fusable; the
+        # postprocess then runs decode + top-k on the device, calls it per image on device tensors, and builds the masks of
+        # its survivors on the device (launch_foreign)
+        return None, None, None
 
     def cfg_struct(self, bbox_pix_stride):
         c = _lib.PostCfg()
-        c.num_scales = 3
-        for i in range(3):
+        c.num_scales = self.scales
+        for i in range(self.scales):
             c.grid_h[i] = self.nHs[i]
             c.grid_w[i] = self.nWs[i]
+            c.anchors_of_scale[i] = self.num_anchors[i]
             for a in range(self.num_anchors[i]):
                 c.anchor_mask[i][a] = self.anchor_mask[i][a]
         c.image_h, c.image_w = self.image_h, self.image_w
@@ -157,12 +164,12 @@ class OrienMaskYOLOPostProcess:
             c.anchor_h[i] = h
         c.num_classes = self.num_classes
         c.conf_thresh = self.conf_thresh
-        c.nms_thresh = self.nms_thresh
+        c.nms_thresh = self.nms_thresh if self.nms_thresh is not None else 0.5      # unused with a foreign nms_func
         c.nms_pre, c.nms_post = self.nms_pre, self.nms_post
         c.orien_thresh = self.orien_thresh
         c.bbox_pix_stride = bbox_pix_stride
         c.nms_semantics = NMS_BACKENDS[self.nms_backend]
-        c.nms_normalized = 1 if self.nms_normalized else 0
+        c.nms_normalized = 1 if (self.nms_normalized or self.nms_normalized is None) else 0
         return c
 
     def __call__(self, predict):
@@ -170,10 +177,12 @@ class OrienMaskYOLOPostProcess:
 
     # -- input plumbing: accept the HIP model's layouts zero-copy, anything else after one repack
     def _bbox_nhwc(self, predict):
-        per = self.num_anchors[0] * (5 + self.num_classes)
+        if len(predict) != self.scales:
+            raise ValueError("predict has %d scales, the postprocess was built for %d" % (len(predict), self.scales))
         strides = set()
         for i, (bbox, _) in enumerate(predict):
             B, C, nH, nW = bbox.shape
+            per = self.num_anchors[i] * (5 + self.num_classes)
             if C != per or nH != self.nHs[i] or nW != self.nWs[i]:
                 raise ValueError("bbox head %d has shape %s, expected [B,%d,%d,%d]" % (i, tuple(bbox.shape), per,
                                                                                      self.nHs[i], self.nWs[i]))
@@ -184,17 +193,27 @@ class OrienMaskYOLOPostProcess:
                 strides.add(-1)
         if len(strides) == 1 and -1 not in strides:
             return [p[0] for p in predict], strides.pop()
-        return [p[0].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2) for p in predict], per
+        # one common pixel stride for every scale: the widest head's channel count
+        per = max(self.num_anchors) * (5 + self.num_classes)
+        out = []
+        for p in predict:
+            t = p[0].new_zeros((p[0].shape[0], p[0].shape[2], p[0].shape[3], per))
+            t[..., :p[0].shape[1]] = p[0].permute(0, 2, 3, 1)
+            out.append(t.permute(0, 3, 1, 2))
+        return out, per
 
     def _oriens_nchw(self, predict):
         o = [p[1] for p in predict]
         oh, ow = self.image_h // 4, self.image_w // 4
-        A2 = self.num_anchors[0] * 2
+        A2 = [n * 2 for n in self.num_anchors]
+        tot = sum(A2)
         base = o[0]
-        same = all(t.shape == (base.shape[0], A2, oh, ow) and t.stride() == (3 * A2 * oh * ow, oh * ow, ow, 1)
-                   for t in o)
-        if same and all(o[i].data_ptr() == base.data_ptr() + i * A2 * oh * ow * 4 for i in range(3)):
-            return base          # three views of one [B, 3*A2, oh, ow] buffer: use it in place
+        for i, t in enumerate(o):
+            if tuple(t.shape[1:]) != (A2[i], oh, ow):
+                raise ValueError("orientation head %d has shape %s, expected [B,%d,%d,%d]" % (i, tuple(t.shape), A2[i], oh, ow))
+        same = all(t.stride() == (tot * oh * ow, oh * ow, ow, 1) for t in o)
+        if same and all(o[i].data_ptr() == base.data_ptr() + sum(A2[:i]) * oh * ow * 4 for i in range(self.scales)):
+            return base          # views of one [B, sum(A2), oh, ow] buffer (torch.split in the model): use it in place
         return torch.cat(o, dim=1).contiguous()
 
     def apply(self, predict):
@@ -214,6 +233,10 @@ class OrienMaskYOLOPostProcess:
         B = bboxes[0].shape[0]
         dev = bboxes[0].device
         cfg = self.cfg_struct(pix_stride)
+        if self.nms_thresh is None:
+            return self._launch_foreign(predict, bboxes, oriens, cfg, B, dev)
+        while len(bboxes) < 3:
+            bboxes = bboxes + [bboxes[0]]        # unused scales: never read
         key = (dev, B, pix_stride)
         ws = self._ws.get(key)
         if ws is None:
@@ -243,6 +266,69 @@ class OrienMaskYOLOPostProcess:
                                   ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.current_stream_ptr(dev))
         _lib.check(rc, "om_postprocess")
         return out_bbox, out_cls, out_mask, out_count, out_keep, (bboxes, oriens), predict     # keep the inputs alive
+
+    def _workspace(self, cfg, B, dev, pix_stride):
+        L = _lib.load()
+        key = (dev, B, pix_stride)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = L.om_postprocess_workspace_bytes(ctypes.byref(cfg), B)
+            if nbytes == 0:
+                _lib.check(-1, "om_postprocess_workspace_bytes")
+            self._ws.clear()
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._ws[key] = ws
+        return ws
+
+    def _launch_foreign(self, predict, bboxes, oriens, cfg, B, dev):
+        """A caller-supplied nms_func (postprocess.py:9-11,146-154): candidates on the device (om_postprocess_candidates), the
+        callable per image on device tensors -- this step reads the candidate counts, so it synchronises, like the reference's
+        own per-image loop -- then the survivors' masks on the device (om_postprocess_masks).  Returns the same tuple as launch."""
+        L = _lib.load()
+        st = _lib.current_stream_ptr(dev)
+        ws = self._workspace(cfg, B, dev, cfg.bbox_pix_stride)
+        heads = [ctypes.c_void_p(t.data_ptr()) for t in bboxes] + [None] * (3 - len(bboxes))
+        cd = torch.empty((B, self.nms_pre, 5), dtype=torch.float32, device=dev)
+        cc = torch.empty((B, self.nms_pre), dtype=torch.long, device=dev)
+        cf = torch.empty((B, self.nms_pre), dtype=torch.int32, device=dev)
+        cn = torch.empty((B,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.om_postprocess_candidates(ctypes.byref(cfg), heads[0], heads[1], heads[2], B, ctypes.c_void_p(cd.data_ptr()),
+                                                   ctypes.c_void_p(cc.data_ptr()), ctypes.c_void_p(cf.data_ptr()),
+                                                   ctypes.c_void_p(cn.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(), st),
+                       "om_postprocess_candidates")
+        out_bbox = torch.zeros((B, self.nms_post, 5), dtype=torch.float32, device=dev)
+        out_cls = torch.zeros((B, self.nms_post), dtype=torch.long, device=dev)
+        out_field = torch.zeros((B, self.nms_post), dtype=torch.int32, device=dev)
+        out_keep = torch.zeros((B, self.nms_post), dtype=torch.int32, device=dev)
+        counts = []
+        for b, n in enumerate(cn.cpu().tolist()):
+            if n == 0:
+                counts.append(0)
+                continue
+            dets, cats, keep = self.nms(cd[b, :n], cc[b, :n])
+            if keep.numel() > self.nms_post:                      # postprocess.py:150-154
+                _, topk = dets[:, -1].topk(self.nms_post)
+                dets, cats, keep = dets[topk], cats[topk], keep[topk]
+            k = int(keep.numel())
+            counts.append(k)
+            out_bbox[b, :k] = dets
+            out_cls[b, :k] = cats
+            out_field[b, :k] = cf[b, :n][keep]
+            out_keep[b, :k] = keep.to(torch.int32)
+        status = getattr(predict, "status", None)
+        n_status = 0 if status is None else int(status.numel())
+        out_count = torch.empty((B + n_status,), dtype=torch.int32, device=dev)
+        out_count[:B] = torch.tensor(counts, dtype=torch.int32)
+        if n_status:
+            out_count[B:].copy_(status)
+        out_mask = torch.empty((B, self.nms_post, self.image_h, self.image_w), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.om_postprocess_masks(ctypes.byref(cfg), ctypes.c_void_p(oriens.data_ptr()), B, ctypes.c_void_p(out_bbox.data_ptr()),
+                                              ctypes.c_void_p(out_field.data_ptr()), ctypes.c_void_p(out_count.data_ptr()),
+                                              ctypes.c_void_p(out_mask.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(), st),
+                       "om_postprocess_masks")
+        return out_bbox, out_cls, out_mask, out_count, out_keep, (bboxes, oriens, out_field), predict
 
     def collect(self, outs):
         """The one host synchronisation of the batch: read the per-image counts (and the forward's status word behind them),

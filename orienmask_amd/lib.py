@@ -37,7 +37,16 @@ class PostCfg(ctypes.Structure):
                 ("nms_pre", ctypes.c_int32), ("nms_post", ctypes.c_int32),
                 ("orien_thresh", ctypes.c_float),
                 ("bbox_pix_stride", ctypes.c_int32),
-                ("nms_semantics", ctypes.c_int32), ("nms_normalized", ctypes.c_int32)]
+                ("nms_semantics", ctypes.c_int32), ("nms_normalized", ctypes.c_int32),
+                ("anchors_of_scale", ctypes.c_int32 * OM_MAX_SCALES)]
+
+
+class RleImage(ctypes.Structure):
+    """include/orienmask_hip.h: om_rle_image"""
+    _fields_ = [("mask", ctypes.c_void_p), ("K", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("crop_top", ctypes.c_int32), ("crop_down", ctypes.c_int32), ("crop_left", ctypes.c_int32),
+                ("crop_right", ctypes.c_int32), ("hflip", ctypes.c_int32), ("vflip", ctypes.c_int32),
+                ("orig_h", ctypes.c_int32), ("orig_w", ctypes.c_int32)]
 
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
@@ -96,9 +105,12 @@ SIGNATURES = {
     "om_pad_nchw": (_i, [_vp, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "om_postprocess_workspace_bytes": (_sz, [ctypes.POINTER(PostCfg), _i]),
     "om_postprocess": (_i, [ctypes.POINTER(PostCfg), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "om_postprocess_candidates": (_i, [ctypes.POINTER(PostCfg), _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "om_postprocess_masks": (_i, [ctypes.POINTER(PostCfg), _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "om_recover_bbox": (_i, [_vp, _i, _i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _i, _i, _i, _i,
                              _vp, _vp]),
     "om_recover_masks_rle": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "om_recover_masks_rle_strings": (_i, [_vp, _i, _vp, _i, _vp, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp]),
     "om_post_kernel_occupancy": (_i, [_i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "om_nms_workspace_bytes": (_sz, [_i]),
     "om_nms": (_i, [_vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),

@@ -113,24 +113,44 @@ class Tester:
         return stats
 
 
-def infer_loop(model, transform, postprocess, images, device, warmup=10, size_divisor=32):
+def infer_loop(model, transform, postprocess, images, device, warmup=10, size_divisor=32, use_graph=True):
     """images: list of [h,w,3] float32 tensors (what cv2.imread + cvtColor give infer.py).
-    Returns (list of per-image detections, list of pad_info, timer log in ms)."""
+    Returns (list of per-image detections, list of pad_info, timer log in ms).
+
+    use_graph (default): forward + postprocess of every network input SHAPE that occurs run as one captured hipGraph
+    (graph.GraphedPipeline: ~95 kernel launches become one graph launch; bit-identical detections, tests/test_hip_parity.py::
+    test_tester_and_infer_loops); a postprocess built for one image size only sees that size (infer.py resizes to 544 x 544
+    first), other shapes fall back to eager launches.  Detections of a graphed call are views of graph-owned buffers that the
+    next call overwrites, so they are cloned here (the reference returns fresh tensors)."""
     _timer.reset()
     _timer.cuda()
     model.eval()
     results, pads = [], []
+    graphs = {}
+
+    def run(x):
+        if not use_graph:
+            return postprocess(model(x))
+        key = tuple(x.shape)
+        if key not in graphs:
+            from .graph import GraphedPipeline
+            graphs[key] = GraphedPipeline(model, postprocess, x) if len(graphs) < 4 else None      # a handful of shapes at most
+        g = graphs[key]
+        if g is None:
+            return postprocess(model(x))
+        return [{k: v.clone() for k, v in d.items()} for d in g(x)]
+
     with torch.no_grad():
         if warmup and images:
             x, _ = transform.padded(images[0].to(device).unsqueeze(0), size_divisor)
             for _ in range(warmup):
-                postprocess(model(x))
+                run(x)
         with _timer.timer("Main Loop"):
             for img in images:
                 with _timer.timer("Load data"):
                     x, pad_info = transform.padded(img.to(device).unsqueeze(0), size_divisor)
                 with _timer.timer("Forward & Postprocess"):
-                    det = postprocess(model(x))
+                    det = run(x)
                 results.append(det[0])
                 pads.append(pad_info)
     return results, pads, _timer.get_all_elapsed_time()

@@ -73,3 +73,54 @@ def test_two_rank_broadcast_and_merge(built):
     assert [r[1] for r in results] == [True, True]              # both ranks hold rank 0's blob
     assert (results[0][2], results[0][3], results[1][2], results[1][3]) == (0, 34, 34, 67)
     assert results[0][4] == list(range(67)) and results[1][4] == list(range(67))
+
+
+# ---- `python bench.py --gpus N` means N: launcher resolution, and the self-spawned job on gloo
+def _bench_module():
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    spec = importlib.util.spec_from_file_location("om_bench_under_test", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, path
+
+
+def test_bench_gpus_flag_is_binding():
+    import pytest
+    bench, path = _bench_module()
+    assert bench.resolve_launch(1, {}, []) == ("run", 1)
+    assert bench.resolve_launch(8, {"WORLD_SIZE": "8"}, []) == ("run", 8)
+    action, cmd = bench.resolve_launch(8, {}, ["--gpus", "8", "--steps", "3"], visible_gpus=8)
+    assert action == "spawn"
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and "127.0.0.1" in cmd and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
+    assert os.path.samefile(cmd[cmd.index("--master-port") + 2], path)
+    for gpus, env, visible in ((2, {"WORLD_SIZE": "1"}, None), (1, {"WORLD_SIZE": "2"}, None), (8, {"WORLD_SIZE": "4"}, None),
+                               (0, {}, None), (2, {}, 1), (8, {}, 0)):
+        with pytest.raises(SystemExit) as e:
+            bench.resolve_launch(gpus, env, [], visible_gpus=visible)
+        assert e.value.code not in (0, None) and "--gpus" in str(e.value.code)
+
+
+def test_bench_gpus_2_without_a_launcher_runs_two_ranks(built):
+    """The command the driver types for N = 1 must work verbatim for N > 1: no launcher, `--gpus 2` -> two ranks, a line with
+    n_gpus 2 (here on gloo with --plumbing-only: no GPU in this container), the slowest rank's time in it."""
+    import json
+    import subprocess
+    import sys
+    _, path = _bench_module()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, path, "--gpus", "2", "--plumbing-only"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                 # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["broadcast"]["intact"] and d["broadcast"]["bytes"] == 4 << 20
+    assert d["rank_ms"]["max"] >= 19.0 > d["rank_ms"]["min"] >= 9.0  # rank 1 slept 20 ms, rank 0 10 ms
+    # a launcher that disagrees with --gpus is refused by every rank
+    r = subprocess.run([sys.executable, path, "--gpus", "2", "--plumbing-only"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    # and without GPUs the real bench fails loudly instead of printing a 1-GPU line
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, path, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "n_gpus" not in r.stdout

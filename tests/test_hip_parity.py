@@ -99,8 +99,10 @@ def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol
       * detections are matched one to one irrespective of position: same class, box within 1e-4, and mask IoU >= 1 - 1e-4
         (north_star) -- or, since ONE boundary pixel is already more than 1e-4 of a mask smaller than 10^4 pixels, every
         differing pixel must be BORDERLINE: its decision margin (_borderline_flips, evaluated in the oracle's arithmetic on the
-        heads under test) at most 1e-4 of the orientation field's scale -- the same 1e-4 the head tensors are held to -- and
-        at most 0.5 % of the mask's pixels + 2 may differ.  Without margin_ctx only images under 200 pixels fall back to
+        heads under test) at most 1e-5 of the orientation field's scale -- forty times the largest margin ever observed,
+        2.3e-7 (profiles/r03_composed_flips.txt), and a tenth of what the head tensors are held to -- and at most 0.1 % of the
+        mask's pixels + 2 may differ (observed: at most 3 pixels of a 13 500-pixel mask; round 3 allowed 1e-4 and 0.5 % + 2,
+        three orders wider than anything seen).  Without margin_ctx only images under 200 pixels fall back to
         "IoU >= 0.999 or at most 2 pixels".  The observed flips are printed per image (pytest -s) and appended to
         gpurun_out/composed_flips.txt when that directory exists;
       * position by position the scores agree within score_tol: detections may only trade places with near-ties;
@@ -134,7 +136,7 @@ def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol
             ok = iou >= 1 - 1e-4
             if not ok and margin_ctx is not None:
                 nflip, margin = _borderline_flips(got_mask[j], want_mask[i], margin_ctx, ctx_of[j])
-                ok = margin <= 1e-4 and nflip <= 2 + 0.005 * np.count_nonzero(want_mask[i])
+                ok = margin <= 1e-5 and nflip <= 2 + 0.001 * np.count_nonzero(want_mask[i])
             elif not ok and small:
                 ok = iou >= 0.999 or nflip <= 2
             if ok:
@@ -1304,6 +1306,10 @@ def test_tester_and_infer_loops(dev):
     with torch.no_grad():
         again = post(net(x))[0]
     assert torch.equal(again["bbox"], dets[1]["bbox"]) and torch.equal(again["mask"], dets[1]["mask"])
+    # the loop above replayed ONE captured hipGraph (the default for a fixed shape); eager launches give the same detections
+    dets_e, _, _ = infer_loop(net, tf, post, imgs, dev, warmup=0, use_graph=False)
+    for a, b in zip(dets, dets_e):
+        assert torch.equal(a["bbox"], b["bbox"]) and torch.equal(a["cls"], b["cls"]) and torch.equal(a["mask"], b["mask"])
 
 
 def test_build_tester_from_checkpoint_file(dev, tmp_path):
@@ -1925,3 +1931,188 @@ def test_rccl_broadcast_of_every_blob_on_one_gpu(dev):
                 assert torch.equal(ab, bb) and torch.equal(ao, bo)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_forward_f16_after_set_precision_split_c_api(dev):
+    """a C-API caller may leave the model in precision mode 1 (split operands) and then call
+    om_forward_f16.  The fp16 forward must not take mode 1's fused conv1 + conv2.0 kernel (fp32 stores into a buffer sized for
+    2-byte elements, split weights that need not be loaded): same heads, bit for bit, as with mode 0."""
+    from orienmask_amd import lib as omlib
+    sd = synth.synth_state_dict(5, obj_bias=-16.0, head_gain=4.0)
+    x = synth.synth_image_batch(23, 2, 96, 128).to(dev)
+    net = _hip_model(sd, dev, "f16")
+    with torch.no_grad():
+        want = [(a.clone(), b.clone()) for a, b in net(x)]           # the wrapper sets mode 0 before an fp16 forward
+    L = omlib.load()
+    h = net._handle
+    B, _, H, W = x.shape
+    heads = [torch.empty((B, H // s, W // s, 256), dtype=torch.float32, device=dev) for s in (32, 16, 8)]
+    oriens = torch.empty((B, 18, H // 4, W // 4), dtype=torch.float32, device=dev)
+    omlib.check(L.om_model_set_precision(h, 1), "om_model_set_precision")     # no split weights were ever loaded
+    nbytes = (L.om_forward_f16_workspace_bytes(h, B, H, W) + 255) // 256 * 256
+    ws = torch.zeros(nbytes + 4096, dtype=torch.uint8, device=dev)
+    ws[nbytes:] = 0x5A                                                          # guard behind the workspace
+    omlib.check(L.om_forward_f16(h, _p(x), B, H, W, _p(heads[0]), _p(heads[1]), _p(heads[2]), _p(oriens), _p(ws), nbytes,
+                                 omlib.current_stream_ptr(dev)), "om_forward_f16")
+    torch.cuda.synchronize()
+    omlib.check(L.om_model_set_precision(h, 0), "om_model_set_precision")
+    assert bool((ws[nbytes:] == 0x5A).all()), "the forward wrote behind its workspace"
+    got_o = torch.split(oriens, 6, dim=1)
+    for i, (wb, wo) in enumerate(want):
+        assert torch.equal(heads[i][..., :255].permute(0, 3, 1, 2), wb) and torch.equal(got_o[i], wo)
+
+
+def test_coco_strings_packed_on_the_device(dev):
+    """pycocotools' rleToString runs as the RLE kernel's last phase (om_recover_masks_rle_strings), every
+    mask of a batch appends to one byte buffer.  Byte-identical to oracle/rle_ref.c on the reference-generated resized masks of
+    tests/golden/coco_format.npz -- all five cases as ONE batch -- and again with first-guess buffers so small that every mask
+    takes an overflow path (too many runs for the run buffer; strings beyond the byte buffer)."""
+    from orienmask_amd.coco_format import COCOFormatter
+    from test_oracle_golden import _coco_cases
+    infos, dets, want = [], [], []
+    for i, (name, info, masks, bbox, xywh, seg) in enumerate(_coco_cases()):
+        K = masks.shape[0]
+        b5 = torch.cat([torch.from_numpy(bbox)[:, :4], torch.linspace(0.9, 0.1, K).reshape(K, 1)], dim=1).float()
+        infos.append(dict(info, id=100 + i))
+        dets.append(dict(bbox=b5.to(dev), cls=torch.arange(K, dtype=torch.int64, device=dev) % 80, mask=torch.from_numpy(masks).to(dev)))
+        want += [(100 + i, [info["height"], info["width"]], R.rle_to_string(R.rle_counts(seg[k])), xywh[k].tolist()) for k in range(K)]
+    # an image without detections in the middle of the batch contributes nothing
+    infos.insert(2, dict(id=7, height=50, width=60))
+    dets.insert(2, dict(bbox=torch.zeros((0, 5), device=dev), cls=torch.zeros((0,), dtype=torch.int64, device=dev),
+                        mask=torch.zeros((0, 96, 128), dtype=torch.bool, device=dev)))
+    for max_runs, per_mask in ((8192, 4096), (4, 4096), (8192, 3)):
+        fmt = COCOFormatter(list(range(1, 81)), with_mask=True)
+        fmt.MAX_RUNS, fmt.BYTES_PER_MASK = max_runs, per_mask
+        res = fmt.to_coco_format(infos, dets)
+        assert len(res["segm"]) == len(res["bbox"]) == len(want)
+        for s, b, (iid, size, counts, box) in zip(res["segm"], res["bbox"], want):
+            assert s["image_id"] == b["image_id"] == iid and s["segmentation"]["size"] == size and b["bbox"] == box
+            assert s["segmentation"]["counts"] == counts, (max_runs, per_mask, iid)
+    # an output too large for the LDS bitmap (1400 x 1000 -> 44 words x 1000 columns) takes the old kernel + the string kernel
+    big = dict(id=1, height=1400, width=1000)
+    m = torch.zeros((2, 96, 128), dtype=torch.bool)
+    m[0, 20:60, 30:90] = True
+    m[1, ::3, ::5] = True
+    res = COCOFormatter(list(range(1, 81))).to_coco_format([big], [dict(bbox=torch.rand(2, 5).to(dev), cls=torch.zeros(2, dtype=torch.int64, device=dev), mask=m.to(dev))])
+    seg = R.recover_shape_segm(m, big).numpy()
+    assert [s["segmentation"]["counts"] for s in res["segm"]] == [R.rle_to_string(R.rle_counts(seg[k])) for k in range(2)]
+
+
+# ------------------------------------------------------------------------------------------------
+# the two generalities of the reference's postprocess the fused path used to refuse (VERDICT round 3, item 8)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("regime,seed", [("mixed", 201), ("sparse_many", 202), ("clustered", 203), ("empty", 204)])
+def test_postprocess_foreign_nms_callable(dev, regime, seed):
+    """nms_func may be ANY callable (dets[n,5], cls[n]) -> (dets[keep], cls[keep], keep), as in the reference
+    (/root/reference/eval/orienmask_yolo_postprocess.py:9-11,146-154).  (a) a plain function that happens to do batched_nms: the
+    three-stage path (om_postprocess_candidates -> callable -> om_postprocess_masks) equals the fused kernel bit for bit;
+    (b) class-agnostic NMS at another threshold, keep in another order: equals the oracle's pieces composed the same way."""
+    from orienmask_amd import eval as om_eval
+    size = (160, 192)
+    pc = post_cfg(size)
+    heads = synth.synth_heads(seed, 3, pc["grid_size"], regime=regime)
+    dheads = tuple((b.to(dev), o.to(dev)) for b, o in heads)
+    fused = _hip_post(size, dev)
+    want = fused(dheads)
+    want_keep = [k.clone() for k in fused.last_keep]
+    calls = []
+
+    def plain(dets, cls):
+        calls.append(int(dets.shape[0]))
+        assert dets.is_cuda and cls.dtype == torch.long
+        return om_eval.batched_nms(dets, cls, threshold=0.5)
+
+    post = _hip_post(size, dev, nms_func=plain)
+    got = post(dheads)
+    assert post.nms_thresh is None and (len(calls) > 0 or regime == "empty")
+    for b, (g, w) in enumerate(zip(got, want)):
+        assert torch.equal(g["bbox"], w["bbox"]) and torch.equal(g["cls"], w["cls"]) and torch.equal(g["mask"], w["mask"]), (regime, b)
+        assert torch.equal(post.last_keep[b], want_keep[b])
+    # (b) class-agnostic, reversed keep order: against the oracle's candidates + its nms + its mask rule
+    def agnostic(dets, cls):
+        keep = om_eval._nms_keep(dets, 0.3, "cpu").flip(0)
+        return dets[keep], cls[keep], keep
+
+    got = _hip_post(size, dev, nms_func=agnostic)(dheads)
+    oracle = R.PostProcessOracle(pc["grid_size"], pc["image_size"], pc["anchors"], pc["anchor_mask"], 80, conf_thresh=pc["conf_thresh"])
+    cpu_heads = [(b.float(), o.float()) for b, o in heads]
+    for b in range(3):
+        coord, score, cls, aidx, sel = oracle.candidates(cpu_heads, b)
+        dets = torch.cat([coord, score.unsqueeze(-1)], 1)
+        keep = R.nms_cpu(dets, 0.3).flip(0)
+        if keep.numel() > 100:
+            keep = keep[dets[keep][:, -1].topk(100)[1]]
+        field = oracle.orien_field(cpu_heads, b)
+        a = aidx[keep]
+        gsx, gsy = oracle.grid_sizes[a, 0], oracle.grid_sizes[a, 1]
+        d = dets[keep]
+        masks = ((torch.abs(field[a, 0] - (gsx * d[:, 0]).view(-1, 1, 1)) < 0.3 * d[:, 2].view(-1, 1, 1) * gsx.view(-1, 1, 1)) &
+                 (torch.abs(field[a, 1] - (gsy * d[:, 1]).view(-1, 1, 1)) < 0.3 * d[:, 3].view(-1, 1, 1) * gsy.view(-1, 1, 1)))
+        _check_detections(got[b], d.numpy(), cls[keep].numpy(), masks.numpy(), (regime, "agnostic", b), exact_decode=True)
+
+
+@pytest.mark.parametrize("masks,slices", [([[6, 7, 8], [3, 4, 5]], (3, 3)), ([[6, 7, 8], [3, 4, 5], [0, 1]], (3, 3, 2)),
+                                          ([[4, 8]], (2,)), ([[6], [3, 5], [0, 1, 2]], (1, 2, 3))])
+@pytest.mark.parametrize("regime", ["mixed", "sparse_many"])
+def test_postprocess_other_scale_and_anchor_counts(dev, masks, slices, regime):
+    """The reference builds its tables for any number of scales and anchors per scale (postprocess.py:13-36).  1..3 scales of
+    1..3 anchors each against the oracle, which is generic like the reference: indices, classes and keep exact, boxes and masks
+    as for the standard configuration; heads both as plain NCHW tensors and in one shared orientation buffer."""
+    from orienmask_amd.eval import OrienMaskYOLOPostProcess
+    size = (160, 192)
+    pc = post_cfg(size)
+    full = synth.synth_heads(77, 2, pc["grid_size"], regime=regime)
+    heads = [(full[i][0][:, :slices[i] * 85].contiguous(), full[i][1][:, :slices[i] * 2].contiguous()) for i in range(len(masks))]
+    grids = pc["grid_size"][:len(masks)]
+    oracle = R.PostProcessOracle(grids, pc["image_size"], pc["anchors"], masks, 80, conf_thresh=pc["conf_thresh"])
+    want = oracle(heads)
+    post = OrienMaskYOLOPostProcess(grids, pc["image_size"], pc["anchors"], masks, 80, conf_thresh=pc["conf_thresh"], device=dev)
+    shared = torch.cat([o for _, o in heads], 1).contiguous().to(dev)
+    views = torch.split(shared, [s * 2 for s in slices], dim=1)
+    for layout in ("plain", "shared"):
+        pred = tuple((b.to(dev), o.to(dev) if layout == "plain" else views[i]) for i, (b, o) in enumerate(heads))
+        got = post(pred)
+        for b, (r, w) in enumerate(zip(got, want)):
+            assert torch.equal(r["cls"].cpu(), w["cls"]) and torch.equal(post.last_keep[b].cpu().long(), w["keep"]), (masks, layout, b)
+            _check_detections(r, w["bbox"].numpy(), w["cls"].numpy(), w["mask"].numpy(), (masks, layout, b), exact_decode=True)
+
+
+@pytest.mark.parametrize("fname", ["post_p544_ties_iou_b1.npz", "post_p544_ties_cut_b2.npz", "post_p544_ties_thresh_b2.npz",
+                                   "post_p544_dense_b1.npz"])
+def test_near_tie_fixtures_beside_fp16_matrix_neighbour(dev, fname):
+    """the comparisons that decide INDICES (confidence against conf_thresh, IoU against the NMS
+    threshold, the order of the sort, the radix select's key tests) are evaluated on bit patterns in VGPRs since round 4
+    (csrc/post.hip: f32_gt_bit / f32_ge_bit / lt_u32_bit ...), because a dense run of VALU compares into SGPR pairs returned stale
+    lane masks on this chip while a co-resident wave issued wide-K fp16 matrix instructions (tools/hazard_probe).  The
+    reference-generated near-tie fixtures -- scores 1-3 ulps apart across the nms_pre cut, confidences stepping through
+    conf_thresh two ulps at a time, IoUs stepping through 0.5 a fraction of an ulp at a time, and the dense fixture that takes
+    the radix-select path -- must come out identical to the reference's own results on every one of 12 repetitions while
+    another stream runs this library's fp16 convolutions (v_mfma_f32_32x32x16_f16 on every CU) without a pause."""
+    g = np.load(os.path.join(GOLDEN, fname))
+    size = tuple(int(v) for v in g["size"]); batch = int(g["batch"])
+    pc = post_cfg(size)
+    heads = synth.synth_heads(int(g["seed"]), batch, pc["grid_size"], regime=str(g["regime"]))
+    dheads = _to_model_layout(heads, dev)
+    post = _hip_post(size, dev)
+    busy = _hip_model(synth.synth_state_dict(3, obj_bias=-16.0, head_gain=4.0), dev).set_precision("f16")
+    y = synth.synth_image_batch(901, 2, 544, 544).to(dev)
+    s0, s1 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    with torch.no_grad():
+        busy(y)
+        alone = post(dheads)
+        alone_keep = [k.clone() for k in post.last_keep]
+        torch.cuda.synchronize()
+        for it in range(12):
+            with torch.cuda.stream(s1):
+                for _ in range(4):
+                    busy(y)
+            with torch.cuda.stream(s0):
+                outs = post.launch(dheads)
+            torch.cuda.synchronize()
+            res = post.collect(outs)
+            for b, r in enumerate(res):
+                _check_detections(r, g["bbox%d" % b], g["cls%d" % b], unpack_masks(g["mask%d" % b], g["maskshape%d" % b]),
+                                  (fname, "beside fp16", it, b), exact_decode=True)
+                assert torch.equal(r["bbox"], alone[b]["bbox"]) and torch.equal(r["cls"], alone[b]["cls"]) and \
+                    torch.equal(r["mask"], alone[b]["mask"]) and torch.equal(post.last_keep[b], alone_keep[b]), (fname, it, b)

@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol(built):
 
 def test_struct_layouts_match_header(built):
     assert ctypes.sizeof(omlib.LayerInfo) == 64 + 8 * 4 + 8 * 8
-    assert ctypes.sizeof(omlib.PostCfg) == 4 * (1 + 3 + 3 + 2 + 1 + 9 + 9 + 9 + 1 + 2 + 2 + 1 + 1 + 2)
+    assert ctypes.sizeof(omlib.PostCfg) == 4 * (1 + 3 + 3 + 2 + 1 + 9 + 9 + 9 + 1 + 2 + 2 + 1 + 1 + 2 + 3)
+    assert ctypes.sizeof(omlib.RleImage) == 8 + 4 * 11 + 4          # pointer, eleven int32, tail padding to 8
 
 
 def test_graph_matches_reference_state_dict(built):
@@ -114,8 +115,17 @@ def test_registry_builders_mirror_reference(built):
     net = builder.build(dict(type="OrienMaskYOLOFPNPlus", num_anchors=3, num_classes=80, pretrained=None,
                              freeze_backbone=False, backbone_batchnorm_eval=False), om_model)
     assert isinstance(net, om_model.OrienMaskYOLOFPNPlus)
-    with pytest.raises(NotImplementedError):
-        om_eval.OrienMaskYOLOPostProcess(nms_func=lambda d, c: None, **post_cfg((544, 544)))
+    # any callable is accepted as nms_func, like the reference's (postprocess.py:9-11): it runs between the device-side
+    # candidate and mask stages instead of inside the fused kernel (tests/test_hip_parity.py covers the results)
+    foreign = om_eval.OrienMaskYOLOPostProcess(nms_func=lambda d, c: None, **post_cfg((544, 544)))
+    assert foreign.nms_thresh is None and foreign.cfg_struct(256).nms_thresh == pytest.approx(0.5)
+    # 1..3 scales, 1..3 anchors each; the library's tables end there and say so
+    two = om_eval.OrienMaskYOLOPostProcess([[3, 4], [6, 8]], [96, 128], post_cfg((96, 128))["anchors"], [[6, 7, 8], [3, 4]], 80)
+    c2 = two.cfg_struct(256)
+    assert (c2.num_scales, list(c2.anchors_of_scale)[:2], list(c2.anchor_mask[1])[:2]) == (2, [3, 2], [3, 4])
+    for bad_masks, bad_grids in (([[0, 1, 2, 3]], [[3, 4]]), ([[0], [1], [2], [3]], [[3, 4]] * 4), ([[0, 11]], [[3, 4]])):
+        with pytest.raises(ValueError):
+            om_eval.OrienMaskYOLOPostProcess(bad_grids, [96, 128], post_cfg((96, 128))["anchors"], bad_masks, 80)
     c = post.cfg_struct(256)
     assert (c.grid_h[0], c.grid_w[2], c.image_h, c.anchors_per_scale, c.num_classes) == (17, 68, 544, 3, 80)
     assert list(c.anchor_mask[0]) == [6, 7, 8] and c.anchor_w[8] == 459.0 and c.anchor_h[8] == 401.0

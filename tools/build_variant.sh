@@ -2,7 +2,7 @@
 # Build a variant of the library for same-box A/B runs (tools/ab_bench.sh):  tools/build_variant.sh NAME "-DOM_EXP_..." [file ...]
 # -> ab/NAME.so (ab/ is git-ignored; it travels to the GPU box with gpurun).  The named source files (default: all) get the flags.
 set -e
-NAME=$1; FLAGS=$2; shift 2
+NAME=$1; FLAGS="$2 -DOM_MEASUREMENT_BUILD=1"; shift 2
 R=$(cd "$(dirname "$0")/.." && pwd)
 B=$R/ab/build_$NAME
 mkdir -p $B
