@@ -57,7 +57,7 @@ typedef unsigned u32x4v __attribute__((__vector_size__(4 * sizeof(unsigned))));
 #error "measurement switches (wrong numerics / trace stores) are only for ab/ variants: build them with tools/build_variant.sh, which defines OM_MEASUREMENT_BUILD and never writes orienmask_amd/lib/"
 #endif
 #ifndef W14_RING
-#define W14_RING 3             // weight-ring slots.  4: blocks of (R + 2) * Ct <= 144 entries (two V buffers of 110 592 B leave room for a
+#define W14_RING 4             // weight-ring slots.  4: blocks of (R + 2) * Ct <= 144 entries (two V buffers of 110 592 B leave room for a
 #endif                         // fourth 12 KiB slot), a group's first fragments are read BEFORE the barrier that starts it (no LDS round
                                // trip between the barrier and the group's first matrix instruction) and its weights still have two
                                // groups to land (requested three groups ahead)
