@@ -452,7 +452,6 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
     const int nms_pre = p.cfg.nms_pre, nms_post = p.cfg.nms_post;
     const unsigned* keys = p.keys + (size_t)b * p.ntiles * DEC_TILE;
     const int* tcount = p.tile_count + (size_t)b * p.ntiles;
-    const int nchunks = (p.ntiles + 1) / 2;       // chunk = 2 tiles = 4096 keys, 4 per thread
 
     // ---- how many pairs passed the threshold
     const int total = (int)min(p.list_count[b], 0x7FFFFFFFu);
@@ -507,83 +506,114 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
         int need = nms_pre - s_res[1];
         above = s_res[1];
         __syncthreads();
+        // Round 4: the three passes over the image's keys (5.8 MB on dense heads) were one uint4 per thread and iteration with a
+        // workgroup scan -- two barriers -- per 4096 keys in the last one: 1.5 ms per batch on all-pass heads (bench.py --heads
+        // allpass), bound by the latency of one load in flight per thread.  Now every wave owns a contiguous range of tiles, has
+        // four 1-KiB rows in flight, and the compaction needs no barrier at all: the level-3 pass also counts, per wave, the keys
+        // above the 24-bit prefix and a private 256-bin histogram of the keys on it, from which each wave's number of selected
+        // keys -- its offset in the index-ordered list -- follows once T is known.
         // level 2: bits 18..8 of keys whose top bits equal t1
         for (int i = tid; i < 2048; i += SEL_THREADS) hist[i] = 0;
         __syncthreads();
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const int t0 = ch * 2, t1i = min(ch * 2 + 1, p.ntiles - 1);
-            if (tcount[t0] + tcount[t1i] == 0) continue;
-            if (ch * 4096 + tid * 4 < p.ntiles * DEC_TILE && tcount[ch * 2 + (tid >> 9)] > 0) {      // a tile without a pass has no keys in memory
-                const uint4 k4 = *reinterpret_cast<const uint4*>(keys + (size_t)ch * 4096 + tid * 4);
-                const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};
+        const int lane = tid & 63, wave = tid >> 6;
+        const int tw0 = (int)((long long)p.ntiles * wave / (SEL_THREADS / 64)), tw1 = (int)((long long)p.ntiles * (wave + 1) / (SEL_THREADS / 64));
+        // rows of 256 keys (64 lanes x uint4); a tile has DEC_TILE / 256 = 8 of them; four rows per step
+        auto for_rows = [&](auto body) {
+            for (int t = tw0; t < tw1; ++t) {
+                if (tcount[t] == 0) continue;           // a tile without a pass has no keys in memory
+                const unsigned* kt = keys + (size_t)t * DEC_TILE + lane * 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if ((eq_u32_bit(kk[e], 0u) ^ 1u) & eq_u32_bit(kk[e] >> 19, t1)) atomicAdd(&hist[(kk[e] >> 8) & 0x7FFu], 1u);
+                for (int r0 = 0; r0 < DEC_TILE / 256; r0 += 4) {
+                    uint4 k4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) k4[q] = *reinterpret_cast<const uint4*>(kt + (r0 + q) * 256);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) body(k4[q], t * DEC_TILE + (r0 + q) * 256 + lane * 4);
+                }
             }
-        }
+        };
+        for_rows([&](const uint4& k4, int) {
+            const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if ((eq_u32_bit(kk[e], 0u) ^ 1u) & eq_u32_bit(kk[e] >> 19, t1)) atomicAdd(&hist[(kk[e] >> 8) & 0x7FFu], 1u);
+        });
         __syncthreads();
         find_bin_from_top(hist, 2048, need, s_wave, s_res);
         const unsigned t2 = s_res[0];
         above += s_res[1];
         need -= s_res[1];
         __syncthreads();
-        // level 3: low 8 bits
-        for (int i = tid; i < 256; i += SEL_THREADS) hist[i] = 0;
+        // level 3: low 8 bits of the keys on the prefix hi, per wave (s_mask is free until the NMS); keys above the prefix counted
+        unsigned* const whist = reinterpret_cast<unsigned*>(s_mask);          // [16 waves][256]
+        int* const wgt = reinterpret_cast<int*>(whist + (SEL_THREADS / 64) * 256);      // [16] keys above the prefix, per wave
+        for (int i = tid; i < (SEL_THREADS / 64) * 256 + SEL_THREADS / 64; i += SEL_THREADS) whist[i] = 0;
         __syncthreads();
         const unsigned hi = (t1 << 11) | t2;
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const int t0 = ch * 2, t1i = min(ch * 2 + 1, p.ntiles - 1);
-            if (tcount[t0] + tcount[t1i] == 0) continue;
-            if (ch * 4096 + tid * 4 < p.ntiles * DEC_TILE && tcount[ch * 2 + (tid >> 9)] > 0) {      // a tile without a pass has no keys in memory
-                const uint4 k4 = *reinterpret_cast<const uint4*>(keys + (size_t)ch * 4096 + tid * 4);
-                const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};
+        int my_above = 0;
+        for_rows([&](const uint4& k4, int) {
+            const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if ((eq_u32_bit(kk[e], 0u) ^ 1u) & eq_u32_bit(kk[e] >> 8, hi)) atomicAdd(&hist[kk[e] & 0xFFu], 1u);
+            for (int e = 0; e < 4; ++e) {
+                my_above += (int)lt_u32_bit(hi, kk[e] >> 8);
+                if (eq_u32_bit(kk[e] >> 8, hi)) atomicAdd(&whist[wave * 256 + (kk[e] & 0xFFu)], 1u);      // (hi != 0: keys of passing pairs only)
             }
+        });
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) my_above += __shfl_xor(my_above, d);
+        if (lane == 0) wgt[wave] = my_above;
+        __syncthreads();
+        for (int i = tid; i < 256; i += SEL_THREADS) {
+            unsigned v = 0;
+            for (int w = 0; w < SEL_THREADS / 64; ++w) v += whist[w * 256 + i];
+            hist[i] = v;
         }
         __syncthreads();
         find_bin_from_top(hist, 256, need, s_wave, s_res);
-        T = (hi << 8) | (unsigned)s_res[0];
+        const unsigned tlow = (unsigned)s_res[0];
+        T = (hi << 8) | tlow;
         above += s_res[1];
         r = nms_pre - above;
         __syncthreads();
-    }
-
-    // ---- index-ordered compaction (row-major (candidate, class) order, postprocess.py:102)
-    {
+        // ---- index-ordered compaction (row-major (candidate, class) order, postprocess.py:102): this wave's first positions
         int run_gt = 0, run_eq = 0;
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const int t0 = ch * 2, t1i = min(ch * 2 + 1, p.ntiles - 1);
-            if (tcount[t0] + tcount[t1i] == 0) continue;
-            unsigned kk[4] = {0, 0, 0, 0};
-            if (ch * 4096 + tid * 4 < p.ntiles * DEC_TILE && tcount[ch * 2 + (tid >> 9)] > 0) {
-                const uint4 k4 = *reinterpret_cast<const uint4*>(keys + (size_t)ch * 4096 + tid * 4);
-                kk[0] = k4.x; kk[1] = k4.y; kk[2] = k4.z; kk[3] = k4.w;
-            }
+        for (int w = 0; w < wave; ++w) {
+            int g = wgt[w];
+            for (unsigned bin = tlow + 1; bin < 256; ++bin) g += (int)whist[w * 256 + bin];
+            run_gt += g;
+            run_eq += (int)whist[w * 256 + tlow];
+        }
+        for_rows([&](const uint4& k4, int pair0) {
+            const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};
             int ngt = 0, neq = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 ngt += (int)lt_u32_bit(T, kk[e]);
-                neq += (int)((eq_u32_bit(T, 0u) ^ 1u) & eq_u32_bit(kk[e], T));
+                neq += (int)eq_u32_bit(kk[e], T);
             }
-            int tot;
-            const int ex = block_scan_excl(ngt | (neq << 16), s_wave, tot);
-            int pg = run_gt + (ex & 0xFFFF), pe = run_eq + (ex >> 16);
+            const int mine = ngt | (neq << 16);
+            if (__ballot(mine != 0) == 0ull) return;          // nearly every row of a dense image
+            int incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(incl, d);
+                if (lane >= d) incl += y;
+            }
+            const int tot = __shfl(incl, 63);
+            int pg = run_gt + ((incl - mine) & 0xFFFF), pe = run_eq + ((incl - mine) >> 16);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int pair = ch * 4096 + tid * 4 + e;
                 if (lt_u32_bit(T, kk[e])) {
-                    if (pg < SEL_MAXN) { s_key[pg] = kk[e]; s_pair[pg] = pair; }
+                    if (pg < SEL_MAXN) { s_key[pg] = kk[e]; s_pair[pg] = pair0 + e; }
                     ++pg;
-                } else if ((eq_u32_bit(T, 0u) ^ 1u) & eq_u32_bit(kk[e], T)) {
-                    if (pe < r) { s_key[above + pe] = kk[e]; s_pair[above + pe] = pair; }
+                } else if (eq_u32_bit(kk[e], T)) {
+                    if (pe < r) { s_key[above + pe] = kk[e]; s_pair[above + pe] = pair0 + e; }
                     ++pe;
                 }
             }
             run_gt += tot & 0xFFFF;
             run_eq += tot >> 16;
-        }
+        });
     }
     __syncthreads();
 
