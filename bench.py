@@ -244,6 +244,8 @@ def main():
     ap.add_argument("--no-f16-compare", action="store_true",
                     help="split mode: skip the extra timed region in the fp16-activation configuration (BASELINE configs[4])")
     ap.add_argument("--no-extras", action="store_true", help="skip the preprocess / COCO-format side measurements")
+    ap.add_argument("--latency-mode", action="store_true",
+                    help="f32_split: model.set_latency_mode(True) for the whole run (direct 3x3 convolutions below ~4 images per batch)")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the bs = 1 / bs = 8 latency figures (`small_batches`)")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
     ap.add_argument("--heads", choices=("dense", "sparse", "allpass"), default="dense",
@@ -333,6 +335,8 @@ def main():
     broadcast_packed_weights(net, dev, src=0, stats=bc_stats)      # one RCCL broadcast per blob, untimed
     if args.replicated_concat:
         net.set_upsample_on_read(False)
+    if args.latency_mode:
+        net.set_latency_mode(True)
     post = OrienMaskYOLOPostProcess(device=dev, **post_config(H, W))
     x_cpu = synth.synth_image_batch(1000 + rank, B, H, W)
     x = x_cpu.to(dev)
@@ -554,6 +558,13 @@ def main():
                 return (time.perf_counter() - t0_) / n
             with torch.no_grad():
                 eager_s = time_loop(lambda i: post(net(xsb[i & 1])), n_it)
+                lat_s = None
+                if split:           # the latency mode infer_loop switches on (model.set_latency_mode): direct 3x3 layers below ~4 images
+                    net.set_latency_mode(True)
+                    gpl = GraphedPipeline(net, post, xsb[0])
+                    lat_s = time_loop(lambda i: gpl(xsb[i & 1]), n_it)
+                    del gpl
+                    net.set_latency_mode(False)
                 gp = GraphedPipeline(net, post, xsb[0])
                 graph_s = time_loop(lambda i: gp(xsb[i & 1]), n_it)
                 del gp
@@ -569,10 +580,14 @@ def main():
                 del pipe4
             small["bs%d" % bsz] = dict(ms_per_step_one_at_a_time_graph=round(graph_s * 1e3, 3), images_per_s_graph=round(bsz / graph_s, 1),
                                        ms_per_step_one_at_a_time_eager=round(eager_s * 1e3, 3), images_per_s_eager=round(bsz / eager_s, 1),
-                                       images_per_s_four_in_flight=round(bsz / fl_s, 1))
+                                       images_per_s_four_in_flight=round(bsz / fl_s, 1),
+                                       ms_per_step_latency_mode_graph=round(lat_s * 1e3, 3) if lat_s else None,
+                                       images_per_s_latency_mode=round(bsz / lat_s, 1) if lat_s else None)
         small["note"] = ("batches of 1 and 8 images per GPU with this run's weights and precision: one at a time through the captured "
                          "hipGraph (orienmask_amd.graph.GraphedPipeline, what infer_loop runs for a fixed shape), one at a time eagerly, "
-                         "and with four batches in flight (InFlightPipeline)")
+                         "with four batches in flight (InFlightPipeline), and -- f32_split -- one at a time through the graph in the model's "
+                         "latency mode (model.set_latency_mode, what tester.infer_loop switches on: stride-1 3x3 layers as direct "
+                         "convolutions below ~4 images; a batch of 8 is above that switch)")
     timed_fw //= max(args.streams, 1)                              # one om_forward per sub-batch
     dom_main_ms = sum(ms for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw      # per step, all launches
     dom_timed_ms = dom_main_ms + sum(pre for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw

@@ -73,6 +73,9 @@ typedef struct om_layer_info {
                                    -1: the stem (always fp32 operands) */
     int64_t wsplit_scale_off;   /* offset in 4-byte words into the split blob of [cout_pad] floats scale * 2^-e[cout] (the
                                    power of two is exact, so the epilogue rounds as with the unscaled weights) */
+    int64_t wsplit_direct_off;  /* wino_planes == 24 only (else -1): the same layer's DIRECT 3x3 weights in the "otherwise" layout
+                                   of wsplit_off, with exponents of their own, for the latency mode (om_model_set_latency_cells) */
+    int64_t wsplit_direct_scale_off;   /* ... and their [cout_pad] floats scale * 2^-e[cout] */
 } om_layer_info;
 
 /* Constants of OrienMaskYOLOPostProcess.__init__ (eval/orienmask_yolo_postprocess.py:9-37). */
@@ -143,6 +146,13 @@ int om_model_load_weights(om_model* m, const void* packed_dev, size_t bytes, int
 size_t om_model_weight_split_words(const om_model* m);
 int om_model_load_weights_split(om_model* m, const void* packed_split_dev, size_t bytes);
 int om_model_set_precision(om_model* m, int mode);
+/* Latency mode of precision 1 (no counterpart in the reference, whose published figure is bs = 1 FPS: README.md:5,
+ * infer.py:143-172).  cells > 0: a forward whose batch has fewer than `cells` 1/32-scale cells (B * H/32 * W/32; one 544 x 544
+ * image has 289) runs its stride-1 3x3 layers as DIRECT convolutions with split operands in the implicit GEMM -- small tiles,
+ * one short round -- instead of the fused F(4,3) kernel, whose 128 x 64 tiles leave most of the chip idle at a few images.
+ * Same layer, other summation: heads agree with the fused form to ~1e-6 of scale, not bit for bit, so an image's outputs then
+ * depend on which side of the switch its batch is.  0 (default): off -- outputs independent of the batch size. */
+int om_model_set_latency_cells(om_model* m, long long cells);
 int om_model_get_precision(const om_model* m);
 /* Precision mode 1 only: 1 (default) = the routes and skips (the 1x1 layers whose output the reference up-samples and concatenates,
  * orienmask_yolo_fpnplus.py:78-86) store ONE copy at their own resolution and the 1x1 layer behind the concat reads them

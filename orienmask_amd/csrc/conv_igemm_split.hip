@@ -245,12 +245,15 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& 
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool FAST = false>
-__global__ __launch_bounds__(256, (split_blocks_per_cu<BM, BN>())) void conv_igemm_split_kernel(const IgemmSParams p) {
+// NBUF: ring stages.  3 (two k-steps in flight) where a launch has rounds of tiles to overlap; the LATENCY form (launches of
+// at most 128 tiles: a batch of one or a few images) has one tile per CU and nothing else to hide a stage's landing time
+// behind, so with 3 to 12 matrix instructions per k-step a k-step took ~700 cycles = that landing time / 2: eight stages for
+// the 64 x 64 tile (64 KiB), five for 128 x 64 -- two workgroups per CU, which such a launch does not fill anyway.
+template <int BM, int BN, int WM, int WN, bool FAST = false, int NBUF = 3>
+__global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())) void conv_igemm_split_kernel(const IgemmSParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NWN = BN / WN;
     constexpr int A_CH = BM / 64, B_CH = (BN + 63) / 64, NP = A_CH + B_CH;   // 64 rows x 64 B per workgroup-wide piece
-    constexpr int NBUF = 3;
     constexpr int STAGE = (BM + (BN < 64 ? 64 : BN)) * 4;   // f32x4 (16-byte) units per ring stage
     static_assert((BM / WM) * (BN / WN) == 4, "four waves per workgroup");
     static_assert(BM % 64 == 0, "A tile = whole 64-row pieces");
@@ -372,29 +375,26 @@ __global__ __launch_bounds__(256, (split_blocks_per_cu<BM, BN>())) void conv_ige
             for (int b = 0; b < TN; ++b) { bh[b] = __builtin_bit_cast(f16x8, nbh[b]); bl[b] = __builtin_bit_cast(f16x8, nbl[b]); }
         };
 
-        // prologue: steps 0, 1, 2 requested; step 0 waited for and converted
+        // prologue: steps 0 .. NBUF - 1 requested; step 0 waited for and converted
 #pragma unroll
-        for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 0, true);
-        advance();
+        for (int st = 0; st < NBUF; ++st) {
 #pragma unroll
-        for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 1, 1 < p.ksteps);
-        advance();
-#pragma unroll
-        for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 2, 2 < p.ksteps);
-        advance();
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NP) : "memory");
+            for (int piece = 0; piece < NP; ++piece) issue_piece(piece, st, st < p.ksteps);
+            advance();
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NBUF - 1) * NP) : "memory");
         __builtin_amdgcn_s_barrier();
         read_raw(0);
         convert();
         int buf = 0;
         for (int s = 0; s < p.ksteps; ++s) {
             const int buf1 = buf == NBUF - 1 ? 0 : buf + 1;
-            // step s+1 has landed (only step s+2's NP pieces may still fly); every wave's reads of `buf` are complete (they
-            // fed its convert) -> `buf` can take step s+3
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NP) : "memory");
+            // step s+1 has landed (only the NBUF - 2 steps behind it may still fly); every wave's reads of `buf` are complete
+            // (they fed its convert) -> `buf` can take step s + NBUF
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"((NBUF - 2) * NP) : "memory");
             __builtin_amdgcn_s_barrier();
             read_raw(buf1);
-            const bool live3 = s + 3 < p.ksteps;
+            const bool live3 = s + NBUF < p.ksteps;
 #pragma unroll
             for (int piece = 0; piece < NP; ++piece) issue_piece(piece, buf, live3);
 #pragma unroll
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool WIDE = false, bool GATHER = false>
+template <int BM, int BN, int WM, int WN, bool WIDE = false, bool GATHER = false, int NBUF = 3>
 static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hipStream_t stream) {
     const int m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = cout_pad / BN;
@@ -671,8 +671,8 @@ static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hi
         if (fast) hipLaunchKernelGGL((conv_igemm_split_wide_kernel<BM, BN, WM, WN, GATHER, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((conv_igemm_split_wide_kernel<BM, BN, WM, WN, GATHER, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     } else {
-        if (fast) hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, WN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+        if (fast) hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, WN, true, NBUF>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, WN, false, NBUF>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     }
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
@@ -690,6 +690,18 @@ void conv_tile_for_split(int M, int cout_pad, int* bm, int* bn) {
         const double cost = (double)((M + c.bm - 1) / c.bm) * (cout_pad / c.bn) * c.bm * c.bn / c.eff;
         if (cost < best) { best = cost; *bm = c.bm; *bn = c.bn; }
     }
+#ifndef OM_SPLIT_NO_LATENCY_TILES
+    // Few tiles (a batch of one or a few images: /root/reference/infer.py:143-172 runs bs = 1): a launch is then ONE round and
+    // its time is a tile's latency, which is k-steps x the time of a k-step -- 12 matrix instructions per SIMD for 128 x 128, 3 for
+    // 64 x 64.  While the chosen shape leaves more than half of the CUs without a tile, take the next smaller one.  (An output
+    // element's sum does not depend on the tile shape: same products, same order.)
+    const Cand small[] = {{128, 64, 0}, {64, 64, 0}};
+    for (const Cand& c : small) {
+        const long long tiles = (long long)((M + *bm - 1) / *bm) * (cout_pad / *bn);
+        if (tiles > 128 || cout_pad % c.bn || c.bm * c.bn >= *bm * *bn) continue;
+        *bm = c.bm; *bn = c.bn;
+    }
+#endif
 }
 
 // a.w: packed hi/lo weights (include/orienmask_hip.h: om_layer_info.wsplit_off); a.scale: scale * 2^-e
@@ -765,6 +777,10 @@ int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream) {
     if (bm == 256 && bn == 128) return launch_tile_split<256, 128, 128, 64>(p, a.cout_pad, 2, stream);
     if (bm == 128 && bn == 128 && a.cin % 32 == 0 && !a.force_bm && OM_SPLIT_WIDE) return launch_tile_split<128, 128, 64, 64, true>(p, a.cout_pad, 2, stream);
     if (bm == 128 && bn == 128) return launch_tile_split<128, 128, 64, 64>(p, a.cout_pad, 3, stream);
+    // the latency form (deep ring, conv_igemm_split_kernel's NBUF) for launches that cannot fill the chip anyway
+    const long long ntile = (long long)((p.M + bm - 1) / bm) * (a.cout_pad / bn);
+    if (bm == 128 && bn == 64 && ntile <= 256 && !a.force_bm) return launch_tile_split<128, 64, 64, 32, false, false, 5>(p, a.cout_pad, 2, stream);
+    if (bm == 64 && bn == 64 && ntile <= 256 && !a.force_bm) return launch_tile_split<64, 64, 32, 32, false, false, 8>(p, a.cout_pad, 2, stream);
     if (bm == 128 && bn == 64) return launch_tile_split<128, 64, 64, 32>(p, a.cout_pad, 4, stream);
     if (bm == 64 && bn == 64) return launch_tile_split<64, 64, 32, 32>(p, a.cout_pad, 4, stream);
     return launch_tile_split<128, 32, 32, 32>(p, a.cout_pad, 4, stream);

@@ -128,6 +128,15 @@ struct om_model {
             L.info.wsplit_scale_off = (int64_t)split_words;
             split_words = om::align_up(split_words + L.info.cout_pad, 4);
         }
+        // ... and for the stride-1 3x3 layers their DIRECT weights as well (own per-channel exponents): the latency mode
+        // (om_model_set_latency_cells) runs them through the implicit GEMM when the batch has too few tiles to fill the chip
+        L.info.wsplit_direct_off = L.info.wsplit_direct_scale_off = -1;
+        if (!stem && L.info.wino_planes == 24) {
+            L.info.wsplit_direct_off = (int64_t)split_words;
+            split_words += (size_t)ks * ks * L.info.cout_pad * cin;
+            L.info.wsplit_direct_scale_off = (int64_t)split_words;
+            split_words = om::align_up(split_words + L.info.cout_pad, 4);
+        }
         L.info.w16_off = -1;
         if (!stem) {
             L.info.w16_off = (int64_t)weight_halfs;
@@ -281,6 +290,16 @@ struct om_model {
     // With split operands (precision 1) F(2x4) runs at every size: its matrix instructions are 5.3x cheaper than the fp32-operand
     // F(2x2) kernel's, which outweighs idle workgroup slots at small batches -- and an image's results then do not depend on the
     // batch it is in.
+    // Latency mode (precision 1, opt-in: 0 = off): a forward whose batch holds fewer than this many 1/32-scale cells runs its
+    // stride-1 3x3 layers as direct convolutions in the implicit GEMM (small tiles, one short round) instead of the fused
+    // F(4,3) kernel, whose 128 x 64 tiles leave most of the chip idle at one or two images and take cin / 16 x 6 groups of
+    // ~1200 cycles each: 544^2, one image, 2.9 of the forward's 3.8 ms.  Other arithmetic than the fused kernel (same
+    // tolerance against the reference), so outputs then depend on which side of the switch a batch is: off by default.
+    long long latency_cells = 0;
+    bool direct_3x3(int B, int H, int W) const {
+        return precision == 1 && !keep_all && latency_cells > 0 && (long long)B * (H / 32) * (W / 32) < latency_cells;
+    }
+
     bool use_f24(int B, int H, int W) const {
         return precision == 1 || (long long)B * (H / 32) * (W / 32) >= 1700ll;
     }
@@ -591,7 +610,13 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             if (li.wino_off >= 0 && om::wino_enabled()) {
                 float* wino_scratch = reinterpret_cast<float*>(static_cast<char*>(workspace) + lay.scratch_off[&L - m->layers.data()]);
                 a.mid_event = ev_mid;
-                if (li.wino_planes == 24 && m->precision == 1) {
+                if (li.wino_planes == 24 && m->precision == 1 && m->direct_3x3(B, H, W)) {
+                    // latency mode: the same layer as a direct 3x3 convolution with split operands (implicit GEMM)
+                    a.w = m->weights_split + li.wsplit_direct_off;
+                    a.scale = m->weights_split + li.wsplit_direct_scale_off;
+                    if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
+                    rc = om::launch_conv_igemm_split(a, stream);
+                } else if (li.wino_planes == 24 && m->precision == 1) {
                     // split operands: the fused F(4,3) form, one kernel, no transformed input in memory
                     a.w = m->weights_split + li.wsplit_off;
                     a.scale = m->weights_split + li.wsplit_scale_off;
@@ -699,6 +724,12 @@ int om_layer_output_view(const om_model* m, int index, int B, int H, int W, int 
     return OM_OK;
 }
 
+int om_model_set_latency_cells(om_model* m, long long cells) {
+    OM_REQUIRE(m && cells >= 0, OM_EINVAL, "om_model_set_latency_cells: bad argument");
+    m->latency_cells = cells;
+    return OM_OK;
+}
+
 int om_model_keep_activations(om_model* m, int keep) {
     OM_REQUIRE(m, OM_EINVAL, "om_model_keep_activations: null model");
     m->keep_all = keep != 0;
@@ -712,6 +743,11 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
     if (L.stem && m->stem2_fused((size_t)index)) { *bm = 128; *bn = 64; *algo = 9; return OM_OK; }      // conv1 + conv2.0 in one kernel
     if (L.stem) { *bm = 0; *bn = 0; *algo = 0; return OM_OK; }
     if (index == 1 && m->stem2_fused(0)) { *bm = 0; *bn = 0; *algo = 10; return OM_OK; }                // ... which this layer is part of
+    if (L.info.wino_off >= 0 && om::wino_enabled() && L.info.wino_planes == 24 && m->precision == 1 && m->direct_3x3(B, H, W)) {
+        om::conv_tile_for_split(B * (H / L.in_div) * (W / L.in_div), L.info.cout_pad, bm, bn);
+        *algo = 7;
+        return OM_OK;
+    }
     if (L.info.wino_off >= 0 && om::wino_enabled() && L.info.wino_planes == 24 && m->precision == 1) {
         *algo = 8; *bm = 128; *bn = 64;
         return OM_OK;

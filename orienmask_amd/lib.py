@@ -22,7 +22,8 @@ class LayerInfo(ctypes.Structure):
                 ("has_bn", ctypes.c_int32), ("leaky", ctypes.c_int32), ("wino_planes", ctypes.c_int32),
                 ("w_off", ctypes.c_int64), ("scale_off", ctypes.c_int64), ("shift_off", ctypes.c_int64),
                 ("wino_off", ctypes.c_int64), ("wino_alt_off", ctypes.c_int64), ("w16_off", ctypes.c_int64),
-                ("wsplit_off", ctypes.c_int64), ("wsplit_scale_off", ctypes.c_int64)]
+                ("wsplit_off", ctypes.c_int64), ("wsplit_scale_off", ctypes.c_int64),
+                ("wsplit_direct_off", ctypes.c_int64), ("wsplit_direct_scale_off", ctypes.c_int64)]
 
 
 class PostCfg(ctypes.Structure):
@@ -66,6 +67,7 @@ SIGNATURES = {
     "om_model_load_weights_split": (_i, [_vp, _vp, _sz]),
     "om_model_set_precision": (_i, [_vp, _i]),
     "om_model_get_precision": (_i, [_vp]),
+    "om_model_set_latency_cells": (_i, [_vp, ctypes.c_longlong]),
     "om_model_set_upsample_on_read": (_i, [_vp, _i]),
     "om_conv2d_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "om_conv2d_winograd24_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp, _vp]),

@@ -145,6 +145,7 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         self._packed16 = None        # fp16 convolution weights (precision == "f16")
         self._packed_split = None    # hi/lo fp16 pairs of the F(2x4) weights (precision == "f32_split")
         self.set_precision(precision)
+        self.latency_cells = 0       # set_latency_mode(): direct 3x3 convolutions for batches of a few images (off)
         self.n_streams = 1           # set_streams(): sub-batches on side HIP streams
         self._side_streams = {}
         self._packed_device = None
@@ -245,6 +246,18 @@ class OrienMaskYOLOFPNPlus(nn.Module):
             _lib.check(_lib.load().om_model_load_weights_split(h, ctypes.c_void_p(blob.data_ptr()), blob.numel() * 4),
                        "om_model_load_weights_split")
         self._packed_split = blob
+
+    LATENCY_CELLS = 1200          # about four 544 x 544 images (289 cells each): set_latency_mode(True)
+
+    def set_latency_mode(self, enable=True, cells=None):
+        """precision 'f32_split' only.  True: batches of fewer than `cells` 1/32-scale cells (default LATENCY_CELLS: up to four
+        544 x 544 images) run their stride-1 3x3 layers as direct convolutions in the implicit GEMM instead of the fused
+        F(4,3) kernel (include/orienmask_hip.h: om_model_set_latency_cells) -- 544^2, one image: 3.8 -> 2.x ms per forward.  Other
+        summation order than the fused kernel (same 1e-4 bar against the reference; ~1e-6 of scale apart), so outputs are no
+        longer independent of the batch size: off by default, on in tester.infer_loop (the reference's bs = 1 loop)."""
+        self.latency_cells = int(cells if cells is not None else self.LATENCY_CELLS) if enable else 0
+        _lib.check(_lib.load().om_model_set_latency_cells(self._ensure_handle(), self.latency_cells), "om_model_set_latency_cells")
+        return self
 
     def set_upsample_on_read(self, enable=True):
         """precision 'f32_split' only: True (default) = the routes and skips store one copy at their own resolution and the 1x1 layer

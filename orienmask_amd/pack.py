@@ -30,7 +30,8 @@ def graph_layers(handle):
                         ksize=info.ksize, stride=info.stride, has_bn=bool(info.has_bn), leaky=bool(info.leaky),
                         w_off=info.w_off, scale_off=info.scale_off, shift_off=info.shift_off,
                         wino_off=info.wino_off, wino_planes=info.wino_planes, wino_alt_off=info.wino_alt_off,
-                        w16_off=info.w16_off, wsplit_off=info.wsplit_off, wsplit_scale_off=info.wsplit_scale_off))
+                        w16_off=info.w16_off, wsplit_off=info.wsplit_off, wsplit_scale_off=info.wsplit_scale_off,
+                        wsplit_direct_off=info.wsplit_direct_off, wsplit_direct_scale_off=info.wsplit_direct_scale_off))
     return out
 
 
@@ -230,4 +231,10 @@ def pack_state_dict_split(state_dict, layers, total_words):
         scale = torch.zeros(cpad, dtype=torch.float64)
         scale[:l["cout"]] = scale64.float().double()
         blob[l["wsplit_scale_off"]:l["wsplit_scale_off"] + cpad] = (scale * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e.double())).float()
+        if l.get("wsplit_direct_off", -1) >= 0:              # the latency mode's direct form of a stride-1 3x3 layer
+            ud, ed = conv_weights_split(w, cpad)
+            nd = ud.numel() // 2
+            blob[l["wsplit_direct_off"]:l["wsplit_direct_off"] + nd] = ud.reshape(-1).view(torch.float32)
+            blob[l["wsplit_direct_scale_off"]:l["wsplit_direct_scale_off"] + cpad] = \
+                (scale * torch.pow(torch.tensor(2.0, dtype=torch.float64), -ed.double())).float()
     return blob

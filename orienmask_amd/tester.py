@@ -113,7 +113,7 @@ class Tester:
         return stats
 
 
-def infer_loop(model, transform, postprocess, images, device, warmup=10, size_divisor=32, use_graph=True):
+def infer_loop(model, transform, postprocess, images, device, warmup=10, size_divisor=32, use_graph=True, latency_mode=True):
     """images: list of [h,w,3] float32 tensors (what cv2.imread + cvtColor give infer.py).
     Returns (list of per-image detections, list of pad_info, timer log in ms).
 
@@ -121,12 +121,20 @@ def infer_loop(model, transform, postprocess, images, device, warmup=10, size_di
     (graph.GraphedPipeline: ~95 kernel launches become one graph launch; bit-identical detections, tests/test_hip_parity.py::
     test_tester_and_infer_loops); a postprocess built for one image size only sees that size (infer.py resizes to 544 x 544
     first), other shapes fall back to eager launches.  Detections of a graphed call are views of graph-owned buffers that the
-    next call overwrites, so they are cloned here (the reference returns fresh tensors)."""
+    next call overwrites, so they are cloned here (the reference returns fresh tensors).
+
+    latency_mode (default): this is the reference's ONE-IMAGE loop (infer.py:143-172), so the model's latency mode is on while
+    it runs (model.set_latency_mode: direct 3x3 convolutions instead of the fused Winograd kernel for a batch this small) and
+    restored afterwards."""
     _timer.reset()
     _timer.cuda()
     model.eval()
     results, pads = [], []
     graphs = {}
+    restore = None
+    if latency_mode and getattr(model, "precision", None) == "f32_split" and hasattr(model, "set_latency_mode"):
+        restore = model.latency_cells
+        model.set_latency_mode(True)
 
     def run(x):
         if not use_graph:
@@ -153,4 +161,6 @@ def infer_loop(model, transform, postprocess, images, device, warmup=10, size_di
                     det = run(x)
                 results.append(det[0])
                 pads.append(pad_info)
+    if restore is not None:
+        model.set_latency_mode(restore > 0, restore or None)
     return results, pads, _timer.get_all_elapsed_time()

@@ -762,19 +762,8 @@ def _hip_model(sd, dev, precision="f32"):
     return net.to(dev)
 
 
-@pytest.mark.parametrize("precision", ["f32", "f32_split"])
-@pytest.mark.parametrize("fname", golden_files("fwd_"))
-def test_forward_matches_reference_golden(dev, fname, precision):
-    """HIP forward vs tensors the real reference produced (tests/golden/fwd_*.npz), with fp32 operands and with split operands
-    (every convolution but the stem; the stride-1 3x3 layers run F(2x4) at every batch size in that mode)."""
-    g = np.load(os.path.join(GOLDEN, fname))
-    size = tuple(int(v) for v in g["size"]); batch = int(g["batch"])
-    sd, x = fixture_weights_and_input(g)       # fwd_stress_*: heavy-tailed BatchNorm scales, 1e-20 / zero rows, saturated input
-    net = _hip_model(sd, dev, precision)
-    with torch.no_grad():
-        out = net(x.to(dev))
-    torch.cuda.synchronize()
-    assert out.flags() == 0, "a fixture must not need the fp32-operand fallback (it would test nothing of the split kernels)"
+def _check_forward_fixture(out, g, fname, precision, dev, size, batch):
+    """Head tensors against the digests / tensors the reference produced, then the composed path against its detections."""
     got = dict(bbox32=out[0][0], bbox16=out[1][0], bbox8=out[2][0],
                oriens=torch.cat([out[0][1], out[1][1], out[2][1]], 1))
     for k, t in got.items():
@@ -798,6 +787,22 @@ def test_forward_matches_reference_golden(dev, fname, precision):
         _check_detections_composed(r, g["bbox_det%d" % b], g["cls_det%d" % b],
                                    unpack_masks(g["mask%d" % b], g["maskshape%d" % b]), (fname, precision, b),
                                    margin_ctx=_margin_ctx(oracle_post, heads_cpu, b))
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32_split"])
+@pytest.mark.parametrize("fname", golden_files("fwd_"))
+def test_forward_matches_reference_golden(dev, fname, precision):
+    """HIP forward vs tensors the real reference produced (tests/golden/fwd_*.npz), with fp32 operands and with split operands
+    (every convolution but the stem; the stride-1 3x3 layers run F(2x4) at every batch size in that mode)."""
+    g = np.load(os.path.join(GOLDEN, fname))
+    size = tuple(int(v) for v in g["size"]); batch = int(g["batch"])
+    sd, x = fixture_weights_and_input(g)       # fwd_stress_*: heavy-tailed BatchNorm scales, 1e-20 / zero rows, saturated input
+    net = _hip_model(sd, dev, precision)
+    with torch.no_grad():
+        out = net(x.to(dev))
+    torch.cuda.synchronize()
+    assert out.flags() == 0, "a fixture must not need the fp32-operand fallback (it would test nothing of the split kernels)"
+    _check_forward_fixture(out, g, fname, precision, dev, size, batch)
 
 
 def test_forward_matches_oracle_and_layouts(dev):
@@ -2116,3 +2121,38 @@ def test_near_tie_fixtures_beside_fp16_matrix_neighbour(dev, fname):
                                   (fname, "beside fp16", it, b), exact_decode=True)
                 assert torch.equal(r["bbox"], alone[b]["bbox"]) and torch.equal(r["cls"], alone[b]["cls"]) and \
                     torch.equal(r["mask"], alone[b]["mask"]) and torch.equal(post.last_keep[b], alone_keep[b]), (fname, it, b)
+
+
+@pytest.mark.parametrize("fname", ["fwd_f544_b1.npz", "fwd_f160x128_b1.npz", "fwd_stress_f160x128_b1.npz"])
+def test_latency_mode_matches_reference_golden(dev, fname):
+    """model.set_latency_mode (om_model_set_latency_cells): batches of a few images run their stride-1
+    3x3 layers as direct split-operand convolutions in the implicit GEMM instead of the fused F(4,3) kernel.  Same bar as every
+    other forward: heads within 1e-4 of the REFERENCE's tensors (tests/golden/fwd_*.npz), detections of the composed path as in
+    test_forward_matches_reference_golden; against the default mode ~1e-6 of scale, and -- the point of the mode being opt-in --
+    not bit-identical to it; above the switch (a batch of 6 images) the mode changes nothing, bit for bit."""
+    g = np.load(os.path.join(GOLDEN, fname))
+    size = tuple(int(v) for v in g["size"])
+    sd, x = fixture_weights_and_input(g)
+    net = _hip_model(sd, dev, "f32_split")
+    xd = x.to(dev)
+    with torch.no_grad():
+        base = [(a.clone(), b.clone()) for a, b in net(xd)]
+        net.set_latency_mode(True)
+        kernels = dict(net.layer_kernels(xd.shape[0], size[0], size[1]))
+        assert kernels["backbone.conv4.1.conv.1"].startswith("conv_igemm_split_kernel"), kernels["backbone.conv4.1.conv.1"]
+        out = net(xd)
+        assert out.flags() == 0
+        _check_forward_fixture(out, g, fname, "f32_split latency mode", dev, size, int(g["batch"]))
+        for i, (gb, go) in enumerate(out):
+            assert _rel_err(gb, base[i][0]) < 2e-5 and _rel_err(go, base[i][1]) < 2e-5
+        assert not all(torch.equal(a, c) for (a, _), (c, _) in zip(out, base)), "the latency mode did not change the arithmetic"
+        again = net(xd)
+        assert all(torch.equal(a, c) and torch.equal(b, d) for (a, b), (c, d) in zip(out, again))      # run-to-run identical
+        # a batch above the switch is untouched by the mode
+        big = torch.cat([xd] * 6) if size[0] * size[1] >= 544 * 544 else None
+        if big is not None:
+            on = [(a.clone(), b.clone()) for a, b in net(big)]
+            net.set_latency_mode(False)
+            off = net(big)
+            assert all(torch.equal(a, c) and torch.equal(b, d) for (a, b), (c, d) in zip(on, off))
+    net.set_latency_mode(False)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(built):
 
 
 def test_struct_layouts_match_header(built):
-    assert ctypes.sizeof(omlib.LayerInfo) == 64 + 8 * 4 + 8 * 8
+    assert ctypes.sizeof(omlib.LayerInfo) == 64 + 8 * 4 + 10 * 8
     assert ctypes.sizeof(omlib.PostCfg) == 4 * (1 + 3 + 3 + 2 + 1 + 9 + 9 + 9 + 1 + 2 + 2 + 1 + 1 + 2 + 3)
     assert ctypes.sizeof(omlib.RleImage) == 8 + 4 * 11 + 4          # pointer, eleven int32, tail padding to 8
 
@@ -362,6 +362,13 @@ def test_pack_state_dict_split_covers_every_layer(built):
         n = (18 if l["wino_planes"] == 24 else l["ksize"] ** 2) * l["cout_pad"] * l["cin"]
         spans.append((l["wsplit_off"], l["wsplit_off"] + n))
         spans.append((l["wsplit_scale_off"], l["wsplit_scale_off"] + l["cout_pad"]))
+        if l["wino_planes"] == 24:      # the latency mode's direct form of the same layer (om_model_set_latency_cells)
+            spans.append((l["wsplit_direct_off"], l["wsplit_direct_off"] + 9 * l["cout_pad"] * l["cin"]))
+            spans.append((l["wsplit_direct_scale_off"], l["wsplit_direct_scale_off"] + l["cout_pad"]))
+            d = blob[l["wsplit_direct_off"]:l["wsplit_direct_off"] + 9 * l["cout_pad"] * l["cin"]].view(torch.float16)
+            assert torch.isfinite(d.float()).all() and d.abs().max() >= 2.0 ** 13
+        else:
+            assert l["wsplit_direct_off"] == -1
     spans.sort()
     assert spans[0][0] == 0 and all(a[1] <= b[0] < a[1] + 4 for a, b in zip(spans, spans[1:])) and total - spans[-1][1] < 4
     perm = torch.tensor(pack._SPLIT_PERM)
