@@ -1,7 +1,7 @@
 #!/bin/bash
 # bench.py at several per-GPU batch sizes (latency view): gpurun -- 'bash tools/batch_sweep.sh 1 4 8 32'
 for b in "$@"; do
-  python bench.py --batch $b --steps 30 --warmup 10 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
+  python bench.py --batch $b --steps 30 --warmup 10 --no-cpu-baseline --no-extras --no-f16-compare --no-small-batch 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 f=d.get('f32_operands') or {}

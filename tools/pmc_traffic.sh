@@ -17,7 +17,7 @@ cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$C
   rocprofv3 --kernel-trace --output-format csv --pmc $C -d $R/gpurun_out/pmc_$C -o pmc -- \
-    timeout 300 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-f32-compare --in-flight 1 $EXTRA > /dev/null 2> $R/gpurun_out/pmc_$C.err || true
+    timeout 300 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-f32-compare --no-f16-compare --no-small-batch --in-flight 1 $EXTRA > /dev/null 2> $R/gpurun_out/pmc_$C.err || true
 done
 cd $R
 TAG=$TAG python - <<'PY'

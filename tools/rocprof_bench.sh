@@ -9,7 +9,7 @@ R=$PWD
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o $TAG -- \
-    python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-compare --in-flight 1 $EXTRA > $R/gpurun_out/prof_${TAG}_bench.json 2> $R/gpurun_out/prof_${TAG}.err
+    python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-compare --no-f16-compare --no-small-batch --in-flight 1 $EXTRA > $R/gpurun_out/prof_${TAG}_bench.json 2> $R/gpurun_out/prof_${TAG}.err
 cd $R
 STATS=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$STATS" gpurun_out/prof_${TAG}_kernel_stats.csv
