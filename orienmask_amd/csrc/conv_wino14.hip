@@ -21,7 +21,7 @@
 //   * (eight consumer waves) runs 18 (ky, j) steps of three v_mfma_f32_32x32x16_f16 per wave: the A fragment of tap ky is the SAME LDS plane read Ct
 //     entries further on (row oy + ky of the block: conv3x3_f16.hip's shared patch, one dimension up), so V is stored once for
 //     the three kernel rows; zero padding is zero ENTRIES (rows / columns outside the image are written as zeros), no masks;
-//   * streams U through a three-slot LDS-DMA ring of (j; ky = 0..2) groups, 12 KiB each, contiguous in the packed blob; a
+//   * streams U through a ring of W14_RING (four since round 4; three before) LDS-DMA slots of (j; ky = 0..2) groups, 12 KiB each, contiguous in the packed blob; a
 //     group's first weight fragments are read AFTER the barrier that starts the group, so a group requested in group g is not
 //     needed before group g + 2 (two groups to land: the landing time of this stream is the consumers' critical path).
 // What binds the kernel is the CU's vector-memory request path (L1 pending-request stalls 41 % of the time: 72 KB of weights and
