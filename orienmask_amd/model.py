@@ -41,7 +41,14 @@ class Prediction(tuple):
       precision  the arithmetic that produced the heads ('f32', 'f32_split', 'f16')
       rerun      callable: the same input through the fp32-operand kernels (precision 'f32') in the same workspace slot,
                  on the current stream -- what a set OM_STATUS_SPLIT_RANGE asks for; None when precision is not 'f32_split'
-    Nothing here synchronises; check() does."""
+    Nothing here synchronises; check() does.
+
+    Two contracts a caller of a bare forward() must know: (1) in precision 'f32_split' the range guard is
+    resolved by whoever reads the status -- orienmask_amd.eval.OrienMaskYOLOPostProcess does, with its own host read; code that
+    hands the heads to anything else calls check() first (an activation beyond ~6550 in front of a 3x3 layer leaves NaN heads and
+    OM_STATUS_SPLIT_RANGE set; construct the model with precision='f32' to have no such condition).  (2) rerun re-reads the INPUT
+    tensor of the forward: it must not be refilled in place between the forward and check() / the postprocess's collect() /
+    InFlightPipeline.result() (the loops in this package allocate a fresh tensor per batch, like the reference's loader)."""
 
     def __new__(cls, items, status=None, precision=None, rerun=None):
         self = super().__new__(cls, items)
