@@ -299,6 +299,14 @@ struct om_model {
     bool direct_3x3(int B, int H, int W) const {
         return precision == 1 && !keep_all && latency_cells > 0 && (long long)B * (H / 32) * (W / 32) < latency_cells;
     }
+    // ... per layer: only where the fused kernel would have at most 128 of its 128 x 64 tiles (half the CUs idle); with more
+    // tiles it is the faster form again (136^2 128 -> 256, one image: 160 tiles, 0.057 ms against 0.080 ms direct)
+    bool direct_3x3_layer(const om::LayerDef& L, int B, int H, int W) const {
+        if (!direct_3x3(B, H, W) || L.info.wino_planes != 24) return false;
+        int R = 0, Ct = 0, ncb = 0, nrb = 0;
+        om::wino14_geometry(B, H / L.in_div, W / L.in_div, &R, &Ct, &ncb, &nrb);
+        return (long long)nrb * ncb * (L.info.cout_pad / 64) <= 128;
+    }
 
     bool use_f24(int B, int H, int W) const {
         return precision == 1 || (long long)B * (H / 32) * (W / 32) >= 1700ll;
@@ -610,7 +618,7 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             if (li.wino_off >= 0 && om::wino_enabled()) {
                 float* wino_scratch = reinterpret_cast<float*>(static_cast<char*>(workspace) + lay.scratch_off[&L - m->layers.data()]);
                 a.mid_event = ev_mid;
-                if (li.wino_planes == 24 && m->precision == 1 && m->direct_3x3(B, H, W)) {
+                if (li.wino_planes == 24 && m->precision == 1 && m->direct_3x3_layer(L, B, H, W)) {
                     // latency mode: the same layer as a direct 3x3 convolution with split operands (implicit GEMM)
                     a.w = m->weights_split + li.wsplit_direct_off;
                     a.scale = m->weights_split + li.wsplit_direct_scale_off;
@@ -743,7 +751,7 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
     if (L.stem && m->stem2_fused((size_t)index)) { *bm = 128; *bn = 64; *algo = 9; return OM_OK; }      // conv1 + conv2.0 in one kernel
     if (L.stem) { *bm = 0; *bn = 0; *algo = 0; return OM_OK; }
     if (index == 1 && m->stem2_fused(0)) { *bm = 0; *bn = 0; *algo = 10; return OM_OK; }                // ... which this layer is part of
-    if (L.info.wino_off >= 0 && om::wino_enabled() && L.info.wino_planes == 24 && m->precision == 1 && m->direct_3x3(B, H, W)) {
+    if (L.info.wino_off >= 0 && om::wino_enabled() && L.info.wino_planes == 24 && m->precision == 1 && m->direct_3x3_layer(L, B, H, W)) {
         om::conv_tile_for_split(B * (H / L.in_div) * (W / L.in_div), L.info.cout_pad, bm, bn);
         *algo = 7;
         return OM_OK;

@@ -259,7 +259,7 @@ class OrienMaskYOLOFPNPlus(nn.Module):
     def set_latency_mode(self, enable=True, cells=None):
         """precision 'f32_split' only.  True: batches of fewer than `cells` 1/32-scale cells (default LATENCY_CELLS: up to four
         544 x 544 images) run their stride-1 3x3 layers as direct convolutions in the implicit GEMM instead of the fused
-        F(4,3) kernel (include/orienmask_hip.h: om_model_set_latency_cells) -- 544^2, one image: 3.8 -> 2.x ms per forward.  Other
+        F(4,3) kernel (include/orienmask_hip.h: om_model_set_latency_cells) -- 544^2, one image: 3.5 -> 2.8 ms end to end; per layer only where the fused kernel would have at most 128 tiles.  Other
         summation order than the fused kernel (same 1e-4 bar against the reference; ~1e-6 of scale apart), so outputs are no
         longer independent of the batch size: off by default, on in tester.infer_loop (the reference's bs = 1 loop)."""
         self.latency_cells = int(cells if cells is not None else self.LATENCY_CELLS) if enable else 0
