@@ -246,6 +246,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the preprocess / COCO-format side measurements")
     ap.add_argument("--latency-mode", action="store_true",
                     help="f32_split: model.set_latency_mode(True) for the whole run (direct 3x3 convolutions below ~4 images per batch)")
+    ap.add_argument("--latency-ksplit", type=int, default=None,
+                    help="with --latency-mode: most parts a small launch's k loop is cut into (om_model_set_latency_ksplit; default: the library's)")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the bs = 1 / bs = 8 latency figures (`small_batches`)")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
     ap.add_argument("--heads", choices=("dense", "sparse", "allpass"), default="dense",
@@ -336,7 +338,7 @@ def main():
     if args.replicated_concat:
         net.set_upsample_on_read(False)
     if args.latency_mode:
-        net.set_latency_mode(True)
+        net.set_latency_mode(True, ksplit=args.latency_ksplit)
     post = OrienMaskYOLOPostProcess(device=dev, **post_config(H, W))
     x_cpu = synth.synth_image_batch(1000 + rank, B, H, W)
     x = x_cpu.to(dev)

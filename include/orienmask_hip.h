@@ -153,6 +153,13 @@ int om_model_set_precision(om_model* m, int mode);
  * Same layer, other summation: heads agree with the fused form to ~1e-6 of scale, not bit for bit, so an image's outputs then
  * depend on which side of the switch its batch is.  0 (default): off -- outputs independent of the batch size. */
 int om_model_set_latency_cells(om_model* m, long long cells);
+/* Latency mode only: the implicit GEMM's launches of few tiles (<= 256 tiles of 64 x 64 / 128 x 64: one image's 1/16- and
+ * 1/32-scale layers are 40 .. 152) cut every tile's k loop into up to `max_parts` parts (default 8; as many as two workgroups per
+ * CU take in one round, sixteen k-steps each at least), one workgroup per part; the parts' raw accumulators meet in the
+ * workspace's partial-tile area and the part that arrives last sums them IN PART ORDER and stores the tile -- no spinning, and
+ * the same bits whichever part is last.  At bs = 1 these layers stream their weights (19 MB for a 512 -> 1024 3x3 layer) and
+ * the number of CUs that request decides the rate.  1: whole tiles. */
+int om_model_set_latency_ksplit(om_model* m, int max_parts);
 int om_model_get_precision(const om_model* m);
 /* Precision mode 1 only: 1 (default) = the routes and skips (the 1x1 layers whose output the reference up-samples and concatenates,
  * orienmask_yolo_fpnplus.py:78-86) store ONE copy at their own resolution and the 1x1 layer behind the concat reads them
@@ -273,6 +280,14 @@ int om_conv2d_split(const float* in, int B, int H, int W, int cin, int in_pix_st
                     const float* scale_split, const float* shift, int cout, int ksize, int stride, int leaky, const float* res,
                     int res_pix_stride, float* out, int out_pix_stride, int out_mode, int up, int tile_bm, int tile_bn,
                     int32_t* status_dev, om_stream stream);
+/* om_conv2d_split with a tile's k loop cut into up to max_parts (1 .. 8) parts, as the latency mode's small launches run
+ * (om_model_set_latency_ksplit: fewer where the tile count or the k loop's length caps it).  Takes effect for the 128x64 and
+ * 64x64 shapes of at most 256 tiles; anything else runs as om_conv2d_split.  The partial tiles live in library-owned memory
+ * (unit-test entry; om_forward uses the caller's workspace). */
+int om_conv2d_split_k(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* w_split,
+                      const float* scale_split, const float* shift, int cout, int ksize, int stride, int leaky, const float* res,
+                      int res_pix_stride, float* out, int out_pix_stride, int out_mode, int up, int tile_bm, int tile_bn,
+                      int max_parts, int32_t* status_dev, om_stream stream);
 /* The 1x1 layer behind an up-sample + concat, as om_forward runs neck16.0 / neck8.0 / neck4.0 in precision mode 1
  * (conv_igemm_split.hip, GATHER form): the input channels are the concatenation of nseg (1..4) NHWC tensors, segment g with
  * seg_channels[g] channels (a multiple of 32) stored at [B, H/seg_up[g], W/seg_up[g], seg_pix_stride[g]] (seg_up a power of two

@@ -58,6 +58,12 @@ struct IgemmSParams {
     int ks, stride, pad;
     int M, kc, ksteps, taps;               // kc = cin / 16
     int n_tiles, total_tiles;
+    // split-K (the deep-ring forms only, conv_igemm_split_kernel<..., NBUF > 3>): a tile's k loop is cut into `ksplit` parts, one
+    // ticket each; every part leaves its raw accumulators in `partial`, the part that arrives LAST at the tile's counter
+    // (kflags[tile], zeroed with the ticket) sums all of them in part order -- a fixed order, whoever is last -- and stores the tile
+    float* partial;
+    int* kflags;
+    int ksplit, total_tickets;
     int leaky, res_pix_stride, out_pix_stride, out_mode, up;
     int vec_io;
     int total_in_pixels;
@@ -259,7 +265,8 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
     static_assert(BM % 64 == 0, "A tile = whole 64-row pieces");
     static_assert(WM * BN / 4 <= NBUF * STAGE, "one wave-row of the fp32 C tile must fit in the operand ring");
     __shared__ f32x4 smem[NBUF * STAGE + 1];      // ONE LDS object (see conv_igemm.hip)
-    int* const s_ticket = reinterpret_cast<int*>(smem + NBUF * STAGE);
+    int* const s_ticket = reinterpret_cast<int*>(smem + NBUF * STAGE);      // [0] the ticket, [1] split-K: arrivals before this part
+    constexpr bool KSPLIT = NBUF > 3;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -279,8 +286,16 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         int tile = *s_ticket;
-        if (tile >= p.total_tiles) break;
+        if (tile >= (KSPLIT ? p.total_tickets : p.total_tiles)) break;
         tile = __builtin_amdgcn_readfirstlane(tile);
+        int s_begin = 0, nsteps = p.ksteps;      // this ticket's part of the k loop
+        [[maybe_unused]] int part = 0;
+        if constexpr (KSPLIT) {
+            part = tile % p.ksplit;              // a tile's parts are consecutive tickets: they run at the same time
+            tile = tile / p.ksplit;
+            s_begin = part * p.ksteps / p.ksplit;
+            nsteps = (part + 1) * p.ksteps / p.ksplit - s_begin;
+        }
         const int tile_n = tile % p.n_tiles;
         const int tile_m = tile / p.n_tiles;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -324,6 +339,12 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
         const int in_bytes = in_left < 0x7FFFFFFFull ? (int)in_left : 0x7FFFFFFF;
 
         int n_kh = 0, n_kw = 0, n_cc = 0;          // step being fetched: (tap row, tap col, 16-channel chunk)
+        if constexpr (KSPLIT) {
+            const int tap0 = s_begin / p.kc;
+            n_cc = s_begin - tap0 * p.kc;
+            n_kh = tap0 / p.ks;
+            n_kw = tap0 - n_kh * p.ks;
+        }
         auto advance = [&]() {
             if (++n_cc == p.kc) {
                 n_cc = 0;
@@ -379,7 +400,7 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
 #pragma unroll
         for (int st = 0; st < NBUF; ++st) {
 #pragma unroll
-            for (int piece = 0; piece < NP; ++piece) issue_piece(piece, st, st < p.ksteps);
+            for (int piece = 0; piece < NP; ++piece) issue_piece(piece, st, st < nsteps);
             advance();
         }
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NBUF - 1) * NP) : "memory");
@@ -387,14 +408,14 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
         read_raw(0);
         convert();
         int buf = 0;
-        for (int s = 0; s < p.ksteps; ++s) {
+        for (int s = 0; s < nsteps; ++s) {
             const int buf1 = buf == NBUF - 1 ? 0 : buf + 1;
             // step s+1 has landed (only the NBUF - 2 steps behind it may still fly); every wave's reads of `buf` are complete
             // (they fed its convert) -> `buf` can take step s + NBUF
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"((NBUF - 2) * NP) : "memory");
             __builtin_amdgcn_s_barrier();
             read_raw(buf1);
-            const bool live3 = s + NBUF < p.ksteps;
+            const bool live3 = s + NBUF < nsteps;
 #pragma unroll
             for (int piece = 0; piece < NP; ++piece) issue_piece(piece, buf, live3);
 #pragma unroll
@@ -412,6 +433,55 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
+
+        if constexpr (KSPLIT) {
+            if (p.ksplit > 1) {
+                // publish this part's raw accumulators (write-through stores, as conv_wino24.hip's stream-K form), count the arrival
+                const auto rs_part = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, 0x7FFFFFFF, 0x00020000);
+                constexpr int PART_BYTES = TM * TN * 4 * 256 * 16;
+                const int pbase = (tile * p.ksplit + part) * PART_BYTES + tid * 16;
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                                                   rs_part, pbase, ((a * TN + b) * 4 + g) * 256 * 16, 16);
+                        }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                // (write-through 16-byte stores, drained by every wave above, then ONE agent-scope atomic: no release fence -- a
+                // buffer_wbl2 would also write back the previous layer's dirty lines, microseconds per part; the last arrival reads
+                // with sc1 loads, which pass this CU's L1: no acquire either.  MI355X_MICROARCH.md, inter-workgroup visibility)
+                if (tid == 0) s_ticket[1] = __hip_atomic_fetch_add(p.kflags + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                if (s_ticket[1] != p.ksplit - 1) continue;      // another part stores the tile
+                // the last arrival: every part has published; the sum runs in part order (this part's own copy included), so the
+                // result does not depend on which part came last
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+                for (int q = 0; q < p.ksplit; ++q) {
+                    const int qbase = (tile * p.ksplit + q) * PART_BYTES + tid * 16;
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_part, qbase, ((a * TN + b) * 4 + g) * 256 * 16, 16));
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) acc[a][b][4 * g + k] += v[k];
+                            }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
 
         float sc[8], sh[8];      // (four blocks per CU: no registers to hold them across the k loop)
         if constexpr (FAST) split_scale_shift<BN>(p, n0, tid, sc, sh);
@@ -664,7 +734,23 @@ static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hi
     const long long total = (long long)m_tiles * p.n_tiles;
     OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "conv split: %lld tiles out of range", total);
     p.total_tiles = (int)total;
-    const long long grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
+    // split-K (deep-ring forms; p.ksplit arrives as the caller's upper bound): as many parts as two workgroups per CU take in one
+    // round, at least sixteen k-steps each (bs = 1, per layer: 1x1 layers of 16 / 32 / 64 k-steps are fastest in 1 / 2 / 4 parts, a
+    // part costing ~2 us of prologue and its share of the last arrival's sum; profiles/r04_experiments.md section 9)
+    int parts = 1;
+    if constexpr (NBUF > 3) {
+        if (p.ksplit > 1 && p.partial && total <= SK_SLOTS) {
+            parts = p.ksplit;
+            if (parts > 512 / (int)total) parts = 512 / (int)total;
+            if (parts > p.ksteps / 16) parts = p.ksteps / 16;
+            if (parts > 8) parts = 8;
+            if (parts < 1) parts = 1;
+        }
+    }
+    p.ksplit = parts;
+    p.total_tickets = p.total_tiles * parts;
+    const long long tickets = total * parts;
+    const long long grid = tickets < 256ll * blocks_per_cu ? tickets : 256ll * blocks_per_cu;
     // the epilogue without loads in its row sweeps (split_epilogue: FAST) wherever the layer allows it
     const bool fast = p.out_mode == 0 && !p.res && p.vec_io && p.cout == cout_pad;
     if constexpr (WIDE) {
@@ -731,6 +817,7 @@ int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream) {
     p.leaky = a.leaky; p.res_pix_stride = a.res_pix_stride; p.out_pix_stride = a.out_pix_stride;
     p.out_mode = a.out_mode; p.up = a.up;
     p.n_tiles = 0; p.total_tiles = 0;
+    p.partial = a.sk_partial; p.kflags = a.ticket + SK_FLAG_OFF; p.ksplit = a.ksplit_max; p.total_tickets = 0;
     p.total_in_pixels = a.B * a.H * a.W;
     p.w_bytes = a.cout_pad * p.taps * a.cin * 4;
     p.vec_io = (a.out_mode != 2 && a.out_pix_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
@@ -779,8 +866,9 @@ int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream) {
     if (bm == 128 && bn == 128) return launch_tile_split<128, 128, 64, 64>(p, a.cout_pad, 3, stream);
     // the latency form (deep ring, conv_igemm_split_kernel's NBUF) for launches that cannot fill the chip anyway
     const long long ntile = (long long)((p.M + bm - 1) / bm) * (a.cout_pad / bn);
-    if (bm == 128 && bn == 64 && ntile <= 256 && !a.force_bm) return launch_tile_split<128, 64, 64, 32, false, false, 5>(p, a.cout_pad, 2, stream);
-    if (bm == 64 && bn == 64 && ntile <= 256 && !a.force_bm) return launch_tile_split<64, 64, 32, 32, false, false, 8>(p, a.cout_pad, 2, stream);
+    const bool deep = ntile <= 256 && (!a.force_bm || a.ksplit_max >= 1);      // (om_conv2d_split_k: a forced shape in its deep-ring form)
+    if (bm == 128 && bn == 64 && deep) return launch_tile_split<128, 64, 64, 32, false, false, 5>(p, a.cout_pad, 2, stream);
+    if (bm == 64 && bn == 64 && deep) return launch_tile_split<64, 64, 32, 32, false, false, 8>(p, a.cout_pad, 2, stream);
     if (bm == 128 && bn == 64) return launch_tile_split<128, 64, 64, 32>(p, a.cout_pad, 4, stream);
     if (bm == 64 && bn == 64) return launch_tile_split<64, 64, 32, 32>(p, a.cout_pad, 4, stream);
     return launch_tile_split<128, 32, 32, 32>(p, a.cout_pad, 4, stream);

@@ -56,6 +56,8 @@ struct ConvArgs {
     int split = 0;          // Winograd F(2x4) only: operands as hi/lo fp16 pairs (conv_wino24.hip)
     int* status = nullptr;  // the forward's status word (include/orienmask_hip.h: OM_STATUS_*), OR-ed by the split-operand kernels
                             // and the stream-K form; nullptr = not reported
+    int ksplit_max = 0;     // conv_igemm_split.hip, launches of few tiles: most parts a tile's k loop may be cut into (needs sk_partial and
+                            // the ticket's flag words; 0 / 1: whole tiles).  The sum order changes with the number of parts.
     int force_bm = 0, force_bn = 0;   // unit-test entries: tile shape of conv_igemm_split.hip for THIS call (0 = the chooser's)
     // gathered input (conv_igemm_split.hip, 1x1 layers): the cin channels are the concatenation of nseg tensors, segment g stored
     // at 1 / seg_up[g] of this layer's resolution and read nearest-up-sampled; nseg = 0: the plain view `in`

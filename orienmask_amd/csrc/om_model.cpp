@@ -296,6 +296,7 @@ struct om_model {
     // ~1200 cycles each: 544^2, one image, 2.9 of the forward's 3.8 ms.  Other arithmetic than the fused kernel (same
     // tolerance against the reference), so outputs then depend on which side of the switch a batch is: off by default.
     long long latency_cells = 0;
+    int latency_ksplit = 8;      // latency mode: most parts a tile's k loop is cut into (conv_igemm_split.hip; 1 = whole tiles)
     bool direct_3x3(int B, int H, int W) const {
         return precision == 1 && !keep_all && latency_cells > 0 && (long long)B * (H / 32) * (W / 32) < latency_cells;
     }
@@ -615,6 +616,7 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             a.ticket = tickets + (&L - m->layers.data()) * om::SYNC_WORDS;
             a.sk_partial = sk_partial;
             a.status = status;
+            a.ksplit_max = (m->precision == 1 && m->direct_3x3(B, H, W)) ? m->latency_ksplit : 0;      // latency mode only
             if (li.wino_off >= 0 && om::wino_enabled()) {
                 float* wino_scratch = reinterpret_cast<float*>(static_cast<char*>(workspace) + lay.scratch_off[&L - m->layers.data()]);
                 a.mid_event = ev_mid;
@@ -735,6 +737,12 @@ int om_layer_output_view(const om_model* m, int index, int B, int H, int W, int 
 int om_model_set_latency_cells(om_model* m, long long cells) {
     OM_REQUIRE(m && cells >= 0, OM_EINVAL, "om_model_set_latency_cells: bad argument");
     m->latency_cells = cells;
+    return OM_OK;
+}
+
+int om_model_set_latency_ksplit(om_model* m, int max_parts) {
+    OM_REQUIRE(m && max_parts >= 1 && max_parts <= 8, OM_EINVAL, "om_model_set_latency_ksplit: max_parts=%d (1 .. 8)", max_parts);
+    m->latency_ksplit = max_parts;
     return OM_OK;
 }
 
@@ -871,6 +879,34 @@ int om_conv2d_split(const float* in, int B, int H, int W, int cin, int in_pix_st
     if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), om::SYNC_WORDS * sizeof(int)));
     if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;
     a.ticket = g_ticket;
+    return om::launch_conv_igemm_split(a, static_cast<hipStream_t>(stream));
+}
+
+int om_conv2d_split_k(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* w_split,
+                      const float* scale_split, const float* shift, int cout, int ksize, int stride, int leaky, const float* res,
+                      int res_pix_stride, float* out, int out_pix_stride, int out_mode, int up, int tile_bm, int tile_bn,
+                      int max_parts, int32_t* status_dev, om_stream stream) {
+    OM_REQUIRE(B > 0 && H > 0 && W > 0 && stride >= 1 && H % stride == 0 && W % stride == 0, OM_EINVAL,
+               "om_conv2d_split_k: bad shape");
+    OM_REQUIRE(out_mode >= 0 && out_mode <= 2 && up >= 1 && (out_mode == 1 || up == 1), OM_EINVAL,
+               "om_conv2d_split_k: out_mode=%d up=%d (0 NHWC, 1 NHWC replicated up x up, 2 NCHW)", out_mode, up);
+    OM_REQUIRE(max_parts >= 1 && max_parts <= 8, OM_EINVAL, "om_conv2d_split_k: max_parts=%d (1 .. 8)", max_parts);
+    om::ConvArgs a;
+    a.in = in; a.w = static_cast<const float*>(w_split); a.scale = scale_split; a.shift = shift; a.res = res; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.cin = cin; a.in_pix_stride = in_pix_stride;
+    a.Ho = H / stride; a.Wo = W / stride; a.cout = cout; a.cout_pad = om::round_up(cout, 32);
+    a.ks = ksize; a.stride = stride; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
+    a.out_pix_stride = out_pix_stride; a.out_mode = out_mode; a.up = up;
+    a.force_bm = tile_bm; a.force_bn = tile_bn; a.status = status_dev;
+    a.ksplit_max = max_parts;
+    // unit-test entry only (see om_conv2d_mode): library-owned sync words and room for 512 parts of 128 x 64 floats
+    static int* g_ticket = nullptr;
+    static float* g_partial = nullptr;
+    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), om::SYNC_WORDS * sizeof(int)));
+    if (!g_partial) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_partial), (size_t)512 * 128 * 64 * sizeof(float)));
+    if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;
+    a.ticket = g_ticket;
+    a.sk_partial = g_partial;
     return om::launch_conv_igemm_split(a, static_cast<hipStream_t>(stream));
 }
 

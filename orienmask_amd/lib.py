@@ -68,8 +68,10 @@ SIGNATURES = {
     "om_model_set_precision": (_i, [_vp, _i]),
     "om_model_get_precision": (_i, [_vp]),
     "om_model_set_latency_cells": (_i, [_vp, ctypes.c_longlong]),
+    "om_model_set_latency_ksplit": (_i, [_vp, _i]),
     "om_model_set_upsample_on_read": (_i, [_vp, _i]),
     "om_conv2d_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "om_conv2d_split_k": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "om_conv2d_winograd24_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp, _vp]),
     "om_conv2d_wino14_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "om_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i]),

@@ -256,7 +256,7 @@ class OrienMaskYOLOFPNPlus(nn.Module):
 
     LATENCY_CELLS = 1200          # about four 544 x 544 images (289 cells each): set_latency_mode(True)
 
-    def set_latency_mode(self, enable=True, cells=None):
+    def set_latency_mode(self, enable=True, cells=None, ksplit=None):
         """precision 'f32_split' only.  True: batches of fewer than `cells` 1/32-scale cells (default LATENCY_CELLS: up to four
         544 x 544 images) run their stride-1 3x3 layers as direct convolutions in the implicit GEMM instead of the fused
         F(4,3) kernel (include/orienmask_hip.h: om_model_set_latency_cells) -- 544^2, one image: 3.5 -> 2.8 ms end to end; per layer only where the fused kernel would have at most 128 tiles.  Other
@@ -264,6 +264,8 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         longer independent of the batch size: off by default, on in tester.infer_loop (the reference's bs = 1 loop)."""
         self.latency_cells = int(cells if cells is not None else self.LATENCY_CELLS) if enable else 0
         _lib.check(_lib.load().om_model_set_latency_cells(self._ensure_handle(), self.latency_cells), "om_model_set_latency_cells")
+        if ksplit is not None:      # most parts a small launch's k loop is cut into (om_model_set_latency_ksplit; default 8, 1 = whole tiles)
+            _lib.check(_lib.load().om_model_set_latency_ksplit(self._ensure_handle(), int(ksplit)), "om_model_set_latency_ksplit")
         return self
 
     def set_upsample_on_read(self, enable=True):

@@ -297,6 +297,82 @@ def test_conv_split_layer_matches_torch(dev, case):
     assert err < 2e-6, case
 
 
+@pytest.mark.parametrize("case", [
+    # (B, H, W, cin, cout, k, stride, leaky, residual, out_mode, tile, max_parts)
+    (1, 17, 17, 512, 1024, 3, 1, 1, 0, 0, (64, 64), 8),      # backbone.conv6.x.conv.1 of one image: 80 tiles, 288 k-steps -> 6 parts
+    (1, 17, 17, 1024, 512, 1, 1, 1, 0, 0, (64, 64), 8),      # conv6.x.conv.0: 40 tiles, 64 k-steps -> 4 parts
+    (1, 34, 34, 256, 512, 3, 1, 1, 1, 0, (64, 64), 3),       # residual: the epilogue with loads; 152 tiles -> 3 parts
+    (2, 34, 34, 256, 512, 3, 2, 1, 0, 0, (64, 64), 8),       # stride 2 (padding taps inside a part's first step), partial last M tile
+    (1, 68, 68, 128, 256, 3, 1, 1, 1, 0, (128, 64), 8),      # the five-stage 128 x 64 form: 148 tiles -> 3 parts
+    (1, 20, 12, 96, 255, 3, 1, 0, 0, 2, (64, 64), 8),        # head: ragged cout, NCHW output, 54 k-steps -> 3 parts of 18
+    (1, 8, 8, 16, 64, 1, 1, 1, 0, 0, (64, 64), 8),           # one k-step: not cut
+    (3, 17, 17, 96, 128, 3, 1, 1, 0, 0, (64, 64), 2),        # 54 k-steps: parts of 27 that start inside a kernel tap
+])
+def test_conv_split_k_parts(dev, case):
+    """conv_igemm_split_kernel's split-K form (latency mode, om_model_set_latency_ksplit: a tile's k loop cut into parts, the last
+    arrival sums the published accumulators in part order) against float64 convolution at the whole-tile kernel's bound, and twice
+    in a row bit for bit (the sum order does not depend on which part arrives last)."""
+    from orienmask_amd.pack import conv_weights_split
+    B, H, W, cin, cout, k, stride, leaky, use_res, out_mode, (bm, bn), parts = case
+    L = omlib.load()
+    g = torch.Generator().manual_seed(B + H + W + cin + cout + k + parts)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.2
+    Ho, Wo = H // stride, W // stride
+    res = torch.randn(B, cout, Ho, Wo, generator=g) if use_res else None
+    want = torch.nn.functional.conv2d(x.double(), w.double(), None, stride, k // 2)
+    want = want * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if leaky:
+        want = torch.where(want > 0, want, want * 0.1)
+    if use_res:
+        want = want + res.double()
+    cpad = (cout + 31) // 32 * 32
+    ws, e = conv_weights_split(w, cpad)
+    sp = torch.zeros(cpad); sp[:cout] = scale
+    sp = (sp.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e.double())).float()
+    hp = torch.zeros(cpad); hp[:cout] = shift
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wd, sd_, hd = ws.to(dev), sp.to(dev), hp.to(dev)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def run(max_parts):
+        shape = (B, cout, Ho, Wo) if out_mode == 2 else (B, Ho, Wo, cout)
+        out = torch.full(shape, float("nan"), device=dev)
+        rc = L.om_conv2d_split_k(_p(xd), B, H, W, cin, cin, _p(wd), _p(sd_), _p(hd), cout, k, stride, leaky,
+                                 _p(rd) if use_res else None, cout if use_res else 0, _p(out), cout, out_mode, 1, bm, bn, max_parts,
+                                 _p(status), omlib.current_stream_ptr(dev))
+        omlib.check(rc, "om_conv2d_split_k")
+        o = out.cpu()
+        return o if out_mode == 2 else o.permute(0, 3, 1, 2)
+
+    got = run(parts)
+    assert torch.isfinite(got).all()
+    assert int(status.item()) == 0
+    err = _rel_err(got.double(), want)
+    print("conv split-K %s: %.2e" % (case, err))
+    assert err < 2e-6, case
+    for _ in range(3):
+        assert torch.equal(run(parts), got)
+    whole = run(1)                                       # the same kernel with whole tiles
+    assert _rel_err(whole.double(), want) < 2e-6
+    assert _rel_err(got.double(), whole.double()) < 4e-6
+    # other data through the same partial-tile area: nothing of the previous launch's parts may be read (a stale line in this
+    # XCD's L2 or this CU's L1 would be exactly that)
+    for rep in range(3):
+        x2 = torch.randn(B, cin, H, W, generator=g)
+        want2 = torch.nn.functional.conv2d(x2.double(), w.double(), None, stride, k // 2)
+        want2 = want2 * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+        if leaky:
+            want2 = torch.where(want2 > 0, want2, want2 * 0.1)
+        if use_res:
+            want2 = want2 + res.double()
+        xd.copy_(x2.permute(0, 2, 3, 1))
+        assert _rel_err(run(parts).double(), want2) < 2e-6, (case, rep)
+
+
 @pytest.mark.parametrize("case", [(8, 68, 68, 256, 128, 1, 1), (4, 68, 68, 128, 256, 3, 2), (2, 34, 34, 96, 128, 3, 2)])
 def test_conv_split_wide_rows_equal_narrow(dev, case):
     """conv_igemm_split_wide_kernel (128 x 128 tile, ring stages of 128-byte operand rows: what the tile chooser's 128 x 128 runs
