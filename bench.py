@@ -589,7 +589,7 @@ def main():
                          "hipGraph (orienmask_amd.graph.GraphedPipeline, what infer_loop runs for a fixed shape), one at a time eagerly, "
                          "with four batches in flight (InFlightPipeline), and -- f32_split -- one at a time through the graph in the model's "
                          "latency mode (model.set_latency_mode, what tester.infer_loop switches on: stride-1 3x3 layers as direct "
-                         "convolutions below ~4 images; a batch of 8 is above that switch)")
+                         "convolutions where the fused kernel would have <= 128 tiles, split-K parts in the implicit GEMM's small launches)")
     timed_fw //= max(args.streams, 1)                              # one om_forward per sub-batch
     dom_main_ms = sum(ms for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw      # per step, all launches
     dom_timed_ms = dom_main_ms + sum(pre for name, ms, pre in timed_ms if name in set(dom_layers)) / timed_fw

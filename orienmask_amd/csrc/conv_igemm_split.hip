@@ -63,7 +63,7 @@ struct IgemmSParams {
     // (kflags[tile], zeroed with the ticket) sums all of them in part order -- a fixed order, whoever is last -- and stores the tile
     float* partial;
     int* kflags;
-    int ksplit, total_tickets;
+    int ksplit, total_tickets, m_tiles;
     int leaky, res_pix_stride, out_pix_stride, out_mode, up;
     int vec_io;
     int total_in_pixels;
@@ -281,23 +281,39 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
     // ONE chip-wide tile queue here: per-XCD queues as in conv_wino24.hip were measured on these layers and lost 5 % end to end
     // (same-box A/B: forward kernels 19.6 -> 21.6 ms) -- most of them have one or two N tiles, so there is no panel to share and
     // the static eighths only unbalance the last round.
-    for (;;) {
-        if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int tile = *s_ticket;
-        if (tile >= (KSPLIT ? p.total_tickets : p.total_tiles)) break;
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        int s_begin = 0, nsteps = p.ksteps;      // this ticket's part of the k loop
+    //
+    // The deep-ring forms (KSPLIT: launches of at most 512 units = tiles x parts, all resident at once) have NO queue: one unit per
+    // workgroup, picked by blockIdx so that the workgroups of one XCD (blockIdx % 8, observed; only speed depends on it) take a
+    // CONTIGUOUS range of units in (part, N tile, M tile) order -- an XCD then reads about an eighth of the weights and an eighth of
+    // the input's k range instead of all of both.  One 544 x 544 image's 17 x 17 layers stream 19 MB of weights: drawn from a
+    // chip-wide queue every XCD pulled all of them through its 4 MiB L2 (8 x 19 MB from the Infinity Cache per layer).
+    for (int round = 0;; ++round) {
+        int tile;
+        int s_begin = 0, nsteps = p.ksteps;      // this unit's part of the k loop
         [[maybe_unused]] int part = 0;
+        int tile_n, tile_m;
         if constexpr (KSPLIT) {
-            part = tile % p.ksplit;              // a tile's parts are consecutive tickets: they run at the same time
-            tile = tile / p.ksplit;
+            if (round) break;
+            const int b = blockIdx.x, x = b & 7;
+            int unit = b >> 3;
+            for (int y = 0; y < x; ++y) unit += (p.total_tickets - y + 7) >> 3;      // units of the XCDs before this one
+            tile_m = unit % p.m_tiles;
+            const int t = unit / p.m_tiles;
+            tile_n = t % p.n_tiles;
+            part = t / p.n_tiles;
+            tile = tile_m * p.n_tiles + tile_n;
             s_begin = part * p.ksteps / p.ksplit;
             nsteps = (part + 1) * p.ksteps / p.ksplit - s_begin;
+        } else {
+            if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            tile = *s_ticket;
+            if (tile >= p.total_tiles) break;
+            tile = __builtin_amdgcn_readfirstlane(tile);
+            tile_n = tile % p.n_tiles;
+            tile_m = tile / p.n_tiles;
         }
-        const int tile_n = tile % p.n_tiles;
-        const int tile_m = tile / p.n_tiles;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
 
         // ---- loader role (conv_igemm_f16.hip): per A row the byte offset of tap (0,0)'s chunk relative to the tile's first
@@ -457,7 +473,7 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
                 // with sc1 loads, which pass this CU's L1: no acquire either.  MI355X_MICROARCH.md, inter-workgroup visibility)
                 if (tid == 0) s_ticket[1] = __hip_atomic_fetch_add(p.kflags + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __syncthreads();
-                if (s_ticket[1] != p.ksplit - 1) continue;      // another part stores the tile
+                if (s_ticket[1] != p.ksplit - 1) break;         // another part stores the tile
                 // the last arrival: every part has published; the sum runs in part order (this part's own copy included), so the
                 // result does not depend on which part came last
 #pragma unroll
@@ -749,8 +765,13 @@ static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hi
     }
     p.ksplit = parts;
     p.total_tickets = p.total_tiles * parts;
+    p.m_tiles = m_tiles;
     const long long tickets = total * parts;
-    const long long grid = tickets < 256ll * blocks_per_cu ? tickets : 256ll * blocks_per_cu;
+    long long grid = tickets < 256ll * blocks_per_cu ? tickets : 256ll * blocks_per_cu;
+    if constexpr (NBUF > 3) {      // one unit per workgroup, no queue
+        OM_REQUIRE(tickets <= 512, OM_EINVAL, "conv split: %lld units in a deep-ring launch", tickets);
+        grid = tickets;
+    }
     // the epilogue without loads in its row sweeps (split_epilogue: FAST) wherever the layer allows it
     const bool fast = p.out_mode == 0 && !p.res && p.vec_io && p.cout == cout_pad;
     if constexpr (WIDE) {

@@ -254,13 +254,17 @@ class OrienMaskYOLOFPNPlus(nn.Module):
                        "om_model_load_weights_split")
         self._packed_split = blob
 
-    LATENCY_CELLS = 1200          # about four 544 x 544 images (289 cells each): set_latency_mode(True)
+    LATENCY_CELLS = 3500          # about twelve 544 x 544 images (289 cells each): set_latency_mode(True)
 
     def set_latency_mode(self, enable=True, cells=None, ksplit=None):
-        """precision 'f32_split' only.  True: batches of fewer than `cells` 1/32-scale cells (default LATENCY_CELLS: up to four
-        544 x 544 images) run their stride-1 3x3 layers as direct convolutions in the implicit GEMM instead of the fused
-        F(4,3) kernel (include/orienmask_hip.h: om_model_set_latency_cells) -- 544^2, one image: 3.5 -> 2.8 ms end to end; per layer only where the fused kernel would have at most 128 tiles.  Other
-        summation order than the fused kernel (same 1e-4 bar against the reference; ~1e-6 of scale apart), so outputs are no
+        """precision 'f32_split' only.  True: batches of fewer than `cells` 1/32-scale cells (default LATENCY_CELLS: up to twelve
+        544 x 544 images) run their stride-1 3x3 layers as direct convolutions in the implicit GEMM instead of the fused F(4,3)
+        kernel -- per layer, only where the fused kernel would have at most 128 tiles (include/orienmask_hip.h:
+        om_model_set_latency_cells) -- and the implicit GEMM's launches of at most 256 tiles cut every tile's k loop into up to
+        `ksplit` parts (om_model_set_latency_ksplit, default 8) run by one workgroup each, placed so that an XCD reads an eighth of
+        the weights.  544^2 through the hipGraph of forward + postprocess: one image 3.4 -> 2.0 ms, two 3.5 -> 2.8, four
+        4.4 -> 3.9, eight 6.4 -> 6.2; from twelve images on nothing changes.  Other summation order than the fused kernel and
+        than whole tiles (same 1e-4 bar against the reference; ~1e-6 of scale apart; run-to-run identical), so outputs are no
         longer independent of the batch size: off by default, on in tester.infer_loop (the reference's bs = 1 loop)."""
         self.latency_cells = int(cells if cells is not None else self.LATENCY_CELLS) if enable else 0
         _lib.check(_lib.load().om_model_set_latency_cells(self._ensure_handle(), self.latency_cells), "om_model_set_latency_cells")

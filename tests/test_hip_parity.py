@@ -2227,6 +2227,7 @@ def test_latency_mode_matches_reference_golden(dev, fname):
         # a batch above the switch is untouched by the mode
         big = torch.cat([xd] * 6) if size[0] * size[1] >= 544 * 544 else None
         if big is not None:
+            net.set_latency_mode(True, cells=1200)      # six images: 1734 cells
             on = [(a.clone(), b.clone()) for a, b in net(big)]
             net.set_latency_mode(False)
             off = net(big)
