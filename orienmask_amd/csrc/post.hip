@@ -73,6 +73,7 @@ struct PostParams {
     float* cand_dets;      // [B][nms_pre][5] in the reference's LIST order (postprocess.py:102-122); NULL: the fused path
     int64_t* cand_cls;     // [B][nms_pre]
     int32_t* cand_field;   // [B][nms_pre] anchor field of the candidate
+    int mask_chunk;        // post_mask_kernel: detections of a field per workgroup (launch_post_mask)
 };
 
 // candidate index -> (scale, anchor slot, pixel)
@@ -810,30 +811,42 @@ __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
     const int b = blockIdx.y / nfields, field = blockIdx.y - b * nfields;
     // The detections of this (image, anchor field), compacted into LDS once per workgroup: {cx, cy, bits(tx), bits(ty)} and
     // the output slot k; the loop over them below touches no global memory but its own stores.
+    //
+    // blockIdx.z = a CHUNK of the field's detections (p.mask_chunk of them, in output-slot order): with few images in the batch a
+    // field that holds half of an image's detections was 19 workgroups walking 50 detections each while the rest of the chip had
+    // nothing to do (one image: 133 us).  The compaction is by ONE wave in slot order, so every workgroup of a field sees the
+    // same list and the chunks partition it.
     __shared__ float4 s_det[SEL_MAXN];
     __shared__ int s_slot[SEL_MAXN];
     __shared__ float s_anchor[2];
     __shared__ int s_n;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
         const int count = p.out_count[b];
         const float* dpar = p.det_par + (size_t)b * p.cfg.nms_post * 8;
-        for (int k = threadIdx.x; k < count; k += 256) {
+        int base = 0;
+        for (int k0 = 0; k0 < count; k0 += 64) {
+            const int k = k0 + lane;
             const float* dp = dpar + k * 8;
-            if (__float_as_int(dp[6]) != field * 2) continue;
-            const int slot = atomicAdd(&s_n, 1);
-            s_det[slot] = make_float4(dp[0], dp[1], __uint_as_float(threshold_bits(dp[2])), __uint_as_float(threshold_bits(dp[3])));
-            s_slot[slot] = k;
-            if (slot == 0) {        // grid_anchors of the field: the same for every detection on it
-                s_anchor[0] = dp[4];
-                s_anchor[1] = dp[5];
+            const bool mine = k < count && __float_as_int(dp[6]) == field * 2;
+            const unsigned long long votes = __ballot(mine);
+            if (mine) {
+                const int slot = base + __popcll(votes & ((1ull << lane) - 1ull));
+                s_det[slot] = make_float4(dp[0], dp[1], __uint_as_float(threshold_bits(dp[2])), __uint_as_float(threshold_bits(dp[3])));
+                s_slot[slot] = k;
+                if (slot == 0) {        // grid_anchors of the field: the same for every detection on it
+                    s_anchor[0] = dp[4];
+                    s_anchor[1] = dp[5];
+                }
             }
+            base += __popcll(votes);
         }
+        if (lane == 0) s_n = base;
     }
     __syncthreads();
-    const int n_det = s_n;
-    if (n_det == 0) return;         // no detection of this image on this field
+    const int i_first = blockIdx.z * p.mask_chunk;
+    const int n_det = min(s_n, i_first + p.mask_chunk);
+    if (i_first >= n_det) return;         // no detection of this image on this field (in this chunk)
     const int H = p.cfg.image_h, W = p.cfg.image_w;
     const int groups = W / MASK_PX;
     const int oh = H / 4, ow = W / 4;
@@ -915,7 +928,7 @@ __global__ __launch_bounds__(256) void post_mask_kernel(const PostParams p) {
             Px[e] = (vx[e] * gax) / 2.0f + base_x;
             Py[e] = (vy[e] * gay) / 2.0f + base_y;
         }
-        for (int i = 0; i < n_det; ++i) {
+        for (int i = i_first; i < n_det; ++i) {
             const float4 d = s_det[i];                                     // uniform: one LDS broadcast
             const int k = s_slot[i];
             const float cx = d.x, cy = d.y;
@@ -1219,7 +1232,12 @@ static int post_setup(const om_post_cfg* cfg, const float* bbox32, const float* 
 
 static int launch_post_mask(const om_post_cfg* cfg, const om::PostParams& p, int B, hipStream_t stream) {
     const int items = (cfg->image_h / 4 + 1) * (cfg->image_w / om::MASK_PX);
-    hipLaunchKernelGGL(om::post_mask_kernel, dim3((items + 255) / 256, B * p.a_off[cfg->num_scales]), dim3(256), 0, stream, p);
+    // detections of a field in chunks of their own workgroups while the batch alone does not fill the chip (post_mask_kernel)
+    const int fields = p.a_off[cfg->num_scales];
+    om::PostParams q = p;
+    q.mask_chunk = (long long)((items + 255) / 256) * B * fields >= 2048 ? cfg->nms_post : 8;
+    const int chunks = (cfg->nms_post + q.mask_chunk - 1) / q.mask_chunk;
+    hipLaunchKernelGGL(om::post_mask_kernel, dim3((items + 255) / 256, B * fields, chunks), dim3(256), 0, stream, q);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }
