@@ -62,11 +62,7 @@ typedef unsigned u32x4v __attribute__((__vector_size__(4 * sizeof(unsigned))));
                                // trip between the barrier and the group's first matrix instruction) and its weights still have two
                                // groups to land (requested three groups ahead)
 constexpr int W14_BM = 128, W14_BN = 64;
-#ifdef W14_BIG_PROBE
-constexpr int W14_EMAX = 144;
-#else
-constexpr int W14_EMAX = W14_RING == 4 ? 144 : 160;
-#endif      // LDS entries per plane: (R + 2) * Ct <= W14_EMAX
+constexpr int W14_EMAX = W14_RING == 4 ? 144 : 160;      // LDS entries per plane: (R + 2) * Ct <= W14_EMAX
 constexpr int W14_VPLANE = W14_EMAX * 4;      // f32x4 units (16 B) per plane
 constexpr int W14_VBUF = 6 * W14_VPLANE;      // one transformed chunk: 61440 B
 constexpr int W14_UGRP = 3 * W14_BN * 4;      // one (j; ky = 0..2) weight group: 12288 B
@@ -800,250 +796,6 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
     }
 }
 
-#ifdef W14_BIG_PROBE
-// ---- measurement only (tools/build_variant.sh ... -DW14_BIG_PROBE=1): the CONSUMER side of a 128 x 128 tile -- eight waves of
-// 64 entries x 32 output channels x six planes (192 accumulator registers, two waves per SIMD), 24 KiB weight groups through a
-// two-slot LDS-DMA ring, V read from LDS but never written (no producers): how fast can the matrix loop of that shape run?
-// Stores one value per lane so that nothing is optimised away; wrong numerics by construction.
-constexpr int W14B_UGRP = 2 * W14_UGRP;      // one plane's three kernel rows x 128 output channels
-__global__ __launch_bounds__(512, 2) void wino14_big_probe_kernel(const Wino14Params p) {
-    __shared__ f32x4 smem[2 * (6 * 144 * 4) + 2 * W14B_UGRP + 1];
-    constexpr int VPL = 144 * 4, VB = 6 * VPL;
-    f32x4* const s_u = smem + 2 * VB;
-    int* const s_ticket = reinterpret_cast<int*>(smem + 2 * VB + 2 * W14B_UGRP);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm2 = wave >> 2, wn4 = wave & 3;
-    const int fi = lane & 31, fk = lane >> 5;
-    const int ngroups = 6 * p.nch;
-    const int n_tiles2 = p.n_tiles >> 1, total2 = (p.total_tiles / p.n_tiles) * n_tiles2;
-    const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.u), 0, p.u_bytes, 0x00020000);
-    // 24 pieces of 1 KiB per group: wave w requests pieces w, w + 8, w + 16 (pieces 0-11: the first 64-channel half, 12-23 the second)
-    const int drow = lane >> 2, dcol = lane & 3;
-    int dvo[3], dhalf[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int piece = wave + 8 * i;
-        dhalf[i] = piece >= 12;
-        const int row = 16 * (piece - 12 * dhalf[i]) + drow;
-        dvo[i] = row * 64 + ((dcol ^ ((row >> 2) & 3)) * 16);
-    }
-    const int swB = (fi >> 2) & 3;
-    const int brow = (wn4 >> 1) * (W14_UGRP) + (32 * (wn4 & 1) + fi) * 4;       // half, then row of the tap's 64 rows
-    const int boff_hi = brow + (fk ^ swB), boff_lo = brow + ((2 + fk) ^ swB);
-    int aoff_hi[3], aoff_lo[3];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int e = 64 * wm2 + fi + ky * p.Ct;
-        const int sw = (e >> 2) & 3;
-        aoff_hi[ky] = e * 4 + (fk ^ sw);
-        aoff_lo[ky] = e * 4 + ((2 + fk) ^ sw);
-    }
-    auto issue_group = [&](int tn2, int g) {
-        if (g >= ngroups) return;
-        const int slot = g & 1;
-        const int c = g / 6, j = g - 6 * c;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int t64 = 2 * tn2 + dhalf[i];
-            const int soff = ((t64 * p.nch + c) * 6 + w14_plane(j)) * (W14_UGRP * 16);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14B_UGRP + (wave + 8 * i) * 64), 16, dvo[i], soff, 0, 0);
-        }
-    };
-    f32x16 acc[6][2];
-    float sink = 0.f;
-    for (;;) {
-        if (tid == 0) s_ticket[0] = atomicAdd(p.ticket + 8, 1);
-        __syncthreads();
-        const int tile = __builtin_amdgcn_readfirstlane(s_ticket[0]);
-        __syncthreads();
-        if (tile >= total2) break;
-        const int tn2 = tile % n_tiles2;
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][b][r] = 0.f;
-        issue_group(tn2, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int g = 0;
-        for (int c = 0; c < p.nch; ++c) {
-            const f32x4* sV = smem + (c & 1) * VB;
-            auto group = [&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                constexpr int pl = w14_plane(j);
-                const int slot = g & 1;
-                issue_group(tn2, g + 1);
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const f32x4 bh = s_u[slot * W14B_UGRP + ky * (W14_BN * 4) + boff_hi];
-                    const f32x4 bl = s_u[slot * W14B_UGRP + ky * (W14_BN * 4) + boff_lo];
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const f32x4 ah = sV[pl * VPL + aoff_hi[ky] + 128 * b];
-                        const f32x4 al = sV[pl * VPL + aoff_lo[ky] + 128 * b];
-                        const f16x8 ahh = __builtin_bit_cast(f16x8, ah), all = __builtin_bit_cast(f16x8, al);
-                        const f16x8 bhh = __builtin_bit_cast(f16x8, bh), bll = __builtin_bit_cast(f16x8, bl);
-                        acc[pl][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhh, all, acc[pl][b], 0, 0, 0);
-                        acc[pl][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bll, ahh, acc[pl][b], 0, 0, 0);
-                        acc[pl][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhh, ahh, acc[pl][b], 0, 0, 0);
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                ++g;
-            };
-            group(std::integral_constant<int, 0>{});
-            group(std::integral_constant<int, 1>{});
-            group(std::integral_constant<int, 2>{});
-            group(std::integral_constant<int, 3>{});
-            group(std::integral_constant<int, 4>{});
-            group(std::integral_constant<int, 5>{});
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sink += acc[j][b][r];
-    }
-    if (sink == 12345.678f) p.out[tid] = sink;
-}
-#endif
-
-#if defined(W14_BIG_PROBE) && W14_BIG_PROBE == 2
-// the same probe with FOUR waves of 64 entries x 64 output channels x six planes (384 accumulator registers, one wave per SIMD):
-// eight fragments per twelve matrix instructions; fragments of the next kernel row are read while this one multiplies
-__global__ __launch_bounds__(256, 1) void wino14_big4_probe_kernel(const Wino14Params p) {
-    __shared__ f32x4 smem[2 * (6 * 144 * 4) + 2 * W14B_UGRP + 1];
-    constexpr int VPL = 144 * 4, VB = 6 * VPL;
-    f32x4* const s_u = smem + 2 * VB;
-    int* const s_ticket = reinterpret_cast<int*>(smem + 2 * VB + 2 * W14B_UGRP);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm2 = wave >> 1, wn2 = wave & 1;
-    const int fi = lane & 31, fk = lane >> 5;
-    const int ngroups = 6 * p.nch;
-    const int n_tiles2 = p.n_tiles >> 1, total2 = (p.total_tiles / p.n_tiles) * n_tiles2;
-    const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.u), 0, p.u_bytes, 0x00020000);
-    const int drow = lane >> 2, dcol = lane & 3;
-    int dvo[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int piece = wave + 4 * i;                 // 0..23; pieces 0-11: first 64-channel half
-        const int row = 16 * (piece % 12) + drow;
-        dvo[i] = row * 64 + ((dcol ^ ((row >> 2) & 3)) * 16);
-    }
-    const int swB = (fi >> 2) & 3;
-    const int brow = wn2 * W14_UGRP + fi * 4;           // this wave's 64-channel half; block nb: + 32 rows
-    const int boff_hi = brow + (fk ^ swB), boff_lo = brow + ((2 + fk) ^ swB);
-    int aoff_hi[3], aoff_lo[3];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int e = 64 * wm2 + fi + ky * p.Ct;
-        const int sw = (e >> 2) & 3;
-        aoff_hi[ky] = e * 4 + (fk ^ sw);
-        aoff_lo[ky] = e * 4 + ((2 + fk) ^ sw);
-    }
-    auto issue_group = [&](int tn2, int g) {
-        if (g >= ngroups) return;
-        const int slot = g & 1;
-        const int c = g / 6, j = g - 6 * c;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int piece = wave + 4 * i;
-            const int t64 = 2 * tn2 + (piece >= 12);
-            const int soff = ((t64 * p.nch + c) * 6 + w14_plane(j)) * (W14_UGRP * 16);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14B_UGRP + piece * 64), 16, dvo[i], soff, 0, 0);
-        }
-    };
-    f32x16 acc[6][2][2];
-    float sink = 0.f;
-    for (;;) {
-        if (tid == 0) s_ticket[0] = atomicAdd(p.ticket + 8, 1);
-        __syncthreads();
-        const int tile = __builtin_amdgcn_readfirstlane(s_ticket[0]);
-        __syncthreads();
-        if (tile >= total2) break;
-        const int tn2 = tile % n_tiles2;
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[j][a][b][r] = 0.f;
-        issue_group(tn2, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int g = 0;
-        for (int c = 0; c < p.nch; ++c) {
-            const f32x4* sV = smem + (c & 1) * VB;
-            auto group = [&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                constexpr int pl = w14_plane(j);
-                const int slot = g & 1;
-                issue_group(tn2, g + 1);
-                f32x4 fa[2][2][2], fb[2][2][2];        // [buffer][block][hi / lo]
-                auto read_frags = [&](int buf, int ky) {
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        fa[buf][b][0] = sV[pl * VPL + aoff_hi[ky] + 128 * b];
-                        fa[buf][b][1] = sV[pl * VPL + aoff_lo[ky] + 128 * b];
-                        fb[buf][b][0] = s_u[slot * W14B_UGRP + ky * (W14_BN * 4) + boff_hi + 128 * b];
-                        fb[buf][b][1] = s_u[slot * W14B_UGRP + ky * (W14_BN * 4) + boff_lo + 128 * b];
-                    }
-                };
-#ifndef W14_PROBE_SINGLE
-                read_frags(0, 0);
-#endif
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-#ifdef W14_PROBE_SINGLE
-                    const int cur = 0;
-                    read_frags(0, ky);
-#else
-                    const int cur = ky & 1;
-                    if (ky < 2) read_frags(cur ^ 1, ky + 1);
-#endif
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            const f16x8 ahh = __builtin_bit_cast(f16x8, fa[cur][a][0]), all = __builtin_bit_cast(f16x8, fa[cur][a][1]);
-                            const f16x8 bhh = __builtin_bit_cast(f16x8, fb[cur][b][0]), bll = __builtin_bit_cast(f16x8, fb[cur][b][1]);
-                            acc[pl][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhh, all, acc[pl][a][b], 0, 0, 0);
-                            acc[pl][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bll, ahh, acc[pl][a][b], 0, 0, 0);
-                            acc[pl][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhh, ahh, acc[pl][a][b], 0, 0, 0);
-                        }
-                }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                ++g;
-            };
-            group(std::integral_constant<int, 0>{});
-            group(std::integral_constant<int, 1>{});
-            group(std::integral_constant<int, 2>{});
-            group(std::integral_constant<int, 3>{});
-            group(std::integral_constant<int, 4>{});
-            group(std::integral_constant<int, 5>{});
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sink += acc[j][a][b][r];
-    }
-    if (sink == 12345.678f) p.out[tid] = sink;
-}
-#endif
-
 // Block shape for a layer: Ct tile columns (a divisor-like split of ceil(W / 4)) x R padded rows with R * Ct <= 128 and
 // (R + 2) * Ct <= 160, picked for the largest share of useful rows in the 128-row matrix tile.
 void wino14_geometry(int B, int H, int W, int* R, int* Ct, int* ncb, int* nrb) {
@@ -1110,17 +862,6 @@ int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream) {
     OM_REQUIRE(p.trace, OM_EINVAL, "wino14 trace build: om_debug_w14_trace() first");
 #endif
     const long long grid = total < 256 ? total : 256;        // one 768-thread workgroup per CU (156 KiB of LDS)
-#ifdef W14_BIG_PROBE
-    if (p.n_tiles % 2 == 0) {
-#if W14_BIG_PROBE == 2
-        hipLaunchKernelGGL(wino14_big4_probe_kernel, dim3(256), dim3(256), 0, stream, p);
-#else
-        hipLaunchKernelGGL(wino14_big_probe_kernel, dim3(256), dim3(512), 0, stream, p);
-#endif
-        OM_CHECK_HIP(hipGetLastError());
-        return OM_OK;
-    }
-#endif
     if (!p.fast_io) hipLaunchKernelGGL(wino14_split_kernel<2>, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);
     else if (a.res) hipLaunchKernelGGL(wino14_split_kernel<1>, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);
     else hipLaunchKernelGGL(wino14_split_kernel<0>, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);
