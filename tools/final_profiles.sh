@@ -16,7 +16,8 @@ timeout 600 python bench.py --dtype f32 --no-cpu-baseline --no-small-batch --lay
 timeout 600 python bench.py --heads sparse --no-cpu-baseline --no-f16-compare --no-small-batch > $O/${TAG}_bench_sparse_heads.json 2> /dev/null
 timeout 600 python bench.py --heads allpass --no-cpu-baseline --no-f32-compare --no-f16-compare --no-small-batch > $O/${TAG}_bench_allpass_heads.json 2> /dev/null
 timeout 600 python bench.py --batch 1 --latency-mode --layers --no-cpu-baseline --no-f32-compare --no-f16-compare --no-small-batch --no-extras > $O/${TAG}_bench_bs1_latency_mode.json 2> $O/${TAG}_layers_bs1_latency_mode.txt
-timeout 600 python bench.py --dtype f16 --no-cpu-baseline --no-small-batch > $O/${TAG}_bench_f16.json 2> /dev/null
+timeout 600 python bench.py --dtype f16 --no-cpu-baseline --no-small-batch --layers > $O/${TAG}_bench_f16.json 2> $O/${TAG}_layers_f16.txt
+timeout 600 python tools/latency_ab.py --bs 1 2 4 8 --ksplit 1 8 --iters 100 > $O/${TAG}_latency_ab.txt 2>&1
 bash tools/rocprof_bench.sh $TAG > $O/rocprof.txt 2>&1
 cp gpurun_out/prof_${TAG}_kernel_stats.csv $O/${TAG}_rocprofv3_kernel_stats.csv
 timeout 600 python tools/split_error.py > $O/${TAG}_split_error.json 2> /dev/null
