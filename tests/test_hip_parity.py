@@ -1847,6 +1847,44 @@ def test_postprocess_and_forward_are_stable_beside_other_streams(dev, prec, othe
                 assert torch.equal(ga, wa) and torch.equal(gb, wb), it
 
 
+@pytest.mark.parametrize("other", ["f32_split", "f16"])
+def test_latency_mode_split_k_is_stable_beside_other_streams(dev, other):
+    """The split-K parts of the latency mode hand their accumulators to the last arrival through memory WITHOUT fences
+    (write-through stores, drained waves, one agent-scope atomic, sc1 loads: conv_igemm_split.hip).  That protocol has to hold
+    under uneven load and with the partial-tile area reused by other data between launches: single-image forwards of two
+    different images, alternating, while another model instance keeps the chip busy on a second stream -- every head bit for bit
+    equal to the forward of the same image that ran alone."""
+    sd = synth.synth_state_dict(3, obj_bias=-16.0, head_gain=4.0)
+    net = _hip_model(sd, dev, "f32_split").set_latency_mode(True)
+    busy = _hip_model(sd, dev).set_precision(other)
+    xs = [synth.synth_image_batch(910 + i, 1, 544, 544).to(dev) for i in range(2)]
+    y = synth.synth_image_batch(920, 6 if other == "f32_split" else 4, 544, 544).to(dev)
+    s0, s1 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    with torch.no_grad():
+        kernels = dict(net.layer_kernels(1, 544, 544))
+        assert kernels["backbone.conv6.1.conv.1"].startswith("conv_igemm_split_kernel<64,64"), kernels["backbone.conv6.1.conv.1"]
+        want = []
+        for x in xs:
+            out = net(x)
+            assert out.flags() == 0
+            want.append([(a.clone(), b.clone()) for a, b in out])
+        assert not torch.equal(want[0][0][0], want[1][0][0])
+        busy(y)
+        torch.cuda.synchronize()
+        for it in range(10):
+            with torch.cuda.stream(s1):
+                for _ in range(4 if other == "f16" else 2):
+                    busy(y)
+            got = []
+            with torch.cuda.stream(s0):
+                for k in range(6):
+                    got.append((k & 1, [(a.clone(), b.clone()) for a, b in net(xs[k & 1])]))
+            torch.cuda.synchronize()
+            for which, heads in got:
+                for (ga, gb), (wa, wb) in zip(heads, want[which]):
+                    assert torch.equal(ga, wa) and torch.equal(gb, wb), (it, which)
+
+
 def test_forward_f16_non_plus_model_matches_oracle(dev):
     """The OrienMaskYOLO graph (variant 1) through the fp16 path."""
     from orienmask_amd.model import OrienMaskYOLO
