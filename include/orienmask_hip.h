@@ -349,6 +349,26 @@ size_t om_postprocess_workspace_bytes(const om_post_cfg* cfg, int B);
 int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbox16, const float* bbox8,
                    const float* oriens, int B, float* out_bbox, int64_t* out_cls, uint8_t* out_mask,
                    int32_t* out_count, int32_t* out_keep, void* workspace, size_t ws_bytes, om_stream stream);
+/* om_postprocess in its two halves (it IS detect followed by assemble on one stream).  detect: decode, threshold, top-nms_pre,
+ * batched NMS, top-nms_post (postprocess.py:102-154) -- reads the box heads only; writes out_bbox / out_cls / out_count /
+ * out_keep and the detections' mask constants into the workspace.  assemble: the masks (postprocess.py:69-72,141-144,156-164) of
+ * those detections from the orientation head, with the same workspace.  Apart they let the first half run on another stream
+ * while the forward is still computing the orientation branch: om_model_attach_postprocess. */
+int om_postprocess_detect(const om_post_cfg* cfg, const float* bbox32, const float* bbox16, const float* bbox8, int B,
+                          float* out_bbox, int64_t* out_cls, int32_t* out_count, int32_t* out_keep, void* workspace, size_t ws_bytes,
+                          om_stream stream);
+int om_postprocess_assemble(const om_post_cfg* cfg, const float* oriens, int B, const int32_t* out_count, uint8_t* out_mask,
+                            void* workspace, size_t ws_bytes, om_stream stream);
+/* The step as ONE call sequence on the forward (tester.py:39-44's two lines; infer.py:154-156).  While a postprocess is
+ * attached, om_forward (fp32 / split precision) also runs it into the attached buffers: decode + select are launched on a second
+ * stream that the library creates, forked off the caller's stream by an event as soon as the last box-head layer is launched and
+ * joined behind the forward's last layer -- they read the box heads only, the select kernel is ONE workgroup per image, so beside
+ * the skips, neck4 and the orientation head they cost nothing -- and the mask kernel follows on the caller's stream.  On return
+ * everything is ordered before later work on the caller's stream; under stream capture the second stream joins the capture
+ * through the same events.  Same kernels on the same inputs as om_forward followed by om_postprocess: same bits.  cfg == NULL
+ * detaches.  The buffers must stay valid while attached (orienmask_amd/eval.py attaches around one forward). */
+int om_model_attach_postprocess(om_model* m, const om_post_cfg* cfg, float* out_bbox, int64_t* out_cls, uint8_t* out_mask,
+                                int32_t* out_count, int32_t* out_keep, void* post_workspace, size_t post_ws_bytes);
 
 /* The same postprocess around a caller-supplied NMS callable -- the reference takes ANY nms_func(dets, cls) -> (dets[keep],
  * cls[keep], keep) (/root/reference/eval/orienmask_yolo_postprocess.py:9-11,146-148); the fused om_postprocess implements

@@ -300,6 +300,27 @@ struct om_model {
     bool direct_3x3(int B, int H, int W) const {
         return precision == 1 && !keep_all && latency_cells > 0 && (long long)B * (H / 32) * (W / 32) < latency_cells;
     }
+    // om_model_attach_postprocess: the step's postprocess rides on the forward.  Decode + select (which read the box heads only)
+    // are launched on a SECOND stream of the library's own as soon as the last box-head layer is in the caller's stream -- forked
+    // there by an event, joined behind the forward's last layer -- and the mask kernel follows on the caller's stream.  The
+    // select kernel is one workgroup per image (0.11 ms at any batch size) and the decode a short pass over the heads: beside
+    // the skips, neck4 and the orientation head they cost nothing.  Same kernels, same inputs: same bits as om_forward followed
+    // by om_postprocess.
+    struct PostAttach {
+        bool on = false;
+        om_post_cfg cfg;
+        float* out_bbox = nullptr; int64_t* out_cls = nullptr; uint8_t* out_mask = nullptr;
+        int32_t* out_count = nullptr; int32_t* out_keep = nullptr;
+        void* ws = nullptr; size_t ws_bytes = 0;
+    } post;
+    struct Side { hipStream_t main = nullptr, side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
+    std::vector<Side> sides;      // one second stream per caller stream (batches in flight on several streams stay independent)
+    int head_last = -2;      // graph index of the last bbox_head* layer (-1: none; -2: not looked up yet)
+    void find_head_last() {
+        head_last = -1;
+        for (int l = 0; l < (int)layers.size(); ++l)
+            if (std::strncmp(layers[l].info.name, "bbox_head", 9) == 0) head_last = l;
+    }
     // ... per layer: only where the fused kernel would have at most 128 of its 128 x 64 tiles (half the CUs idle); with more
     // tiles it is the faster form again (136^2 128 -> 256, one image: 160 tiles, 0.057 ms against 0.080 ms direct)
     bool direct_3x3_layer(const om::LayerDef& L, int B, int H, int W) const {
@@ -434,6 +455,11 @@ int om_model_create_variant(om_model** out, int variant, int num_anchors, int nu
 void om_model_destroy(om_model* m) {
     if (!m) return;
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
+    for (om_model::Side& sd : m->sides) {
+        (void)hipEventDestroy(sd.ev_fork);
+        (void)hipEventDestroy(sd.ev_join);
+        (void)hipStreamDestroy(sd.side);
+    }
     delete m;
 }
 
@@ -511,8 +537,43 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
     const size_t need = forward_workspace_bytes(m, B, H, W, f16);
     OM_REQUIRE(ws_bytes >= need, OM_ENOMEM, "om_forward: workspace %zu bytes < %zu needed", ws_bytes, need);
     OM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, OM_EINVAL, "om_forward: workspace not 256-byte aligned");
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipStream_t const main_stream = static_cast<hipStream_t>(stream_);
     const size_t esz = f16 ? 2 : 4;
+    // an attached postprocess (om_model_attach_postprocess): decode + select on the library's second stream behind the last box head
+    const bool fused_post = m->post.on && !f16;
+    const bool early = fused_post && m->head_last >= 0;
+    om_model::Side sd;
+    if (early) {
+        for (const om_model::Side& have : m->sides)
+            if (have.main == main_stream) sd = have;
+        if (!sd.side && !m->sides.empty()) {
+            // a capturing stream (torch.cuda.graph captures on a stream of its own, after warm-ups elsewhere): nothing is created
+            // during a capture -- any existing second stream serves, the capture isolates it
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(main_stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
+                sd = m->sides.back();
+                sd.main = main_stream;
+            }
+        }
+        if (!sd.side) {      // first forward with an attachment on this stream
+            OM_REQUIRE(m->sides.size() < 64, OM_ESTATE, "om_forward: an attached postprocess was used from more than 64 streams");
+            sd.main = main_stream;
+            OM_CHECK_HIP(hipStreamCreateWithFlags(&sd.side, hipStreamNonBlocking));
+            OM_CHECK_HIP(hipEventCreateWithFlags(&sd.ev_fork, hipEventDisableTiming));
+            OM_CHECK_HIP(hipEventCreateWithFlags(&sd.ev_join, hipEventDisableTiming));
+            m->sides.push_back(sd);
+        }
+    }
+    struct JoinGuard {      // whatever path leaves the function: the caller's stream waits for the side stream's work
+        om_model::Side sd; bool forked;
+        void join() {
+            if (!forked) return;
+            forked = false;
+            (void)hipEventRecord(sd.ev_join, sd.side);
+            (void)hipStreamWaitEvent(sd.main, sd.ev_join, 0);
+        }
+        ~JoinGuard() { join(); }
+    } join_guard{sd, false};
 
     const om_model::Layout lay = m->layout(B, H, W, f16);
     std::vector<char*> base(m->bufs.size());
@@ -520,7 +581,7 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
     int* tickets = reinterpret_cast<int*>(static_cast<char*>(workspace) + lay.tickets_off);
     float* sk_partial = f16 ? nullptr : reinterpret_cast<float*>(static_cast<char*>(workspace) + lay.partial_off);
     int* status = tickets + m->layers.size() * om::SYNC_WORDS;      // om_forward_status_offset
-    if (int rc = om::launch_zero_words(tickets, m->layers.size() * om::SYNC_WORDS + om::STATUS_WORDS, stream)) return rc;
+    if (int rc = om::launch_zero_words(tickets, m->layers.size() * om::SYNC_WORDS + om::STATUS_WORDS, main_stream)) return rc;
     // element pointer of a view: workspace buffers hold esz-byte elements, the four outputs are always fp32
     auto ptr_of = [&](const om::View& v) -> void* {
         switch (v.buf) {
@@ -535,6 +596,8 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
     bool fused_into_previous = false;
     for (const om::LayerDef& L : m->layers) {
         const om_layer_info& li = L.info;
+        const int layer_index = (int)(&L - m->layers.data());
+        hipStream_t const stream = main_stream;
         hipEvent_t ev_stop = nullptr, ev_mid = nullptr;
         if (m->profiling && (m->prof_mask.empty() || m->prof_mask[&L - m->layers.data()])) {
             if (m->ev_used + 3 > m->ev_pool.size()) {
@@ -671,8 +734,27 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             om::set_error("layer %s: %s", li.name, msg);
             return rc;
         }
+        if (early && layer_index == m->head_last) {
+            // the box heads are complete in the caller's stream: decode + select beside the rest of the forward
+            OM_CHECK_HIP(hipEventRecord(sd.ev_fork, main_stream));
+            OM_CHECK_HIP(hipStreamWaitEvent(sd.side, sd.ev_fork, 0));
+            join_guard.forked = true;
+            const om_model::PostAttach& q = m->post;
+            if (int prc = om_postprocess_detect(&q.cfg, bbox32, bbox16, bbox8, B, q.out_bbox, q.out_cls, q.out_count, q.out_keep, q.ws,
+                                                q.ws_bytes, sd.side))
+                return prc;
+        }
     }
     if (m->profiling) ++m->prof_forwards;
+    if (fused_post) {
+        const om_model::PostAttach& q = m->post;
+        join_guard.join();
+        if (!early)
+            if (int prc = om_postprocess_detect(&q.cfg, bbox32, bbox16, bbox8, B, q.out_bbox, q.out_cls, q.out_count, q.out_keep, q.ws,
+                                                q.ws_bytes, main_stream))
+                return prc;
+        if (int prc = om_postprocess_assemble(&q.cfg, oriens, B, q.out_count, q.out_mask, q.ws, q.ws_bytes, main_stream)) return prc;
+    }
     return OM_OK;
 }
 
@@ -737,6 +819,24 @@ int om_layer_output_view(const om_model* m, int index, int B, int H, int W, int 
 int om_model_set_latency_cells(om_model* m, long long cells) {
     OM_REQUIRE(m && cells >= 0, OM_EINVAL, "om_model_set_latency_cells: bad argument");
     m->latency_cells = cells;
+    return OM_OK;
+}
+
+int om_model_attach_postprocess(om_model* m, const om_post_cfg* cfg, float* out_bbox, int64_t* out_cls, uint8_t* out_mask,
+                                int32_t* out_count, int32_t* out_keep, void* post_workspace, size_t post_ws_bytes) {
+    OM_REQUIRE(m, OM_EINVAL, "om_model_attach_postprocess: null model");
+    if (!cfg) {
+        m->post.on = false;
+        return OM_OK;
+    }
+    OM_REQUIRE(out_bbox && out_cls && out_mask && out_count && post_workspace, OM_EINVAL, "om_model_attach_postprocess: null argument");
+    OM_REQUIRE(post_ws_bytes >= om_postprocess_workspace_bytes(cfg, 1), OM_ENOMEM, "om_model_attach_postprocess: workspace too small");
+    m->post.cfg = *cfg;
+    m->post.out_bbox = out_bbox; m->post.out_cls = out_cls; m->post.out_mask = out_mask;
+    m->post.out_count = out_count; m->post.out_keep = out_keep;
+    m->post.ws = post_workspace; m->post.ws_bytes = post_ws_bytes;
+    m->post.on = true;
+    if (m->head_last == -2) m->find_head_last();
     return OM_OK;
 }
 

@@ -1242,24 +1242,42 @@ static int launch_post_mask(const om_post_cfg* cfg, const om::PostParams& p, int
     return OM_OK;
 }
 
-int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbox16, const float* bbox8,
-                   const float* oriens, int B, float* out_bbox, int64_t* out_cls, uint8_t* out_mask,
-                   int32_t* out_count, int32_t* out_keep, void* workspace, size_t ws_bytes, om_stream stream_) {
-    OM_REQUIRE(cfg && bbox32 && (cfg->num_scales < 2 || bbox16) && (cfg->num_scales < 3 || bbox8) && oriens && out_bbox && out_cls &&
-                   out_mask && out_count && workspace,
-               OM_EINVAL, "om_postprocess: null argument");
-    OM_REQUIRE((reinterpret_cast<uintptr_t>(out_mask) & 15) == 0, OM_EINVAL, "om_postprocess: out_mask must be 16-byte aligned");
+int om_postprocess_detect(const om_post_cfg* cfg, const float* bbox32, const float* bbox16, const float* bbox8, int B,
+                          float* out_bbox, int64_t* out_cls, int32_t* out_count, int32_t* out_keep, void* workspace, size_t ws_bytes,
+                          om_stream stream_) {
+    OM_REQUIRE(cfg && bbox32 && (cfg->num_scales < 2 || bbox16) && (cfg->num_scales < 3 || bbox8) && out_bbox && out_cls && out_count &&
+                   workspace,
+               OM_EINVAL, "om_postprocess_detect: null argument");
     om::PostParams p;
-    if (int rc = post_setup(cfg, bbox32, bbox16, bbox8, oriens, B, workspace, ws_bytes, p, "om_postprocess")) return rc;
+    if (int rc = post_setup(cfg, bbox32, bbox16, bbox8, nullptr, B, workspace, ws_bytes, p, "om_postprocess_detect")) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    p.out_bbox = out_bbox; p.out_cls = out_cls; p.out_mask = out_mask; p.out_count = out_count; p.out_keep = out_keep;
-
+    p.out_bbox = out_bbox; p.out_cls = out_cls; p.out_count = out_count; p.out_keep = out_keep;
     if (int rc = om::launch_zero_words(p.hist1, (size_t)B * om::L1_BINS + B, stream)) return rc;
     hipLaunchKernelGGL(om::post_decode_kernel, dim3(p.ntiles, B), dim3(256), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(om::post_select_kernel, dim3(B), dim3(om::SEL_THREADS), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
-    return launch_post_mask(cfg, p, B, stream);
+    return OM_OK;
+}
+
+int om_postprocess_assemble(const om_post_cfg* cfg, const float* oriens, int B, const int32_t* out_count, uint8_t* out_mask,
+                            void* workspace, size_t ws_bytes, om_stream stream_) {
+    OM_REQUIRE(cfg && oriens && out_count && out_mask && workspace, OM_EINVAL, "om_postprocess_assemble: null argument");
+    OM_REQUIRE((reinterpret_cast<uintptr_t>(out_mask) & 15) == 0, OM_EINVAL, "om_postprocess_assemble: out_mask must be 16-byte aligned");
+    om::PostParams p;
+    if (int rc = post_setup(cfg, oriens, oriens, oriens, oriens, B, workspace, ws_bytes, p, "om_postprocess_assemble")) return rc;   // (heads: not read)
+    p.out_mask = out_mask; p.out_count = const_cast<int32_t*>(out_count);
+    return launch_post_mask(cfg, p, B, static_cast<hipStream_t>(stream_));
+}
+
+int om_postprocess(const om_post_cfg* cfg, const float* bbox32, const float* bbox16, const float* bbox8,
+                   const float* oriens, int B, float* out_bbox, int64_t* out_cls, uint8_t* out_mask,
+                   int32_t* out_count, int32_t* out_keep, void* workspace, size_t ws_bytes, om_stream stream) {
+    OM_REQUIRE(oriens && out_mask, OM_EINVAL, "om_postprocess: null argument");
+    OM_REQUIRE((reinterpret_cast<uintptr_t>(out_mask) & 15) == 0, OM_EINVAL, "om_postprocess: out_mask must be 16-byte aligned");
+    if (int rc = om_postprocess_detect(cfg, bbox32, bbox16, bbox8, B, out_bbox, out_cls, out_count, out_keep, workspace, ws_bytes, stream))
+        return rc;
+    return om_postprocess_assemble(cfg, oriens, B, out_count, out_mask, workspace, ws_bytes, stream);
 }
 
 int om_postprocess_candidates(const om_post_cfg* cfg, const float* bbox32, const float* bbox16, const float* bbox8, int B,

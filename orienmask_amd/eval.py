@@ -267,6 +267,47 @@ class OrienMaskYOLOPostProcess:
         _lib.check(rc, "om_postprocess")
         return out_bbox, out_cls, out_mask, out_count, out_keep, (bboxes, oriens), predict     # keep the inputs alive
 
+    def launch_step(self, model, image):
+        """`self.launch(model(image))` as one sequence on the forward (tester.py:39-44's two lines): the postprocess is attached
+        to the model for this forward (om_model_attach_postprocess), whose C call then launches decode + select on the library's
+        second stream as soon as the box heads are written -- beside the rest of the forward -- and the mask kernel behind its last
+        layer.  Same kernels, same inputs, same bits; no host synchronisation (capturable).  Falls back to the two calls where
+        the fused form does not apply (a foreign nms_func, the fp16 configuration, sub-batch streams, another model class)."""
+        from .model import HEAD_PIX_STRIDE, OrienMaskYOLOFPNPlus
+        fused = (self.nms_thresh is not None and isinstance(model, OrienMaskYOLOFPNPlus) and model.precision != "f16"
+                 and model.n_streams == 1 and self.scales == 3 and image.is_cuda and image.dim() == 4
+                 and self.num_anchors == [model.num_anchors] * 3 and self.num_classes == model.num_classes
+                 and [image.shape[2] // s for s in (32, 16, 8)] == self.nHs and [image.shape[3] // s for s in (32, 16, 8)] == self.nWs
+                 and (self.image_h, self.image_w) == tuple(image.shape[2:]))
+        if not fused:
+            return self.launch(model(image))
+        L = _lib.load()
+        B, dev = image.shape[0], image.device
+        cfg = self.cfg_struct(HEAD_PIX_STRIDE)
+        ws = self._workspace(cfg, B, dev, HEAD_PIX_STRIDE)
+        out_bbox = torch.empty((B, self.nms_post, 5), dtype=torch.float32, device=dev)
+        out_cls = torch.empty((B, self.nms_post), dtype=torch.long, device=dev)
+        out_mask = torch.empty((B, self.nms_post, self.image_h, self.image_w), dtype=torch.uint8, device=dev)
+        n_status = 1
+        out_count = torch.empty((B + n_status,), dtype=torch.int32, device=dev)
+        out_keep = torch.empty((B, self.nms_post), dtype=torch.int32, device=dev)
+        h = model._ensure_handle()
+        with torch.cuda.device(dev):
+            _lib.check(L.om_model_attach_postprocess(h, ctypes.byref(cfg), ctypes.c_void_p(out_bbox.data_ptr()),
+                                                     ctypes.c_void_p(out_cls.data_ptr()), ctypes.c_void_p(out_mask.data_ptr()),
+                                                     ctypes.c_void_p(out_count.data_ptr()), ctypes.c_void_p(out_keep.data_ptr()),
+                                                     ctypes.c_void_p(ws.data_ptr()), ws.numel()), "om_model_attach_postprocess")
+            try:
+                predict = model(image)
+            finally:
+                _lib.check(L.om_model_attach_postprocess(h, None, None, None, None, None, None, None, 0), "om_model_attach_postprocess")
+        status = getattr(predict, "status", None)
+        if status is None or int(status.numel()) != n_status:
+            raise _lib.OrienMaskHipError("launch_step: the forward returned %s status words" % (None if status is None else status.numel()))
+        out_count[B:].copy_(status)
+        bboxes, _ = self._bbox_nhwc(predict)
+        return out_bbox, out_cls, out_mask, out_count, out_keep, (bboxes, self._oriens_nchw(predict)), predict
+
     def _workspace(self, cfg, B, dev, pix_stride):
         L = _lib.load()
         key = (dev, B, pix_stride)

@@ -25,11 +25,12 @@ import torch
 
 
 class GraphedPipeline:
-    def __init__(self, model, postprocess, example_input, warmup=3):
+    def __init__(self, model, postprocess, example_input, warmup=3, fuse_step=True):
         if not example_input.is_cuda:
             raise RuntimeError("GraphedPipeline needs a CUDA example input (no CPU fallback)")
         self.model = model.eval()
         self.post = postprocess
+        self.fuse_step = fuse_step        # False: model(x) then postprocess.launch on one stream (A/B of eval.launch_step)
         self.static_in = example_input.detach().clone().contiguous()
         dev = self.static_in.device
         side = torch.cuda.Stream(device=dev)
@@ -57,8 +58,9 @@ class GraphedPipeline:
                                "GraphedPipeline (the captured kernels read the packed blobs that were bound at capture time)")
 
     def _launch(self):
-        pred = self.model(self.static_in)
-        self._outs = self.post.launch(pred)               # kernels only: no host synchronisation
+        # kernels only, no host synchronisation; decode + select beside the orientation branch (eval.launch_step)
+        step = getattr(self.post, "launch_step", None) if self.fuse_step else None
+        self._outs = step(self.model, self.static_in) if step is not None else self.post.launch(self.model(self.static_in))
 
     def __call__(self, image):
         if image.shape != self.static_in.shape:

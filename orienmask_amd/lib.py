@@ -69,6 +69,7 @@ SIGNATURES = {
     "om_model_get_precision": (_i, [_vp]),
     "om_model_set_latency_cells": (_i, [_vp, ctypes.c_longlong]),
     "om_model_set_latency_ksplit": (_i, [_vp, _i]),
+    "om_model_attach_postprocess": (_i, [_vp, ctypes.POINTER(PostCfg), _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t]),
     "om_model_set_upsample_on_read": (_i, [_vp, _i]),
     "om_conv2d_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "om_conv2d_split_k": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -109,6 +110,8 @@ SIGNATURES = {
     "om_pad_nchw": (_i, [_vp, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "om_postprocess_workspace_bytes": (_sz, [ctypes.POINTER(PostCfg), _i]),
     "om_postprocess": (_i, [ctypes.POINTER(PostCfg), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "om_postprocess_detect": (_i, [ctypes.POINTER(PostCfg), _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "om_postprocess_assemble": (_i, [ctypes.POINTER(PostCfg), _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "om_postprocess_candidates": (_i, [ctypes.POINTER(PostCfg), _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "om_postprocess_masks": (_i, [ctypes.POINTER(PostCfg), _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "om_recover_bbox": (_i, [_vp, _i, _i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _i, _i, _i, _i,

@@ -30,11 +30,14 @@ from . import lib as _lib
 
 
 class InFlightPipeline:
-    def __init__(self, model, postprocess, depth=2):
+    def __init__(self, model, postprocess, depth=2, fuse_step=True):
         if int(depth) < 1:
             raise ValueError("depth must be >= 1")
         self.model = model.eval()
         self.depth = int(depth)
+        # True: eval.launch_step -- the forward's C call launches decode + select on a second stream as soon as the box heads are
+        # written (same bits); False: model(x), then postprocess.launch, on the slot's stream
+        self.fuse_step = bool(fuse_step) and hasattr(postprocess, "launch_step")
         # PRIVATE resources per batch in flight: forward workspace slots 1..depth (slot 0 stays the eager model(x) path's, which
         # runs on the caller's stream: sharing it would race with a pending batch on a side stream) and one copy of the
         # postprocess per slot -- same configuration, own workspace cache
@@ -65,7 +68,8 @@ class InFlightPipeline:
         s = streams[slot]
         s.wait_stream(torch.cuda.current_stream(dev))          # the image was produced on the caller's stream
         with torch.cuda.stream(s), torch.no_grad(), self.model.workspace_slot(slot + 1):
-            outs = self._posts[slot].launch(self.model(image))
+            outs = (self._posts[slot].launch_step(self.model, image) if self.fuse_step
+                    else self._posts[slot].launch(self.model(image)))
             done = torch.cuda.Event()
             done.record(s)
         image.record_stream(s)

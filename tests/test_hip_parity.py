@@ -1847,6 +1847,54 @@ def test_postprocess_and_forward_are_stable_beside_other_streams(dev, prec, othe
                 assert torch.equal(ga, wa) and torch.equal(gb, wb), it
 
 
+@pytest.mark.parametrize("prec,latency,B", [("f32_split", True, 1), ("f32_split", False, 3), ("f32", False, 2), ("f32_split", True, 2)])
+def test_launch_step_same_bits_as_two_calls(dev, prec, latency, B):
+    """eval.launch_step / om_model_attach_postprocess: the postprocess attached to the forward -- decode + select on the library's
+    second stream as soon as the box heads are launched, the mask kernel behind the last layer -- against postprocess(model(x)):
+    every output bit for bit, eagerly back to back without a synchronisation in between (the next forward must not run into the
+    previous step's second stream: the join), with the attachment gone afterwards, and through a captured hipGraph."""
+    from orienmask_amd.graph import GraphedPipeline
+    sd = synth.synth_state_dict(3, obj_bias=-16.0, head_gain=4.0)
+    net = _hip_model(sd, dev, prec)
+    if latency:
+        net.set_latency_mode(True)
+    post = _hip_post((544, 544), dev)
+    xs = [synth.synth_image_batch(930 + i, B, 544, 544).to(dev) for i in range(2)]
+
+    def same(got, want, tag):
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert torch.equal(g["bbox"], w["bbox"]) and torch.equal(g["cls"], w["cls"]) and torch.equal(g["mask"], w["mask"]), tag
+
+    with torch.no_grad():
+        want, want_keep, want_heads = [], [], []
+        for x in xs:
+            out = net(x)
+            want_heads.append([(a.clone(), b.clone()) for a, b in out])
+            want.append([{k: v.clone() for k, v in d.items()} for d in post(out)])
+            want_keep.append([k.clone() for k in post.last_keep])
+        assert sum(len(d["cls"]) for d in want[0]) > 0
+        for rep in range(3):
+            outs = [post.launch_step(net, xs[k & 1]) for k in range(4)]      # back to back, nothing synchronises in between
+            for k, o in enumerate(outs):
+                same(post.collect(o), want[k & 1], (rep, k))
+                for a, b in zip(post.last_keep, want_keep[k & 1]):
+                    assert torch.equal(a, b)
+                for (ga, gb), (wa, wb) in zip(o[6], want_heads[k & 1]):      # the forward's own outputs
+                    assert torch.equal(ga, wa) and torch.equal(gb, wb)
+        # detached again: a plain forward launches no postprocess (the attached buffers are untouched by it)
+        o = post.launch_step(net, xs[0])
+        torch.cuda.synchronize()
+        before = o[0].clone()
+        o[0].fill_(-7.0)
+        net(xs[1])
+        torch.cuda.synchronize()
+        assert bool((o[0] == -7.0).all()) and before.numel() > 0
+        gp = GraphedPipeline(net, post, xs[0])
+        for k in range(5):
+            same(gp(xs[k & 1]), want[k & 1], ("graph", k))
+
+
 @pytest.mark.parametrize("other", ["f32_split", "f16"])
 def test_latency_mode_split_k_is_stable_beside_other_streams(dev, other):
     """The split-K parts of the latency mode hand their accumulators to the last arrival through memory WITHOUT fences

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--bs", type=int, nargs="+", default=[1])
     ap.add_argument("--ksplit", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--fuse", type=int, nargs="+", default=[1], help="1: eval.launch_step (decode + select beside the orientation branch), 0: two calls on one stream")
     ap.add_argument("--cells", type=int, default=None, help="the switch of the latency mode in 1/32-scale cells per batch (default: the model's)")
     ap.add_argument("--layers", action="store_true", help="per-layer kernel times of the last setting (HIP events, eager)")
     args = ap.parse_args()
@@ -49,11 +50,12 @@ def main():
             print("bs=%d default                 %.3f ms" % (bsz, time_loop(lambda i: gp(xs[i & 1]), args.iters)), flush=True)
             del gp
             for ks in args.ksplit:
-                net.set_latency_mode(True, cells=args.cells, ksplit=ks)
-                gp = GraphedPipeline(net, post, xs[0])
-                ms = [time_loop(lambda i: gp(xs[i & 1]), args.iters) for _ in range(3)]
-                print("bs=%d latency mode, ksplit %d   %s ms" % (bsz, ks, " ".join("%.3f" % m for m in ms)), flush=True)
-                del gp
+                for br in args.fuse:
+                    net.set_latency_mode(True, cells=args.cells, ksplit=ks)
+                    gp = GraphedPipeline(net, post, xs[0], fuse_step=bool(br))
+                    ms = [time_loop(lambda i: gp(xs[i & 1]), args.iters) for _ in range(3)]
+                    print("bs=%d latency mode, ksplit %d fused step %d   %s ms" % (bsz, ks, br, " ".join("%.3f" % m for m in ms)), flush=True)
+                    del gp
             if args.layers:      # per-layer table of this batch size in latency mode (bench.py's events), to stderr of that run
                 import subprocess
                 subprocess.call([sys.executable, "bench.py", "--batch", str(bsz), "--steps", "10", "--warmup", "3", "--latency-mode",
