@@ -340,8 +340,9 @@ int om_pad_nchw(const float* in, long long planes, int h, int w, int pad_top, in
 size_t om_postprocess_workspace_bytes(const om_post_cfg* cfg, int B);
 /* Limits of the fused path (the reference has none): nms_pre <= 1024; 1..3 scales of 1..3 anchors; conf_thresh >= 0 (the
  * decode skips a candidate whose sigmoid(objectness) is not above it before reading its class logits); num_classes such that
- * (2047 / C + 2) * max(C & ~31, C & 31) + 63 <= 2560 -- every C <= 251, e.g. not LVIS's 1203 -- because a decode thread's visits
- * per sweep are unrolled (DEC_VISITS in csrc/post.hip); larger class counts return OM_EINVAL with that message.
+ * (2047 / C + 2) * max(C & ~31, C & 31) + 63 <= 6144 -- every C < 2048 (a decode thread's visits per sweep are unrolled: 10 of
+ * them cover C <= 251, a second instantiation with 24 the rest, e.g. LVIS's 1203; csrc/post.hip DEC_VISITS / DEC_VISITS_MANY);
+ * larger class counts return OM_EINVAL with that message.
  * out_bbox [B,nms_post,5] (cx,cy,w,h normalised, score); out_cls [B,nms_post] int64;
  * out_mask [B,nms_post,image_h,image_w] uint8 0/1 (rows >= out_count[b] are left untouched);
  * out_count [B] int32; out_keep [B,nms_post] int32 position of each detection in the

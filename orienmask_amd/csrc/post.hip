@@ -44,6 +44,7 @@ constexpr int SEL_LDS_MASK_N = 512;     // up to this many candidates the suppre
 constexpr int L1_BINS = 2048;           // key >> 19
 constexpr int MASK_PX = 16;             // pixels per thread in the mask kernel
 constexpr int DEC_VISITS = 10;          // visits per thread and sweep of the decode kernel: (DEC_TILE / C + 2) * max(CV, CS) <= 2560 for C <= 251
+constexpr int DEC_VISITS_MANY = 24;     // ... and of its instantiation for larger class counts (every C < 2048: LVIS's 1203 takes 15)
 constexpr int SEL_LIST_MAX = 4096;      // passing pairs per image the compacted list holds (= the u64 words of the LDS bit-matrix)
 
 struct PostParams {
@@ -74,6 +75,7 @@ struct PostParams {
     int64_t* cand_cls;     // [B][nms_pre]
     int32_t* cand_field;   // [B][nms_pre] anchor field of the candidate
     int mask_chunk;        // post_mask_kernel: detections of a field per workgroup (launch_post_mask)
+    int dec_visits;        // which post_decode_kernel instantiation runs (fill_params)
 };
 
 // candidate index -> (scale, anchor slot, pixel)
@@ -133,6 +135,7 @@ __device__ __forceinline__ unsigned lt_u64_bit(unsigned long long a, unsigned lo
 // ------------------------------------------------------------------------------------------------
 // decode: postprocess.py:126-139 (confidence part) and :102 (threshold)
 // ------------------------------------------------------------------------------------------------
+template <int VISITS>
 __global__ __launch_bounds__(256) void post_decode_kernel(const PostParams p) {
     __shared__ unsigned hist[L1_BINS];
     __shared__ int wcnt[4];
@@ -240,16 +243,16 @@ __global__ __launch_bounds__(256) void post_decode_kernel(const PostParams p) {
     // both kinds and execute both functions; the tile's pairs are therefore visited in two sweeps, the vectorised classes of
     // its candidates (whole waves: CV is a multiple of 32, the sweep is padded to one of 64) and then the scalar tails.  One
     // division per thread and sweep; the next visit is 256 items further: + (256 / n, 256 % n) with a carry.
-    // A sweep has at most DEC_VISITS visits per thread (n_c <= DEC_TILE / C + 2 candidates: the host checks the bound).
+    // A sweep has at most VISITS (DEC_VISITS, or DEC_VISITS_MANY for class counts beyond 251) visits per thread (n_c <= DEC_TILE / C + 2 candidates: the host checks the bound).
     const int CV = C & ~31, CS = C - CV;
-    float xv[DEC_VISITS], xs[DEC_VISITS];
+    float xv[VISITS], xs[VISITS];
     // (plain unrolled loops with compile-time indices: the arrays must stay in registers)
 #define OM_DEC_STEP(n_per) { cand_l += dq; cls += dr; if (cls >= (n_per)) { cls -= (n_per); ++cand_l; } }
 #define OM_DEC_FETCH(n_per, cls0, x)                                                              \
     if ((n_per) != 0) {                                                                           \
         const int n = ncand_t * (n_per), dq = 256 / (n_per), dr = 256 - dq * (n_per);             \
         int cand_l = tid / (n_per), cls = tid - cand_l * (n_per);                                 \
-        _Pragma("unroll") for (int v = 0; v < DEC_VISITS; ++v) {                                  \
+        _Pragma("unroll") for (int v = 0; v < VISITS; ++v) {                                  \
             x[v] = fetch(cand_l, (cls0) + cls, tid + 256 * v < n);                                \
             OM_DEC_STEP(n_per)                                                                    \
         }                                                                                         \
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256) void post_decode_kernel(const PostParams p) {
     if ((n_per) != 0) {                                                                           \
         const int n = ncand_t * (n_per), n_pad = (n + 63) & ~63, dq = 256 / (n_per), dr = 256 - dq * (n_per); \
         int cand_l = tid / (n_per), cls = tid - cand_l * (n_per);                                 \
-        _Pragma("unroll") for (int v = 0; v < DEC_VISITS; ++v) {                                  \
+        _Pragma("unroll") for (int v = 0; v < VISITS; ++v) {                                  \
             if (tid + 256 * v < n_pad) finish(cand_l, (cls0) + cls, tid + 256 * v < n, x[v], vector_path);   /* wave-uniform */ \
             OM_DEC_STEP(n_per)                                                                    \
         }                                                                                         \
@@ -1165,8 +1168,10 @@ static int fill_params(const om_post_cfg* cfg, PostParams& p) {
     p.ntiles = (p.npairs + DEC_TILE - 1) / DEC_TILE;
     {      // post_decode_kernel: a sweep visits (candidates of a tile) x (vectorised or scalar classes) items, DEC_VISITS per thread
         const int C = cfg->num_classes, CV = C & ~31, CS = C - CV;
-        OM_REQUIRE(((DEC_TILE - 1) / C + 2) * (CV > CS ? CV : CS) + 63 <= 256 * DEC_VISITS, OM_EINVAL,
-                   "postprocess: num_classes=%d needs more than %d visits per decode thread", C, DEC_VISITS);
+        const int items = ((DEC_TILE - 1) / C + 2) * (CV > CS ? CV : CS) + 63;
+        OM_REQUIRE(items <= 256 * DEC_VISITS_MANY, OM_EINVAL, "postprocess: num_classes=%d needs more than %d visits per decode thread", C,
+                   DEC_VISITS_MANY);
+        p.dec_visits = items <= 256 * DEC_VISITS ? DEC_VISITS : DEC_VISITS_MANY;
     }
     return OM_OK;
 }
@@ -1185,6 +1190,11 @@ static PostWs post_ws_layout(const PostParams& p, int B) {
     if (p.cfg.nms_pre > SEL_LDS_MASK_N) off += align_up((size_t)B * SEL_MAXN * (SEL_MAXN / 64) * sizeof(unsigned long long), 256);
     w.total = off;
     return w;
+}
+
+static void launch_post_decode(const PostParams& p, int B, hipStream_t stream) {
+    if (p.dec_visits == DEC_VISITS) hipLaunchKernelGGL(post_decode_kernel<DEC_VISITS>, dim3(p.ntiles, B), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(post_decode_kernel<DEC_VISITS_MANY>, dim3(p.ntiles, B), dim3(256), 0, stream, p);
 }
 
 }  // namespace om
@@ -1253,7 +1263,7 @@ int om_postprocess_detect(const om_post_cfg* cfg, const float* bbox32, const flo
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     p.out_bbox = out_bbox; p.out_cls = out_cls; p.out_count = out_count; p.out_keep = out_keep;
     if (int rc = om::launch_zero_words(p.hist1, (size_t)B * om::L1_BINS + B, stream)) return rc;
-    hipLaunchKernelGGL(om::post_decode_kernel, dim3(p.ntiles, B), dim3(256), 0, stream, p);
+    om::launch_post_decode(p, B, stream);
     OM_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(om::post_select_kernel, dim3(B), dim3(om::SEL_THREADS), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
@@ -1291,7 +1301,7 @@ int om_postprocess_candidates(const om_post_cfg* cfg, const float* bbox32, const
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     p.cand_dets = cand_dets; p.cand_cls = cand_cls; p.cand_field = cand_field; p.out_count = cand_count;
     if (int rc = om::launch_zero_words(p.hist1, (size_t)B * om::L1_BINS + B, stream)) return rc;
-    hipLaunchKernelGGL(om::post_decode_kernel, dim3(p.ntiles, B), dim3(256), 0, stream, p);
+    om::launch_post_decode(p, B, stream);
     OM_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(om::post_select_kernel, dim3(B), dim3(om::SEL_THREADS), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
@@ -1315,7 +1325,7 @@ int om_postprocess_masks(const om_post_cfg* cfg, const float* oriens, int B, con
 int om_post_kernel_occupancy(int which, int* threads, int* vgprs, int* lds_bytes, int* max_blocks_per_cu) {
     OM_REQUIRE(threads && vgprs && lds_bytes && max_blocks_per_cu, OM_EINVAL, "om_post_kernel_occupancy: null argument");
     OM_REQUIRE(which >= 0 && which <= 2, OM_EINVAL, "om_post_kernel_occupancy: which=%d (0 decode, 1 select, 2 mask)", which);
-    const void* fn = which == 0 ? reinterpret_cast<const void*>(om::post_decode_kernel)
+    const void* fn = which == 0 ? reinterpret_cast<const void*>(om::post_decode_kernel<om::DEC_VISITS>)
                    : which == 1 ? reinterpret_cast<const void*>(om::post_select_kernel)
                                 : reinterpret_cast<const void*>(om::post_mask_kernel);
     const int nthreads = which == 1 ? om::SEL_THREADS : 256;

@@ -2245,6 +2245,34 @@ def test_postprocess_other_scale_and_anchor_counts(dev, masks, slices, regime):
             _check_detections(r, w["bbox"].numpy(), w["cls"].numpy(), w["mask"].numpy(), (masks, layout, b), exact_decode=True)
 
 
+@pytest.mark.parametrize("C,regime", [(1, "mixed"), (20, "sparse_many"), (251, "mixed"), (252, "mixed"), (300, "dense"), (1203, "mixed"),
+                                      (2047, "sparse")])
+def test_postprocess_class_counts(dev, C, regime):
+    """The reference takes any num_classes (postprocess.py:13-36).  The decode kernel unrolls a thread's visits per sweep: ten
+    cover C <= 251 (the COCO configuration's 80 among them), a second instantiation the counts up to 2047 (LVIS: 1203); both
+    against the oracle -- indices, classes and keep exact, boxes and masks as for the standard configuration -- and one class more
+    than the library holds is refused loudly."""
+    from orienmask_amd.eval import OrienMaskYOLOPostProcess
+    size = (96, 128)
+    pc = post_cfg(size)
+    heads = synth.synth_heads(300 + C, 2, pc["grid_size"], num_classes=C, regime=regime)
+    oracle = R.PostProcessOracle(pc["grid_size"], pc["image_size"], pc["anchors"], pc["anchor_mask"], C, conf_thresh=pc["conf_thresh"])
+    want = oracle(heads)
+    post = OrienMaskYOLOPostProcess(pc["grid_size"], pc["image_size"], pc["anchors"], pc["anchor_mask"], C,
+                                    conf_thresh=pc["conf_thresh"], device=dev)
+    got = post(tuple((b.to(dev), o.to(dev)) for b, o in heads))
+    assert sum(len(w["cls"]) for w in want) > 0
+    for b, (r, w) in enumerate(zip(got, want)):
+        assert torch.equal(r["cls"].cpu(), w["cls"]) and torch.equal(post.last_keep[b].cpu().long(), w["keep"]), (C, b)
+        _check_detections(r, w["bbox"].numpy(), w["cls"].numpy(), w["mask"].numpy(), (C, b), exact_decode=True)
+    if C == 2047:
+        too_many = OrienMaskYOLOPostProcess(pc["grid_size"], pc["image_size"], pc["anchors"], pc["anchor_mask"], 4100,
+                                            conf_thresh=pc["conf_thresh"], device=dev)
+        big = synth.synth_heads(1, 1, pc["grid_size"], num_classes=4100, regime="sparse")
+        with pytest.raises(omlib.OrienMaskHipError, match="num_classes"):
+            too_many(tuple((b.to(dev), o.to(dev)) for b, o in big))
+
+
 @pytest.mark.parametrize("fname", ["post_p544_ties_iou_b1.npz", "post_p544_ties_cut_b2.npz", "post_p544_ties_thresh_b2.npz",
                                    "post_p544_dense_b1.npz"])
 def test_near_tie_fixtures_beside_fp16_matrix_neighbour(dev, fname):
