@@ -246,9 +246,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the preprocess / COCO-format side measurements")
     ap.add_argument("--latency-mode", action="store_true",
                     help="f32_split: model.set_latency_mode(True) for the whole run (direct 3x3 convolutions below ~4 images per batch)")
-    ap.add_argument("--no-fuse-step", action="store_true",
-                    help="A/B: the pipelines call model(x) and postprocess.launch one after the other on one stream instead of "
-                         "eval.launch_step (decode + select on a second stream beside the orientation branch; same bits)")
+    ap.add_argument("--fuse-step", action="store_true",
+                    help="A/B: the in-flight pipeline behind `value` goes through eval.launch_step (decode + select on a second stream "
+                         "beside the orientation branch; same bits) instead of model(x) + postprocess.launch on one stream per batch; "
+                         "the graph replays of `small_batches` always do")
     ap.add_argument("--latency-ksplit", type=int, default=None,
                     help="with --latency-mode: most parts a small launch's k loop is cut into (om_model_set_latency_ksplit; default: the library's)")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the bs = 1 / bs = 8 latency figures (`small_batches`)")
@@ -424,7 +425,7 @@ def main():
     if args.in_flight > 1:
         import itertools
         from orienmask_amd.pipeline import InFlightPipeline
-        pipe = InFlightPipeline(net, post, depth=args.in_flight, fuse_step=not args.no_fuse_step)
+        pipe = InFlightPipeline(net, post, depth=args.in_flight, fuse_step=args.fuse_step)
         for dets in pipe.map(batches(2 * args.in_flight)):                 # allocates the per-slot workspaces, untimed
             pass
         if use_dist:

@@ -30,13 +30,20 @@ from . import lib as _lib
 
 
 class InFlightPipeline:
-    def __init__(self, model, postprocess, depth=2, fuse_step=True):
+    def __init__(self, model, postprocess, depth=2, fuse_step=None):
         if int(depth) < 1:
             raise ValueError("depth must be >= 1")
         self.model = model.eval()
         self.depth = int(depth)
         # True: eval.launch_step -- the forward's C call launches decode + select on a second stream as soon as the box heads are
         # written (same bits); False: model(x), then postprocess.launch, on the slot's stream
+        # Default (None): off.  Batches in flight on several streams already overlap one batch's select kernel with another's
+        # convolutions, every fused batch drives TWO streams (the runtime maps streams onto four hardware queues) and pays two
+        # event operations per step on the host: measured eagerly, same box, 32 x 544^2 two in flight 2134 / 2098 (off) against
+        # 2110 / 2123 (on), three in flight 2133 against 2065, four single images in flight 569-737 against 486-496
+        # (tools/inflight_ab.py).  The form pays where ONE stream replays a captured graph: graph.GraphedPipeline.
+        if fuse_step is None:
+            fuse_step = False
         self.fuse_step = bool(fuse_step) and hasattr(postprocess, "launch_step")
         # PRIVATE resources per batch in flight: forward workspace slots 1..depth (slot 0 stays the eager model(x) path's, which
         # runs on the caller's stream: sharing it would race with a pending batch on a side stream) and one copy of the
