@@ -17,10 +17,14 @@ def main():
     ap.add_argument("--bs", type=int, nargs="+", default=[1])
     ap.add_argument("--ksplit", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--lib", default=None, help="another build of the library (ab/NAME.so)")
     ap.add_argument("--fuse", type=int, nargs="+", default=[1], help="1: eval.launch_step (decode + select beside the orientation branch), 0: two calls on one stream")
     ap.add_argument("--cells", type=int, default=None, help="the switch of the latency mode in 1/32-scale cells per batch (default: the model's)")
     ap.add_argument("--layers", action="store_true", help="per-layer kernel times of the last setting (HIP events, eager)")
     args = ap.parse_args()
+    if args.lib:
+        from orienmask_amd import lib as _omlib
+        _omlib.LIB_PATH = os.path.abspath(args.lib)
     import bench
     from orienmask_amd import synth
     from orienmask_amd.eval import OrienMaskYOLOPostProcess
