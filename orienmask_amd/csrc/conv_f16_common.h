@@ -26,6 +26,13 @@ struct IgemmHParams {
     int vec_io;
     int total_in_pixels;
     int w_bytes;
+    // gathered input of a 1x1 layer (conv_igemm_f16_kernel<..., GATHER>; as conv_igemm_split.hip's): the cin channels are the
+    // concatenation of nseg tensors, segment g holding the 32-channel chunks [seg_end[g-1], seg_end[g]) and stored at
+    // 1 / 2^seg_shift[g] of this layer's resolution -- the nearest-neighbour up-sampling of the reference's routes and skips
+    // (orienmask_yolo_fpnplus.py:78-86) happens in the operand addresses instead of in replicated stores
+    int nseg, nimg;
+    const _Float16* seg_ptr[4];
+    int seg_stride[4], seg_shift[4], seg_end[4];      // pixel stride in halfs
 };
 
 // Epilogue of a finished BM x BN tile whose accumulators are in the transposed 32x32 MFMA layout

@@ -42,7 +42,10 @@ namespace om {
 template <int BM, int BN>
 constexpr int f16_blocks_per_cu() { return BM * BN >= 256 * 128 ? 2 : (BM * BN >= 128 * 128 ? 3 : 4); }
 
-template <int BM, int BN, int WM, int WN, int FAST = 0>
+// GATHER: the A rows come from up to four tensors at their own resolutions (IgemmHParams::nseg; 1x1 layers only): the row offsets
+// are recomputed when the k loop crosses into the next segment, everything else is the same instruction stream and the products
+// are summed in the same order as over the materialised concat (bit-identical; the port of conv_igemm_split.hip's form).
+template <int BM, int BN, int WM, int WN, int FAST = 0, bool GATHER = false>
 __global__ __launch_bounds__(256, (f16_blocks_per_cu<BM, BN>())) void conv_igemm_f16_kernel(const IgemmHParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NWN = BN / WN;
@@ -82,6 +85,7 @@ __global__ __launch_bounds__(256, (f16_blocks_per_cu<BM, BN>())) void conv_igemm
         // relative to the tile's first image, and a mask whose bit t says "tap t of this row is padding / beyond M".
         int rowoff[A_CH];
         unsigned invmask[A_CH];
+        [[maybe_unused]] int g_img[A_CH], g_y[A_CH], g_x[A_CH];      // GATHER: the row's pixel, for the segments' own resolutions
         const int b_first = (m0 < p.M ? m0 : p.M - 1) / p.HoWo;
 #pragma unroll
         for (int j = 0; j < A_CH; ++j) {
@@ -94,6 +98,7 @@ __global__ __launch_bounds__(256, (f16_blocks_per_cu<BM, BN>())) void conv_igemm
             const int ox = rr - oy * p.Wo;
             const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
             rowoff[j] = (((b - b_first) * p.H * p.W + iy0 * p.W + ix0) * p.in_pix_stride + scol * 8) * 2;
+            if constexpr (GATHER) { g_img[j] = b - b_first; g_y[j] = oy; g_x[j] = ox; }
             unsigned badrow = 0, badcol = 0;        // bit k: input row iy0 + k / column ix0 + k is outside the image
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -114,7 +119,23 @@ __global__ __launch_bounds__(256, (f16_blocks_per_cu<BM, BN>())) void conv_igemm
         for (int j = 0; j < B_CH; ++j) rowoffB[j] = ((n0 + lrow + 64 * j) * row_halfs + scol * 8) * 2;
         const _Float16* in_base = p.in + (size_t)b_first * p.H * p.W * p.in_pix_stride;
         const size_t in_left = ((size_t)p.total_in_pixels - (size_t)b_first * p.H * p.W) * p.in_pix_stride * 2;
-        const int in_bytes = in_left < 0x7FFFFFFFull ? (int)in_left : 0x7FFFFFFF;
+        int in_bytes = in_left < 0x7FFFFFFFull ? (int)in_left : 0x7FFFFFFF;
+        [[maybe_unused]] int seg = 0, seg_c0 = 0, seg_c1 = 0x7FFFFFFF;      // GATHER: current segment, its 32-channel chunk range
+        [[maybe_unused]] auto set_segment = [&](int g) {
+            // (selects, not p.seg_x[g]: a run-time index into the by-value parameter block would copy the arrays to scratch)
+            auto pick = [g](const auto (&v)[4]) { return g == 0 ? v[0] : g == 1 ? v[1] : g == 2 ? v[2] : v[3]; };
+            const int sh = pick(p.seg_shift), Hs = p.Ho >> sh, Ws = p.Wo >> sh, st = pick(p.seg_stride);
+            in_base = pick(p.seg_ptr) + (size_t)b_first * Hs * Ws * st;
+            const size_t left = (size_t)(p.nimg - b_first) * Hs * Ws * st * 2;
+            in_bytes = left < 0x7FFFFFFFull ? (int)left : 0x7FFFFFFF;
+#pragma unroll
+            for (int j = 0; j < A_CH; ++j)
+                rowoff[j] = (((g_img[j] * Hs + (g_y[j] >> sh)) * Ws + (g_x[j] >> sh)) * st + scol * 8) * 2;
+            seg = g;
+            seg_c0 = g == 0 ? 0 : g == 1 ? p.seg_end[0] : g == 2 ? p.seg_end[1] : p.seg_end[2];
+            seg_c1 = pick(p.seg_end);
+        };
+        if constexpr (GATHER) set_segment(0);
 
         int n_kh = 0, n_kw = 0, n_cc = 0;          // step being fetched: (tap row, tap col, 32-channel chunk)
         auto advance = [&]() {
@@ -129,9 +150,13 @@ __global__ __launch_bounds__(256, (f16_blocks_per_cu<BM, BN>())) void conv_igemm
             f32x4* dst = smem + buf * STAGE + wave_u * 64;
             if (piece < A_CH) {
                 const int j = piece;
+                if constexpr (GATHER) {
+                    if (piece == 0 && live && n_cc >= seg_c1) set_segment(seg + 1);      // uniform; the steps walk the channels in order
+                }
                 const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(in_base), 0, live ? in_bytes : 0, 0x00020000);
                 const int tap = n_kh * p.ks + n_kw;
-                const int tap_off = ((n_kh * p.W + n_kw) * p.in_pix_stride + n_cc * 32) * 2;      // scalar
+                const int tap_off = GATHER ? (n_cc - seg_c0) * 64      // 1x1: one tap; the chunk within its segment
+                                           : ((n_kh * p.W + n_kw) * p.in_pix_stride + n_cc * 32) * 2;      // scalar
                 const int voff = (rowoff[j] + tap_off) | ((invmask[j] << (31 - tap)) & 0x80000000u);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(dst + j * 256), 16, voff, 0, 0, 0);
             } else {
@@ -247,7 +272,7 @@ void conv_tile_for_f16(int M, int cout_pad, int cin, int* bm, int* bn) {
     *bm = t.bm; *bn = t.bn;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool GATHER = false>
 static int launch_tile_f16(IgemmHParams p, int cout_pad, int blocks_per_cu, hipStream_t stream) {
     const int m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = cout_pad / BN;
@@ -258,6 +283,12 @@ static int launch_tile_f16(IgemmHParams p, int cout_pad, int blocks_per_cu, hipS
     grid = total < 256ll * blocks_per_cu ? total : 256ll * blocks_per_cu;
     // the epilogue without loads in its row sweeps (f16_epilogue: FAST) wherever the layer allows it
     const bool fast = p.out_mode == 0 && !p.out_f32 && p.vec_io && p.cout == cout_pad;
+    if constexpr (GATHER) {
+        OM_REQUIRE(fast && !p.res, OM_EINVAL, "conv f16: a gathered input needs a plain fp16 NHWC output without residual");
+        hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN, 1, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+        OM_CHECK_HIP(hipGetLastError());
+        return OM_OK;
+    }
     if (fast && !p.res) hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN, 1>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     else if (fast) hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN, 2>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN, 0>), dim3((unsigned)grid), dim3(256), 0, stream, p);
@@ -266,12 +297,12 @@ static int launch_tile_f16(IgemmHParams p, int cout_pad, int blocks_per_cu, hipS
 }
 
 int launch_conv_igemm_f16(const ConvArgsH& a, hipStream_t stream) {
-    OM_REQUIRE(a.in && a.w && a.scale && a.shift && a.out, OM_EINVAL, "conv f16: null pointer");
-    if (conv3x3_f16_supported(a)) return launch_conv3x3_f16(a, stream);
+    OM_REQUIRE((a.in || a.nseg > 0) && a.w && a.scale && a.shift && a.out, OM_EINVAL, "conv f16: null pointer");
+    if (a.nseg == 0 && conv3x3_f16_supported(a)) return launch_conv3x3_f16(a, stream);
     OM_REQUIRE(a.cin % 32 == 0 && a.cin >= 32, OM_EINVAL, "conv f16: cin=%d must be a multiple of 32", a.cin);
     OM_REQUIRE(a.ks == 1 || a.ks == 3, OM_EINVAL, "conv f16: ksize=%d not supported", a.ks);
     OM_REQUIRE(a.stride == 1 || a.stride == 2, OM_EINVAL, "conv f16: stride=%d not supported", a.stride);
-    OM_REQUIRE(a.in_pix_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 &&
+    OM_REQUIRE((a.nseg > 0 || (a.in_pix_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0)) &&
                    (reinterpret_cast<uintptr_t>(a.w) & 15) == 0,
                OM_EINVAL, "conv f16: input view / weights must be 16-byte aligned");
     OM_REQUIRE(a.cout_pad % 32 == 0 && a.cout <= a.cout_pad, OM_EINVAL, "conv f16: cout_pad=%d", a.cout_pad);
@@ -300,8 +331,35 @@ int launch_conv_igemm_f16(const ConvArgsH& a, hipStream_t stream) {
                 (!a.res || (a.res_pix_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)))
                    ? 1 : 0;
     OM_REQUIRE(a.ticket, OM_EINVAL, "conv f16: the tile queue needs a zeroed ticket word");
+    p.nseg = 0; p.nimg = a.B;
+    for (int g = 0; g < 4; ++g) { p.seg_ptr[g] = p.in; p.seg_stride[g] = 0; p.seg_shift[g] = 0; p.seg_end[g] = 0x7FFFFFFF; }
     int bm, bn;
     conv_tile_for_f16(p.M, a.cout_pad, a.cin, &bm, &bn);
+    if (a.nseg > 0) {
+        // gathered input: 1x1, whole 32-channel chunks per segment, every segment's resolution a power-of-two fraction of this one
+        OM_REQUIRE(a.nseg <= 4 && a.ks == 1 && a.stride == 1 && a.cout_pad % 128 == 0, OM_EINVAL,
+                   "conv f16: a gathered input needs a 1x1 stride-1 layer with cout_pad %% 128 == 0 and at most 4 segments (nseg=%d ks=%d "
+                   "stride=%d cout_pad=%d)", a.nseg, a.ks, a.stride, a.cout_pad);
+        int end = 0;
+        for (int g = 0; g < a.nseg; ++g) {
+            const int up = a.seg_up[g];
+            int sh = 0;
+            while ((1 << sh) < up) ++sh;
+            OM_REQUIRE(a.seg_ptr[g] && up >= 1 && (1 << sh) == up && a.H % up == 0 && a.W % up == 0 && a.seg_channels[g] > 0 &&
+                           a.seg_channels[g] % 32 == 0 && a.seg_pix_stride[g] % 8 == 0 && a.seg_pix_stride[g] >= a.seg_channels[g] &&
+                           (reinterpret_cast<uintptr_t>(a.seg_ptr[g]) & 15) == 0,
+                       OM_EINVAL, "conv f16: segment %d (channels=%d pix_stride=%d up=%d) of a gathered input", g, a.seg_channels[g],
+                       a.seg_pix_stride[g], up);
+            end += a.seg_channels[g] / 32;
+            p.seg_ptr[g] = static_cast<const _Float16*>(a.seg_ptr[g]);
+            p.seg_stride[g] = a.seg_pix_stride[g]; p.seg_shift[g] = sh; p.seg_end[g] = end;
+        }
+        OM_REQUIRE(end * 32 == a.cin, OM_EINVAL, "conv f16: the segments hold %d channels, the layer reads %d", end * 32, a.cin);
+        p.nseg = a.nseg;
+        p.in = p.seg_ptr[0];
+        if (bm == 256) return launch_tile_f16<256, 128, 128, 64, true>(p, a.cout_pad, 2, stream);
+        return launch_tile_f16<128, 128, 64, 64, true>(p, a.cout_pad, 3, stream);
+    }
     if (bm == 256 && bn == 128) return launch_tile_f16<256, 128, 128, 64>(p, a.cout_pad, 2, stream);
     if (bm == 128 && bn == 128) return launch_tile_f16<128, 128, 64, 64>(p, a.cout_pad, 3, stream);
     if (bm == 128 && bn == 64) return launch_tile_f16<128, 64, 64, 32>(p, a.cout_pad, 4, stream);

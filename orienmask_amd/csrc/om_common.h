@@ -95,6 +95,10 @@ struct ConvArgsH {
     int out_mode;           // 0: NHWC   1: NHWC replicated up x up (fp16 only)   2: NCHW contiguous (fp32 only)
     int up;
     int out_f32;            // 1: the output tensor is fp32 (the four head convolutions)
+    // gathered input (conv_igemm_f16.hip, 1x1 layers; as ConvArgs'): nseg = 0: the plain view `in`
+    int nseg = 0;
+    const void* seg_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+    int seg_channels[4] = {0, 0, 0, 0}, seg_pix_stride[4] = {0, 0, 0, 0}, seg_up[4] = {1, 1, 1, 1};
 };
 int launch_conv_igemm_f16(const ConvArgsH& a, hipStream_t stream);     // dispatches stride-1 3x3 layers to conv3x3_f16.hip
 int launch_conv3x3_f16(const ConvArgsH& a, hipStream_t stream);

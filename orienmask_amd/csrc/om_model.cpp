@@ -283,7 +283,7 @@ struct om_model {
     }
     // split operands, fp32 tensors, activations not kept for om_layer_output_view (which reports a slice of the concat buffer)
     bool upsample_on_read = true;      // om_model_set_upsample_on_read
-    bool gather_active(bool f16) const { return !f16 && precision == 1 && !keep_all && upsample_on_read; }
+    bool gather_active(bool f16) const { return (f16 || precision == 1) && !keep_all && upsample_on_read; }
 
     // F(2x4,3x3) needs enough tiles to fill the chip: measured at 544^2, bs=4 is 4 % faster with F(2x2) and bs=8 is 4 % faster
     // with F(2x4); the switch is on the number of 1/32-scale cells in the batch (289 per 544^2 image).
@@ -663,6 +663,20 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             a.out_mode = L.out_mode; a.up = L.up;
             a.out_f32 = L.out.buf < 0 ? 1 : 0;
             a.ticket = tickets + (&L - m->layers.data()) * om::SYNC_WORDS;
+            if (m->gather_active(f16)) {      // routes / skips stored once at their own resolution, read up-sampled (as in split mode below)
+                if (L.side >= 0) {
+                    a.out = base[L.side];
+                    a.out_pix_stride = m->pix_stride(L.side); a.out_mode = 0; a.up = 1;
+                }
+                a.nseg = (int)L.gather.size();
+                for (int g = 0; g < a.nseg; ++g) {
+                    const om::LayerDef::Seg& sg = L.gather[g];
+                    const int side = sg.producer >= 0 ? m->layers[sg.producer].side : -1;
+                    a.seg_ptr[g] = side >= 0 ? static_cast<const void*>(base[side]) : ptr_of(sg.view);
+                    a.seg_pix_stride[g] = side >= 0 ? m->pix_stride(side) : m->pix_stride(sg.view.buf);
+                    a.seg_channels[g] = sg.channels; a.seg_up[g] = sg.up;
+                }
+            }
             if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
             rc = om::launch_conv_igemm_f16(a, stream);
         } else {
@@ -796,6 +810,11 @@ int om_layer_tile_f16(const om_model* m, int index, int B, int H, int W, int* bm
     }
     om::conv_tile_for_f16(B * Ho * Wo, L.info.cout_pad, L.info.cin, bm, bn);
     *algo = 1;
+    if (m->gather_active(true) && !L.gather.empty()) {      // up-sampling on read: conv_igemm_f16_kernel<..., GATHER>
+        if (!(*bm == 256 && *bn == 128)) *bm = 128;
+        *bn = 128;
+        *algo = 5;
+    }
     return OM_OK;
 }
 

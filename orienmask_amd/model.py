@@ -273,9 +273,9 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         return self
 
     def set_upsample_on_read(self, enable=True):
-        """precision 'f32_split' only: True (default) = the routes and skips store one copy at their own resolution and the 1x1 layer
-        behind each concat (neck16.0 / neck8.0 / neck4.0) reads them up-sampled; False = they store their output replicated into
-        the concat buffer (what 'f32' and 'f16' do).  Bit-identical outputs; for A/B measurements and the test of that claim.
+        """precisions 'f32_split' and 'f16': True (default) = the routes and skips store one copy at their own resolution and the 1x1
+        layer behind each concat (neck16.0 / neck8.0 / neck4.0) reads them up-sampled; False = they store their output replicated
+        into the concat buffer (what 'f32' does).  Bit-identical outputs; for A/B measurements and the test of that claim.
         Drops the cached workspaces (their layout differs)."""
         _lib.check(_lib.load().om_model_set_upsample_on_read(self._ensure_handle(), 1 if enable else 0), "om_model_set_upsample_on_read")
         self._workspace.clear()
@@ -451,7 +451,8 @@ class OrienMaskYOLOFPNPlus(nn.Module):
                 bm, bn, algo = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
                 _lib.check(_lib.load().om_layer_tile_f16(h, i, B, H, W, ctypes.byref(bm), ctypes.byref(bn),
                                                          ctypes.byref(algo)), "om_layer_tile_f16")
-                fmt = {0: "conv_stem_kernel<f16>", 1: "conv_igemm_f16_kernel<%d,%d>", 4: "conv3x3_f16_kernel<%d,%d>"}[algo.value]
+                fmt = {0: "conv_stem_kernel<f16>", 1: "conv_igemm_f16_kernel<%d,%d>", 4: "conv3x3_f16_kernel<%d,%d>",
+                       5: "conv_igemm_f16_kernel<%d,%d,gather>"}[algo.value]
                 out.append((l["name"], fmt % (bm.value, bn.value) if algo.value else fmt))
             return out
         _lib.check(_lib.load().om_model_set_precision(h, 1 if self.precision == "f32_split" else 0), "om_model_set_precision")

@@ -449,15 +449,16 @@ def test_conv_split_gather_equals_materialised_concat(dev, case):
     assert bad != 0
 
 
-def test_forward_gather_equals_replicated_concat(dev):
-    """Split-operand forward: the up-sampling-on-read form (routes and skips stored once at their own resolution, neck16.0 / neck8.0 /
+@pytest.mark.parametrize("prec", ["f32_split", "f16"])
+def test_forward_gather_equals_replicated_concat(dev, prec):
+    """Split-operand and fp16 forwards: the up-sampling-on-read form (routes and skips stored once at their own resolution, neck16.0 / neck8.0 /
     neck4.0 gathering them) against the replicated-concat form of the same library (set_upsample_on_read(False): what the other
     precisions run) -- all four heads bit-identical, bs=3 at 544x544 and a 64x96 image; keeping the activations
     (om_layer_output_view reports slices of the concat buffers) also selects the replicated form."""
     sd = synth.synth_state_dict(11, obj_bias=-16.0, head_gain=4.0)
     for shape, seed in (((3, 544, 544), 31), ((2, 64, 96), 32)):
         x = synth.synth_image_batch(seed, *shape).to(dev)
-        net = _hip_model(sd, dev).set_precision("f32_split")
+        net = _hip_model(sd, dev).set_precision(prec)
         kinds = dict(net.layer_kernels(*shape))
         assert "gather" in kinds["neck4.0"] and "gather" in kinds["neck8.0"] and "gather" in kinds["neck16.0"]
         with torch.no_grad():
