@@ -32,6 +32,9 @@ namespace om {
 #define OM_SPLIT_WIDE 1        // 128 x 128 tiles with 128-byte operand rows (conv_igemm_split_wide_kernel) where cin % 32 == 0
 #endif
 
+#if defined(OM_SPLIT_NO_XCD_PLACEMENT) && !defined(OM_MEASUREMENT_BUILD)
+#error "OM_SPLIT_NO_XCD_PLACEMENT is a measurement switch: tools/build_variant.sh only"
+#endif
 #ifndef OM_SPLIT_TRACE
 #define OM_SPLIT_TRACE 0       // measurement builds only: s_memtime stamps per tile of the wide kernel (tools/split_trace.py)
 #endif
@@ -297,6 +300,9 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
             const int b = blockIdx.x, x = b & 7;
             int unit = b >> 3;
             for (int y = 0; y < x; ++y) unit += (p.total_tickets - y + 7) >> 3;      // units of the XCDs before this one
+#ifdef OM_SPLIT_NO_XCD_PLACEMENT      // measurement build: units in launch order, i.e. round-robin over the XCDs
+            unit = b;
+#endif
             tile_m = unit % p.m_tiles;
             const int t = unit / p.m_tiles;
             tile_n = t % p.n_tiles;
