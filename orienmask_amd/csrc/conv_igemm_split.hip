@@ -522,12 +522,17 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
 // GATHER: the A rows come from up to four tensors at their own resolutions (IgemmSParams::nseg; 1x1 layers only).  The row
 // offsets are recomputed when the k loop crosses into the next segment (at most three times per tile); everything else is the
 // same instruction stream, and the products are summed in the same order as over the materialised concat (bit-identical).
-template <int BM, int BN, int WM, int WN, bool GATHER = false, bool FAST = false>
+// NBUF > 2: the DEEP-RING form of the small launches (a batch of one or a few images; conv_igemm_split_kernel's KSPLIT form with
+// whole-line rows): no tile queue -- one unit (tile x part of the k loop) per workgroup, placed XCD-contiguously --, NBUF stages of
+// two k-steps in the ring, split-K parts summed by the last arrival.  The 64-byte-row form of those launches ran its k loop at
+// ~30 B/clk/CU, the half-line request rate (tools/deep_trace.py: 545 cycles per 8 KB k-step, two workgroups per CU).
+template <int BM, int BN, int WM, int WN, bool GATHER = false, bool FAST = false, int NBUF = 2>
 __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const IgemmSParams p) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int NWN = BN / WN;
     constexpr int A_CH = BM / 32, B_CH = BN / 32, NP = A_CH + B_CH;     // 32 rows x 128 B per workgroup-wide piece
-    constexpr int NBUF = 2;
+    constexpr bool KSPLIT = NBUF > 2;
+    static_assert(!(KSPLIT && GATHER), "the deep-ring form has no gathered input");
     constexpr int STAGE = (BM + BN) * 8;            // f32x4 (16-byte) units per ring stage
     static_assert((BM / WM) * (BN / WN) == 4, "four waves per workgroup");
     static_assert(BM % 32 == 0 && BN % 32 == 0, "whole 32-row pieces");
@@ -550,19 +555,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
 
     // The tile queue's NEXT ticket is drawn while this tile's k loop runs and handed over through LDS before the epilogue (its
     // value must not be consumed behind the epilogue's stores: loads, atomics and stores retire through one in-order counter).
-    if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (;;) {
+    if constexpr (!KSPLIT) {
+        if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    for (int round = 0;; ++round) {
 #if OM_SPLIT_TRACE
         unsigned long long ts0, ts1, ts2, ts3, twait = 0, wa, wb;
         SPLIT_STAMP(ts0);
 #endif
-        int tile = *s_ticket;
-        if (tile >= p.total_tiles) break;
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        const int tile_n = tile % p.n_tiles;
-        const int tile_m = tile / p.n_tiles;
+        int tile, tile_n, tile_m;
+        [[maybe_unused]] int part = 0;
+        if constexpr (KSPLIT) {
+            if (round) break;
+            const int b = blockIdx.x, x = b & 7;      // (conv_igemm_split_kernel: XCD-contiguous units in (part, N tile, M tile) order)
+            int unit = b >> 3;
+            for (int y = 0; y < x; ++y) unit += (p.total_tickets - y + 7) >> 3;
+            tile_m = unit % p.m_tiles;
+            const int t = unit / p.m_tiles;
+            tile_n = t % p.n_tiles;
+            part = t / p.n_tiles;
+            tile = tile_m * p.n_tiles + tile_n;
+        } else {
+            tile = *s_ticket;
+            if (tile >= p.total_tiles) break;
+            tile = __builtin_amdgcn_readfirstlane(tile);
+            tile_n = tile % p.n_tiles;
+            tile_m = tile / p.n_tiles;
+        }
         const int m0 = tile_m * BM, n0 = tile_n * BN;
 
         int rowoff[A_CH];
@@ -620,8 +641,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
         if constexpr (GATHER) set_segment(0);
 
         const int kc2 = p.kc >> 1;                  // pairs of 16-channel chunks per tap
-        const int nstages = p.taps * kc2;
+        int nstages = p.taps * kc2;
         int n_kh = 0, n_kw = 0, n_cc = 0;          // stage being fetched: (tap row, tap col, 32-channel chunk)
+        if constexpr (KSPLIT) {                     // this part's stages
+            const int s_begin = part * nstages / p.ksplit;
+            nstages = (part + 1) * nstages / p.ksplit - s_begin;
+            const int tap0 = s_begin / kc2;
+            n_cc = s_begin - tap0 * kc2;
+            n_kh = tap0 / p.ks;
+            n_kw = tap0 - n_kh * p.ks;
+        }
         auto advance = [&]() {
             if (++n_cc == kc2) {
                 n_cc = 0;
@@ -690,16 +719,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
                 }
         };
 
-        // prologue: stages 0 and 1 requested; stage 0 waited for, its first k-step converted
+        // prologue: stages 0 .. NBUF - 1 requested; stage 0 waited for, its first k-step converted
 #pragma unroll
-        for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 0, true);
-        advance();
+        for (int st = 0; st < NBUF; ++st) {
 #pragma unroll
-        for (int piece = 0; piece < NP; ++piece) issue_piece(piece, 1, 1 < nstages);
-        advance();
-        int next_ticket = 0;
-        if (tid == 0) next_ticket = atomicAdd(p.ticket, 1);      // newer than stage 1's pieces: the wait below still covers stage 0
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NP) : "memory");
+            for (int piece = 0; piece < NP; ++piece) issue_piece(piece, st, st < nstages);
+            advance();
+        }
+        [[maybe_unused]] int next_ticket = 0;
+        if constexpr (!KSPLIT) {
+            if (tid == 0) next_ticket = atomicAdd(p.ticket, 1);      // newer than stage 1's pieces: the wait below still covers stage 0
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NBUF - 1) * NP) : "memory");
         __builtin_amdgcn_s_barrier();
 #if OM_SPLIT_TRACE
         SPLIT_STAMP(ts1);
@@ -711,28 +742,76 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
             read_raw(buf, 1);
             multiply();                              // k-step (s, 0)
             convert();                               // operands of (s, 1); my reads of `buf` are complete
-            // stage s + 1 (requested one stage ago) has landed; every wave is done reading `buf`: it takes stage s + 2
+            // stage s + 1 has landed (only the NBUF - 2 stages behind it may still fly); every wave is done reading `buf`: it takes
+            // stage s + NBUF
 #if OM_SPLIT_TRACE
             SPLIT_STAMP(wa);
 #endif
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"((NBUF - 2) * NP) : "memory");
             __builtin_amdgcn_s_barrier();
 #if OM_SPLIT_TRACE
             SPLIT_STAMP(wb);
             twait += wb - wa;
 #endif
-            const bool live2 = s + 2 < nstages;
+            const bool live2 = s + NBUF < nstages;
 #pragma unroll
             for (int piece = 0; piece < NP; ++piece) issue_piece(piece, buf, live2);
             advance();
-            read_raw(buf ^ 1, 0);
+            const int buf1 = buf == NBUF - 1 ? 0 : buf + 1;
+            read_raw(buf1, 0);
             multiply();                              // k-step (s, 1)
             convert();                               // operands of (s + 1, 0)
-            buf ^= 1;
+            buf = buf1;
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if (tid == 0) *s_ticket = next_ticket;      // every wave read the current ticket many barriers ago
+        if constexpr (!KSPLIT) {
+            if (tid == 0) *s_ticket = next_ticket;      // every wave read the current ticket many barriers ago
+        }
         __syncthreads();
+        if constexpr (KSPLIT) {
+            if (p.ksplit > 1) {
+                // publish / count / sum in part order: conv_igemm_split_kernel's split-K hand-off (write-through stores, drained
+                // waves, one agent-scope atomic, sc1 loads; the parts are whole STAGES here)
+                const auto rs_part = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, 0x7FFFFFFF, 0x00020000);
+                constexpr int PART_BYTES = TM * TN * 4 * 256 * 16;
+                const int pbase = (tile * p.ksplit + part) * PART_BYTES + tid * 16;
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                                                   rs_part, pbase, ((a * TN + b) * 4 + g) * 256 * 16, 16);
+                        }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) s_ticket[1] = __hip_atomic_fetch_add(p.kflags + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                if (s_ticket[1] != p.ksplit - 1) break;         // another part stores the tile
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+                for (int q = 0; q < p.ksplit; ++q) {
+                    const int qbase = (tile * p.ksplit + q) * PART_BYTES + tid * 16;
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_part, qbase, ((a * TN + b) * 4 + g) * 256 * 16, 16));
+#pragma unroll
+                                for (int kk = 0; kk < 4; ++kk) acc[a][b][4 * g + kk] += v[kk];
+                            }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
 #if OM_SPLIT_TRACE
         SPLIT_STAMP(ts2);
 #endif
@@ -749,7 +828,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool WIDE = false, bool GATHER = false, int NBUF = 3>
+// NBUF: ring stages of the 64-byte-row kernel (> 3: its deep-ring form); WSTAGES: ring stages of the whole-line kernel's deep-ring
+// form (0: the two-stage form with a tile queue)
+template <int BM, int BN, int WM, int WN, bool WIDE = false, bool GATHER = false, int NBUF = 3, int WSTAGES = 0>
 static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hipStream_t stream) {
     const int m_tiles = (p.M + BM - 1) / BM;
     p.n_tiles = cout_pad / BN;
@@ -759,8 +840,9 @@ static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hi
     // split-K (deep-ring forms; p.ksplit arrives as the caller's upper bound): as many parts as two workgroups per CU take in one
     // round, at least sixteen k-steps each (bs = 1, per layer: 1x1 layers of 16 / 32 / 64 k-steps are fastest in 1 / 2 / 4 parts, a
     // part costing ~2 us of prologue and its share of the last arrival's sum; profiles/r04_experiments.md section 9)
+    constexpr bool DEEP = WIDE ? WSTAGES > 2 : NBUF > 3;      // the small launches' forms: one unit per workgroup, split-K
     int parts = 1;
-    if constexpr (NBUF > 3) {
+    if constexpr (DEEP) {
         if (p.ksplit > 1 && p.partial && total <= SK_SLOTS) {
             parts = p.ksplit;
             if (parts > 512 / (int)total) parts = 512 / (int)total;
@@ -774,15 +856,16 @@ static int launch_tile_split(IgemmSParams p, int cout_pad, int blocks_per_cu, hi
     p.m_tiles = m_tiles;
     const long long tickets = total * parts;
     long long grid = tickets < 256ll * blocks_per_cu ? tickets : 256ll * blocks_per_cu;
-    if constexpr (NBUF > 3) {      // one unit per workgroup, no queue
+    if constexpr (DEEP) {      // one unit per workgroup, no queue
         OM_REQUIRE(tickets <= 512, OM_EINVAL, "conv split: %lld units in a deep-ring launch", tickets);
         grid = tickets;
     }
     // the epilogue without loads in its row sweeps (split_epilogue: FAST) wherever the layer allows it
     const bool fast = p.out_mode == 0 && !p.res && p.vec_io && p.cout == cout_pad;
     if constexpr (WIDE) {
-        if (fast) hipLaunchKernelGGL((conv_igemm_split_wide_kernel<BM, BN, WM, WN, GATHER, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv_igemm_split_wide_kernel<BM, BN, WM, WN, GATHER, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+        constexpr int WNBUF = DEEP ? WSTAGES : 2;
+        if (fast) hipLaunchKernelGGL((conv_igemm_split_wide_kernel<BM, BN, WM, WN, GATHER, true, WNBUF>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_igemm_split_wide_kernel<BM, BN, WM, WN, GATHER, false, WNBUF>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     } else {
         if (fast) hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, WN, true, NBUF>), dim3((unsigned)grid), dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, WN, false, NBUF>), dim3((unsigned)grid), dim3(256), 0, stream, p);
@@ -894,6 +977,13 @@ int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream) {
     // the latency form (deep ring, conv_igemm_split_kernel's NBUF) for launches that cannot fill the chip anyway
     const long long ntile = (long long)((p.M + bm - 1) / bm) * (a.cout_pad / bn);
     const bool deep = ntile <= 256 && (!a.force_bm || a.ksplit_max >= 1);      // (om_conv2d_split_k: a forced shape in its deep-ring form)
+#ifndef OM_DEEP_WIDE
+#define OM_DEEP_WIDE 1          // whole-line rows in the deep-ring forms where cin % 32 == 0
+#endif
+    if (OM_DEEP_WIDE && deep && a.cin % 32 == 0) {      // three stages of 24 KiB / four of 16 KiB: two workgroups per CU
+        if (bm == 128 && bn == 64) return launch_tile_split<128, 64, 64, 32, true, false, 3, 3>(p, a.cout_pad, 2, stream);
+        if (bm == 64 && bn == 64) return launch_tile_split<64, 64, 32, 32, true, false, 3, 4>(p, a.cout_pad, 2, stream);
+    }
     if (bm == 128 && bn == 64 && deep) return launch_tile_split<128, 64, 64, 32, false, false, 5>(p, a.cout_pad, 2, stream);
     if (bm == 64 && bn == 64 && deep) return launch_tile_split<64, 64, 32, 32, false, false, 8>(p, a.cout_pad, 2, stream);
     if (bm == 128 && bn == 64) return launch_tile_split<128, 64, 64, 32>(p, a.cout_pad, 4, stream);
