@@ -290,6 +290,14 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
     // CONTIGUOUS range of units in (part, N tile, M tile) order -- an XCD then reads about an eighth of the weights and an eighth of
     // the input's k range instead of all of both.  One 544 x 544 image's 17 x 17 layers stream 19 MB of weights: drawn from a
     // chip-wide queue every XCD pulled all of them through its 4 MiB L2 (8 x 19 MB from the Infinity Cache per layer).
+#if OM_SPLIT_TRACE
+    // deep-ring forms (tools/deep_trace.py): start, first stage landed, k loop done, arrival counted, parts summed, stored
+    unsigned long long dts[6] = {0, 0, 0, 0, 0, 0};
+    auto deep_dump = [&]() {
+        if (KSPLIT && tid == 0 && p.trace && blockIdx.x < 512)
+            for (int i = 0; i < 6; ++i) p.trace[blockIdx.x * 8 + i] = dts[i];
+    };
+#endif
     for (int round = 0;; ++round) {
         int tile;
         int s_begin = 0, nsteps = p.ksteps;      // this unit's part of the k loop
@@ -297,6 +305,9 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
         int tile_n, tile_m;
         if constexpr (KSPLIT) {
             if (round) break;
+#if OM_SPLIT_TRACE
+            SPLIT_STAMP(dts[0]);
+#endif
             const int b = blockIdx.x, x = b & 7;
             int unit = b >> 3;
             for (int y = 0; y < x; ++y) unit += (p.total_tickets - y + 7) >> 3;      // units of the XCDs before this one
@@ -427,6 +438,9 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
         }
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NBUF - 1) * NP) : "memory");
         __builtin_amdgcn_s_barrier();
+#if OM_SPLIT_TRACE
+        SPLIT_STAMP(dts[1]);
+#endif
         read_raw(0);
         convert();
         int buf = 0;
@@ -456,6 +470,9 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
 
+#if OM_SPLIT_TRACE
+        SPLIT_STAMP(dts[2]);
+#endif
         if constexpr (KSPLIT) {
             if (p.ksplit > 1) {
                 // publish this part's raw accumulators (write-through stores, as conv_wino24.hip's stream-K form), count the arrival
@@ -479,6 +496,10 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
                 // with sc1 loads, which pass this CU's L1: no acquire either.  MI355X_MICROARCH.md, inter-workgroup visibility)
                 if (tid == 0) s_ticket[1] = __hip_atomic_fetch_add(p.kflags + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __syncthreads();
+#if OM_SPLIT_TRACE
+                SPLIT_STAMP(dts[3]);
+                if (s_ticket[1] != p.ksplit - 1) deep_dump();
+#endif
                 if (s_ticket[1] != p.ksplit - 1) break;         // another part stores the tile
                 // the last arrival: every part has published; the sum runs in part order (this part's own copy included), so the
                 // result does not depend on which part came last
@@ -505,9 +526,17 @@ __global__ __launch_bounds__(256, (NBUF > 3 ? 2 : split_blocks_per_cu<BM, BN>())
             }
         }
 
+#if OM_SPLIT_TRACE
+        SPLIT_STAMP(dts[4]);
+#endif
         float sc[8], sh[8];      // (four blocks per CU: no registers to hold them across the k loop)
         if constexpr (FAST) split_scale_shift<BN>(p, n0, tid, sc, sh);
         split_epilogue<BM, BN, WM, WN, FAST>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk, sc, sh);
+#if OM_SPLIT_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SPLIT_STAMP(dts[5]);
+        deep_dump();
+#endif
     }
 }
 
@@ -560,6 +589,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+#if OM_SPLIT_TRACE
+    // deep-ring forms (tools/deep_trace.py): start, first stage landed, k loop done, arrival counted, parts summed, stored
+    unsigned long long dts[6] = {0, 0, 0, 0, 0, 0};
+    auto deep_dump = [&]() {
+        if (KSPLIT && tid == 0 && p.trace && blockIdx.x < 512)
+            for (int i = 0; i < 6; ++i) p.trace[blockIdx.x * 8 + i] = dts[i];
+    };
+#endif
     for (int round = 0;; ++round) {
 #if OM_SPLIT_TRACE
         unsigned long long ts0, ts1, ts2, ts3, twait = 0, wa, wb;
@@ -569,6 +606,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
         [[maybe_unused]] int part = 0;
         if constexpr (KSPLIT) {
             if (round) break;
+#if OM_SPLIT_TRACE
+            SPLIT_STAMP(dts[0]);
+#endif
             const int b = blockIdx.x, x = b & 7;      // (conv_igemm_split_kernel: XCD-contiguous units in (part, N tile, M tile) order)
             int unit = b >> 3;
             for (int y = 0; y < x; ++y) unit += (p.total_tickets - y + 7) >> 3;
@@ -735,6 +775,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
 #if OM_SPLIT_TRACE
         SPLIT_STAMP(ts1);
 #endif
+#if OM_SPLIT_TRACE
+        SPLIT_STAMP(dts[1]);
+#endif
         read_raw(0, 0);
         convert();
         int buf = 0;
@@ -768,6 +811,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
             if (tid == 0) *s_ticket = next_ticket;      // every wave read the current ticket many barriers ago
         }
         __syncthreads();
+#if OM_SPLIT_TRACE
+        SPLIT_STAMP(dts[2]);
+#endif
         if constexpr (KSPLIT) {
             if (p.ksplit > 1) {
                 // publish / count / sum in part order: conv_igemm_split_kernel's split-K hand-off (write-through stores, drained
@@ -789,6 +835,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
                 __syncthreads();
                 if (tid == 0) s_ticket[1] = __hip_atomic_fetch_add(p.kflags + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __syncthreads();
+#if OM_SPLIT_TRACE
+                SPLIT_STAMP(dts[3]);
+                if (s_ticket[1] != p.ksplit - 1) deep_dump();
+#endif
                 if (s_ticket[1] != p.ksplit - 1) break;         // another part stores the tile
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
@@ -816,8 +866,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
         SPLIT_STAMP(ts2);
 #endif
 
+#if OM_SPLIT_TRACE
+        SPLIT_STAMP(dts[4]);
+#endif
         split_epilogue<BM, BN, WM, WN, FAST>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk, sc, sh);
 #if OM_SPLIT_TRACE
+        if constexpr (KSPLIT) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SPLIT_STAMP(dts[5]);
+            deep_dump();
+        }
         SPLIT_STAMP(ts3);
         if (p.trace && blockIdx.x < 16 && n_traced < 16 && tid == 0) {
             unsigned long long* t = p.trace + ((size_t)blockIdx.x * 16 + n_traced) * 8;

@@ -1,6 +1,6 @@
 """Time line of the deep-ring (latency-mode) implicit GEMM from a trace build:
    tools/build_variant.sh deeptrace "-DOM_SPLIT_TRACE=1" conv_igemm_split;  gpurun -- 'python tools/deep_trace.py'
-Per workgroup (s_memtime, 100 MHz ticks -> us): start -> first stage landed -> k loop done -> arrival counted -> parts summed -> stored,
+Per workgroup (s_memtime deltas in shader cycles -> us at 2.4 GHz): start -> first stage landed -> k loop done -> arrival counted -> parts summed -> stored,
 as percentiles over the launch's workgroups, separately for the parts that only publish and the last arrivals."""
 import ctypes
 import os
@@ -21,7 +21,7 @@ def main():
     raw = ctypes.CDLL(omlib.LIB_PATH)
     dev = torch.device("cuda:0")
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    tick_us = 0.01      # s_memtime: 100 MHz
+    tick_us = 1.0 / 2400.0      # s_memtime deltas are shader cycles (~2.4 GHz); its absolute value differs between XCDs
     for hw, cin, cout, k, stride, bm, bn, use_res in SHAPES:
         x = torch.randn(1, hw, hw, cin, device=dev)
         w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
@@ -47,16 +47,13 @@ def main():
         torch.cuda.synchronize()
         t = trace.cpu().view(512, 8)[:, :6]
         t = t[t[:, 0] > 0].double()
-        t0 = t[:, 0].min()
         last = t[:, 5] > 0
-        print("== %dx%d %d->%d k%d tile %dx%d res %d: %.1f us by events, %d workgroups (%d store a tile); launch span %.1f us" % (
-            hw, hw, cin, cout, k, bm, bn, use_res, a.elapsed_time(b) * 1e3, len(t), int(last.sum()),
-            (torch.where(last, t[:, 5], t[:, 3]).max() - t0) * tick_us))
+        print("== %dx%d %d->%d k%d tile %dx%d res %d: %.1f us by events (launch included), %d workgroups (%d store a tile)" % (
+            hw, hw, cin, cout, k, bm, bn, use_res, a.elapsed_time(b) * 1e3, len(t), int(last.sum())))
 
         def pct(v):
             v = v.sort().values
             return "%5.1f / %5.1f / %5.1f" % tuple(float(v[int(q * (len(v) - 1))]) * tick_us for q in (0.1, 0.5, 0.9))
-        print("   start after launch's first    ", pct(t[:, 0] - t0))
         print("   first stage landed            ", pct(t[:, 1] - t[:, 0]))
         print("   k loop                        ", pct(t[:, 2] - t[:, 1]))
         print("   publish + arrival             ", pct(t[:, 3] - t[:, 2]))
@@ -64,7 +61,7 @@ def main():
             tl = t[last]
             print("   last arrival: parts summed    ", pct(tl[:, 4] - tl[:, 3]))
             print("   last arrival: epilogue stored ", pct(tl[:, 5] - tl[:, 4]))
-            print("   last arrival: end after first ", pct(tl[:, 5] - t0))
+            print("   last arrival: start to stored ", pct(tl[:, 5] - tl[:, 0]))
 
 
 if __name__ == "__main__":
