@@ -262,8 +262,8 @@ class OrienMaskYOLOFPNPlus(nn.Module):
         kernel -- per layer, only where the fused kernel would have at most 128 tiles (include/orienmask_hip.h:
         om_model_set_latency_cells) -- and the implicit GEMM's launches of at most 256 tiles cut every tile's k loop into up to
         `ksplit` parts (om_model_set_latency_ksplit, default 8) run by one workgroup each, placed so that an XCD reads an eighth of
-        the weights.  544^2 through the hipGraph of forward + postprocess: one image 3.3 -> 1.9 ms, two 3.4 -> 2.65, four
-        4.3 -> 3.8, eight 6.4 -> 6.1; from twelve images on nothing changes.  Other summation order than the fused kernel and
+        the weights.  544^2 through the hipGraph of forward + postprocess: one image 3.2 -> 1.75 ms, two 3.4 -> 2.6, four
+        4.3 -> 3.8, eight 6.4 -> 5.9; from twelve images on nothing changes.  Other summation order than the fused kernel and
         than whole tiles (same 1e-4 bar against the reference; ~1e-6 of scale apart; run-to-run identical), so outputs are no
         longer independent of the batch size: off by default, on in tester.infer_loop (the reference's bs = 1 loop)."""
         self.latency_cells = int(cells if cells is not None else self.LATENCY_CELLS) if enable else 0
