@@ -1173,6 +1173,12 @@ int om_conv2d_wino14_split(const float* in, int B, int H, int W, int cin, int in
     return om::launch_conv_wino14_split(a, static_cast<hipStream_t>(stream));
 }
 
+int om_set_wino14_variant(int variant) {
+    OM_REQUIRE(variant == 0 || variant == 1, OM_EINVAL, "om_set_wino14_variant: %d", variant);
+    om::wino14_set_variant(variant);
+    return OM_OK;
+}
+
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale, const float* shift,
                    int cout, float* out, om_stream stream) {
     return om::launch_conv_stem(in, B, H, W, w, scale, shift, cout, out, static_cast<hipStream_t>(stream));

@@ -713,6 +713,71 @@ def test_wino14_split_layer_matches_torch(dev, case):
     assert err < 5e-6, (case, err)
 
 
+WINO14_DUAL_CASES = [
+    # B, H, W, cin, cout, leaky, residual -- all with an even number >= 2 of 16-channel chunks (the dual-role kernel's domain)
+    (2, 34, 34, 32, 192, 1, True),       # two chunks: every chunk is a tile's first or last; three N tiles
+    (4, 17, 17, 64, 64, 1, False),       # 25-row blocks across image boundaries, four chunks
+    (1, 40, 136, 32, 64, 0, False),      # four column blocks of 9
+    (3, 68, 68, 128, 256, 1, True),      # the network's 68 x 68 layers: more tiles than one round of 256 workgroups
+    (2, 17, 17, 512, 128, 1, True),      # 32 chunks
+    (1, 7, 9, 32, 70, 1, False),         # tiny image: (R + 2) Ct below 128 entries, cout not a multiple of 64
+    (9, 136, 136, 64, 128, 1, False),    # many tiles per workgroup: the chunk stream across tiles, the two-ahead ticket
+]
+
+
+@pytest.mark.parametrize("case", WINO14_DUAL_CASES)
+def test_wino14_dual_equals_twelve_wave(dev, case):
+    """conv_wino14d.hip (round 5: four dual-role waves, accumulators owned by name) against conv_wino14.hip (eight consumer + four
+    producer waves) on the same inputs: the same sequence of fp32 operations per output, so bit-identical outputs -- and both within
+    the fused form's bound of the float64 convolution (/root/reference/model/base.py:104-137)."""
+    from orienmask_amd.pack import winograd14_weights_split
+    B, H, W, cin, cout, leaky, use_res = case
+    L = omlib.load()
+    g = torch.Generator().manual_seed(sum(case) + 5)
+    x = torch.randn(B, H, W, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.2
+    res = torch.randn(B, H, W, cout, generator=g) if use_res else None
+    cpad = (cout + 63) // 64 * 64
+    us, e = winograd14_weights_split(w, cpad)
+    sp = torch.zeros(cpad); sp[:cout] = scale
+    sps = (sp.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e.double())).float().to(dev)
+    hp = torch.zeros(cpad); hp[:cout] = shift
+    hd, ud, xd = hp.to(dev), us.to(dev), x.to(dev)
+    rd = res.to(dev) if use_res else None
+    ostride = cout + (4 - cout % 4) % 4
+    outs = []
+    try:
+        for variant in (0, 1):
+            omlib.check(L.om_set_wino14_variant(variant), "om_set_wino14_variant")
+            for rep in range(2 if variant else 1):           # the dual kernel twice: nothing depends on what the LDS held
+                out = torch.full((B, H, W, ostride), float("nan"), device=dev)
+                status = torch.zeros(1, dtype=torch.int32, device=dev)
+                rc = L.om_conv2d_wino14_split(_p(xd), B, H, W, cin, cin, _p(ud), _p(sps), _p(hd), cout, leaky,
+                                              _p(rd) if use_res else None, cout if use_res else 0, _p(out), ostride, _p(status),
+                                              omlib.current_stream_ptr(dev))
+                omlib.check(rc, "om_conv2d_wino14_split")
+                torch.cuda.synchronize()
+                assert int(status.item()) == 0
+                outs.append(out.cpu())
+    finally:
+        L.om_set_wino14_variant(1)
+    ref = outs[0]
+    assert torch.isfinite(ref[..., :cout]).all()
+    for o in outs[1:]:
+        assert torch.equal(o[..., :cout], ref[..., :cout]), (case, (o[..., :cout] - ref[..., :cout]).abs().max())
+        assert torch.isnan(o[..., cout:]).all()
+    want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1)
+    want = want * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if leaky:
+        want = torch.where(want > 0, want, want * 0.1)
+    if use_res:
+        want = want + res.permute(0, 3, 1, 2).double()
+    err = _rel_err(outs[1][..., :cout].permute(0, 3, 1, 2).double(), want)
+    assert err < 5e-6, (case, err)
+
+
 @pytest.mark.parametrize("gain,finite", [(100.0, True), (3.0e4, False)])
 def test_split_operand_range(dev, gain, finite):
     """The documented range of split operands (include/orienmask_hip.h: om_model_set_precision): activations 100x larger than a

@@ -19,7 +19,7 @@ def main():
     dev = torch.device("cuda:0")
     B = 32
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    tot14 = tot24 = 0.0
+    tot14 = tot24 = tot12 = 0.0
     shapes = SHAPES if not os.environ.get("OM_SHAPES") else [SHAPES[int(i)] for i in os.environ["OM_SHAPES"].split(",")]
     for hw, cin, cout, n in shapes:
         x = torch.randn(B, hw, hw, cin, device=dev)
@@ -40,8 +40,11 @@ def main():
         def run24():
             omlib.check(L.om_conv2d_winograd24_split(p(x), B, hw, hw, cin, cin, p(u24), p(s24), p(hd), cout, 1, None, 0, p(out), cout,
                                                      p(scratch), scratch.numel(), None, st), "w24")
+        def run14_old():
+            L.om_set_wino14_variant(0); run14(); L.om_set_wino14_variant(1)
+
         res = []
-        for fn in (run14, run24):
+        for fn in (run14, run24, run14_old):
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
@@ -53,10 +56,10 @@ def main():
             torch.cuda.synchronize()
             res.append(a.elapsed_time(b) / 10)
         fl = 2.0 * B * hw * hw * cin * cout * 9
-        print("%3dx%-3d %4d->%-4d x%2d  fused F(4,3) %.3f ms (%.0f TF alg, %.0f TF executed)   F(2x4) two kernels %.3f ms" % (
-            hw, hw, cin, cout, n, res[0], fl / res[0] / 1e9, 1.5 * fl / res[0] / 1e9, res[1]), flush=True)
-        tot14 += n * res[0]; tot24 += n * res[1]
-    print("all 37 layers: fused %.2f ms, two-kernel %.2f ms" % (tot14, tot24))
+        print("%3dx%-3d %4d->%-4d x%2d  fused F(4,3) dual-role %.3f ms (%.0f TF alg, %.0f TF executed)   twelve-wave %.3f ms   F(2x4) two kernels %.3f ms" % (
+            hw, hw, cin, cout, n, res[0], fl / res[0] / 1e9, 1.5 * fl / res[0] / 1e9, res[2], res[1]), flush=True)
+        tot14 += n * res[0]; tot24 += n * res[1]; tot12 += n * res[2]
+    print("all 37 layers: fused dual-role %.2f ms, twelve-wave %.2f ms, two-kernel %.2f ms" % (tot14, tot12, tot24))
 
 
 if __name__ == "__main__":
