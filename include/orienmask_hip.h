@@ -310,9 +310,10 @@ int om_conv2d_winograd24_split(const float* in, int B, int H, int W, int cin, in
 int om_conv2d_wino14_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* u14_split,
                            const float* scale_split, const float* shift, int cout, int leaky, const float* res,
                            int res_pix_stride, float* out, int out_pix_stride, int32_t* status_dev, om_stream stream);
-/* Which kernel runs that layer (process-wide; the outputs are bit-identical): 1 (default; environment OM_W14_VARIANT) the
- * four-dual-role-wave kernel of round 5 (conv_wino14d.hip) wherever it applies -- an even number >= 2 of 16-channel chunks,
- * 16-byte aligned views -- and the twelve-wave kernel (conv_wino14.hip) elsewhere; 0 the twelve-wave kernel everywhere. */
+/* Which kernel runs that layer (process-wide; the outputs are bit-identical): 0 (default; environment OM_W14_VARIANT) the
+ * twelve-wave kernel (conv_wino14.hip) everywhere; 1 the four-dual-role-wave kernel of round 5 (conv_wino14d.hip: one wave per
+ * SIMD, accumulators owned by name) wherever it applies -- an even number >= 2 of 16-channel chunks, 16-byte aligned views.
+ * The second form is kept as a measured alternative (8-25 % slower: profiles/r05_experiments.md), not as the product's path. */
 int om_set_wino14_variant(int variant);
 /* first layer: in [B,3,H,W] NCHW -> out [B,H,W,cout] NHWC, 3x3 stride 1. */
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale,

@@ -603,7 +603,7 @@ static int g_w14_variant = -1;
 int wino14_variant() {
     if (g_w14_variant < 0) {
         const char* e = std::getenv("OM_W14_VARIANT");
-        g_w14_variant = e ? std::atoi(e) : 1;
+        g_w14_variant = e ? std::atoi(e) : 0;
     }
     return g_w14_variant;
 }
@@ -653,8 +653,8 @@ int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream) {
     p.trace = g_w14_trace;
     OM_REQUIRE(p.trace, OM_EINVAL, "wino14 trace build: om_debug_w14_trace() first");
 #endif
-    // round 5: four dual-role waves (conv_wino14d.hip) wherever that form applies; this file's twelve-wave kernel otherwise (odd
-    // chunk counts, cin = 16, unaligned views) and on request (om_debug_set_wino14_variant(0): the bit-identity tests)
+    // round 5: the four-dual-role-wave form (conv_wino14d.hip) on request only (om_set_wino14_variant(1) / OM_W14_VARIANT=1): bit-identical,
+    // but measured 8-25 % slower than this file's twelve-wave kernel on every layer shape (profiles/r05_experiments.md 1)
     if (wino14_variant() == 1 && wino14_dual_supported(p)) return launch_wino14_dual(p, a.res != nullptr, stream);
     const long long grid = total < 256 ? total : 256;        // one 768-thread workgroup per CU (156 KiB of LDS)
     if (!p.fast_io) hipLaunchKernelGGL(wino14_split_kernel<2>, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);

@@ -33,7 +33,12 @@
 //     the epilogue (its set is the epilogue's working registers).
 //
 // Requires an even number of 16-channel chunks >= 2 (every layer of the network: cin = 32 ... 512) and the buffer-descriptor
-// epilogue (16-byte aligned views); launch_conv_wino14_split falls back to conv_wino14.hip otherwise.
+// epilogue (16-byte aligned views).
+//
+// MEASURED (profiles/r05_experiments.md 1): 8-25 % SLOWER than conv_wino14.hip on every layer shape (136 x 136 128 -> 256: 0.89 ms
+// against 0.73).  A lone wave per SIMD overlaps only about half of its other instructions with its own matrix instructions: a
+// group costs 900-1000 cycles of issue for 576 cycles of matrix work, the other instructions alone 760-800.  The kernel stays
+// as a tested alternative (om_set_wino14_variant(1) / OM_W14_VARIANT=1); om_forward runs conv_wino14.hip.
 #include "wino14_shared.h"
 
 namespace om {
@@ -168,8 +173,11 @@ __device__ __forceinline__ void wd_epilogue(const Wino14Params& p, const Wino14T
             elem(std::integral_constant<int, 0>{}); elem(std::integral_constant<int, 1>{});
             elem(std::integral_constant<int, 2>{}); elem(std::integral_constant<int, 3>{});
         };
-        quad(std::integral_constant<int, 0>{}); quad(std::integral_constant<int, 1>{});
-        quad(std::integral_constant<int, 2>{}); quad(std::integral_constant<int, 3>{});
+        // (scheduling fences: left alone, the scheduler reads every accumulator up front and keeps every intermediate alive -- spills)
+        quad(std::integral_constant<int, 0>{}); __builtin_amdgcn_sched_barrier(0);
+        quad(std::integral_constant<int, 1>{}); __builtin_amdgcn_sched_barrier(0);
+        quad(std::integral_constant<int, 2>{}); __builtin_amdgcn_sched_barrier(0);
+        quad(std::integral_constant<int, 3>{}); __builtin_amdgcn_sched_barrier(0);
     };
     auto transpose_in = [&](int slot) {
 #pragma unroll
@@ -201,11 +209,13 @@ __device__ __forceinline__ void wd_epilogue(const Wino14Params& p, const Wino14T
     auto one_position = [&](auto pxc, auto nextc) {
         constexpr int px = decltype(pxc)::value, nx = decltype(nextc)::value;
         transpose_in(px == 0 || px == 1 ? 0 : 1);
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 v[4];
 #pragma unroll
         for (int rd = 0; rd < 4; ++rd) {
             v[rd] = activate(transpose_out(rd), oxe[rd] + px < p.W);
             if constexpr (MODE == 1) v[rd] += rc[rd];
+            __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (MODE == 1 && nx >= 0) {
 #pragma unroll
@@ -216,6 +226,7 @@ __device__ __forceinline__ void wd_epilogue(const Wino14Params& p, const Wino14T
         for (int rd = 0; rd < 4; ++rd)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v[rd]), rs_out, offset(rd, px, p.out_ps), 0, 0);
         asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     };
     using std::integral_constant;
     form(integral_constant<int, 0>{});
@@ -283,15 +294,43 @@ __global__ __launch_bounds__(WD_THREADS, 1) void wino14_dual_kernel(const Wino14
     // ---------------------------------------------------------------- producer side: items (conv_wino14.hip's: a thread owns channel
     // quad tid & 3 of entries tid >> 2 and 64 + (tid >> 2), and a channel pair of entry 128 + (tid >> 3))
     const int ecount = (p.R + 2) * p.Ct;
+    // Per-lane LDS addresses are recomputed at the top of every tile from an opaque copy of the thread id: as kernel-long values
+    // they are live across the epilogue, whose working set then spills (and a reload in front of a matrix step waits for the
+    // whole vector-memory queue).
     int xlds[3];               // LDS byte address of the item's hi halfs in plane 0 (lo: the 16-byte chunk two further on, XOR-swizzled)
+    int dvo, boff_hi, boff_lo, aoff_hi[2][3], aoff_lo[2][3];
+    auto setup_lane = [&]() {
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        const int l_ = t_ & 63, w_ = __builtin_amdgcn_readfirstlane(t_ >> 6);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int e = k < 2 ? 64 * k + (tid >> 2) : 128 + (tid >> 3);
-        const int q = k < 2 ? tid & 3 : (tid >> 1) & 3;
-        const int ch = k < 2 ? 4 * q : 4 * q + 2 * (tid & 1);
-        const int sw = (e >> 2) & 3;
-        xlds[k] = e * 64 + (((q >> 1) ^ sw) * 16) + (ch & 7) * 2;
-    }
+        for (int k = 0; k < 3; ++k) {
+            const int e = k < 2 ? 64 * k + (t_ >> 2) : 128 + (t_ >> 3);
+            const int q = k < 2 ? t_ & 3 : (t_ >> 1) & 3;
+            const int ch = k < 2 ? 4 * q : 4 * q + 2 * (t_ & 1);
+            const int sw = (e >> 2) & 3;
+            xlds[k] = e * 64 + (((q >> 1) ^ sw) * 16) + (ch & 7) * 2;
+        }
+        // weight-group DMA: twelve 1-KiB pieces of 16 rows; wave w requests pieces 3 w .. 3 w + 2: one LDS base (M0) per group, the
+        // instruction's immediate offset (0 / 1024 / 2048) steps through both the source and the LDS image
+        const int drow = l_ >> 2, dcol = l_ & 3;
+        const int row = 16 * (3 * w_) + drow;             // rows 16 i + drow of piece i: the swizzle (row >> 2) & 3 is the same in every piece
+        dvo = row * 64 + ((dcol ^ ((row >> 2) & 3)) * 16);  // swizzle on the SOURCE chunk: the LDS image stays lane-linear
+        const int fi_ = l_ & 31, fk_ = l_ >> 5;
+        const int swB = (fi_ >> 2) & 3;
+        boff_hi = (32 * (w_ & 1) + fi_) * 4 + (fk_ ^ swB);
+        boff_lo = (32 * (w_ & 1) + fi_) * 4 + ((2 + fk_) ^ swB);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int e = 32 * (2 * (w_ >> 1) + blk) + fi_ + ky * p.Ct;
+                const int sw = (e >> 2) & 3;
+                aoff_hi[blk][ky] = e * 4 + (fk_ ^ sw);
+                aoff_lo[blk][ky] = e * 4 + ((2 + fk_) ^ sw);
+            }
+    };
+    setup_lane();
     struct Items { int base[3]; unsigned nok[3]; };      // nok: bit 26 + x set = pixel x of the item does not exist
     // (everything recomputed from an opaque copy of the thread id: nothing of it is live across the chunk loop)
     auto setup_items = [&](int tile_id, Items& it) {
@@ -329,13 +368,15 @@ __global__ __launch_bounds__(WD_THREADS, 1) void wino14_dual_kernel(const Wino14
     const auto rs_in1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in) - p.in_ps, 0, p.in_bytes + p.in_ps * 4, 0x00020000);
     const auto rs_none = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0, 0x00020000);
     auto item_voff = [&](int k, int x) { return (int)(((it.nok[k] << (5 - x)) & 0x80000000u) | (unsigned)(it.base[k] + p.in_ps * 4)); };
-    auto load_quad = [&](auto setc, int k, int c) {
+    auto load_quad_px = [&](auto setc, int k, int c, int x0, int x1) {
         constexpr int S = decltype(setc)::value;
         const bool live = c >= 0 && !(OM_WD_ABLATE & 4);
 #pragma unroll
         for (int x = 0; x < 6; ++x)
-            xq[S][k][x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(live ? rs_in1 : rs_none, item_voff(k, x), x * p.in_ps * 4 + c * 64, 0));
+            if (x >= x0 && x < x1)
+                xq[S][k][x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(live ? rs_in1 : rs_none, item_voff(k, x), x * p.in_ps * 4 + c * 64, 0));
     };
+    auto load_quad = [&](auto setc, int k, int c) { load_quad_px(setc, k, c, 0, 6); };
     auto load_pair = [&](auto setc, int c, int x0, int x1) {
         constexpr int S = decltype(setc)::value;
         const bool live = c >= 0 && !(OM_WD_ABLATE & 4);
@@ -400,29 +441,7 @@ __global__ __launch_bounds__(WD_THREADS, 1) void wino14_dual_kernel(const Wino14
 
     // ---------------------------------------------------------------- consumer side
     const int wm = wave >> 1, wn = wave & 1;
-    const int fi = lane & 31, fk = lane >> 5;
-    // weight-group DMA: twelve 1-KiB pieces of 16 rows; wave w requests pieces 3 w .. 3 w + 2: one LDS base (M0) per group, the
-    // instruction's immediate offset (0 / 1024 / 2048) steps through both the source and the LDS image
-    const int drow = lane >> 2, dcol = lane & 3;
-    int dvo;
-    {
-        const int row = 16 * (3 * wave) + drow;             // rows 16 i + drow of piece i: the swizzle (row >> 2) & 3 is the same in every piece
-        dvo = row * 64 + ((dcol ^ ((row >> 2) & 3)) * 16);  // swizzle on the SOURCE chunk: the LDS image stays lane-linear
-    }
     const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.u), 0, p.u_bytes, 0x00020000);
-    const int swB = (fi >> 2) & 3;
-    const int boff_hi = (32 * wn + fi) * 4 + (fk ^ swB);
-    const int boff_lo = (32 * wn + fi) * 4 + ((2 + fk) ^ swB);
-    int aoff_hi[2][3], aoff_lo[2][3];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int e = 32 * (2 * wm + blk) + fi + ky * p.Ct;
-            const int sw = (e >> 2) & 3;
-            aoff_hi[blk][ky] = e * 4 + (fk ^ sw);
-            aoff_lo[blk][ky] = e * 4 + ((2 + fk) ^ sw);
-        }
     constexpr int GRP_BYTES = WD_UGRP * 16;
     int G = 0;                                  // groups since the kernel's start: group G lives in ring slot G % RING
     Wino14Tile tl, tn;
@@ -454,6 +473,10 @@ __global__ __launch_bounds__(WD_THREADS, 1) void wino14_dual_kernel(const Wino14
         f.a[2] = smem[j * WD_VPLANE + aoff_hi[1][ky]];
         f.a[3] = smem[j * WD_VPLANE + aoff_lo[1][ky]];
     };
+    auto read_a1 = [&](Frags& f, int i, int j, int ky) {      // one of the four A fragments: hi / lo of block 0, hi / lo of block 1
+        if constexpr (OM_WD_ABLATE & 32) { f.a[i] = f32x4{(float)j, 1.f, (float)ky, (float)lane}; return; }
+        f.a[i] = smem[j * WD_VPLANE + ((i & 1) ? aoff_lo[i >> 1][ky] : aoff_hi[i >> 1][ky])];
+    };
     // (bh / bl: the group's slot base + this lane's row, one address computation per group; the kernel row is an immediate offset)
     auto read_b = [&](Frags& f, int ky, const f32x4* bh, const f32x4* bl) {
         if constexpr (OM_WD_ABLATE & 32) { f.b[0] = f.b[1] = f32x4{(float)ky, 1.f, (float)ky, (float)lane}; return; }
@@ -474,7 +497,6 @@ __global__ __launch_bounds__(WD_THREADS, 1) void wino14_dual_kernel(const Wino14
     // weight groups, planes (0, 5) and (1, 2) of the first chunk
     setup_items(tile, it);
     load_quad(I0{}, 0, 0); load_quad(I0{}, 1, 0); load_pair(I0{}, 0, 0, 6);
-    load_quad(I1{}, 0, 1); load_quad(I1{}, 1, 1); load_pair(I1{}, 1, 0, 6);
 #pragma unroll
     for (int g = 0; g < WD_RING - 1; ++g) issue_group(g / 6, g % 6, g);
 #pragma unroll
@@ -482,14 +504,21 @@ __global__ __launch_bounds__(WD_THREADS, 1) void wino14_dual_kernel(const Wino14
     pair_plane(I0{}, 0); pair_plane(I0{}, 5); pair_plane(I0{}, 1); pair_plane(I0{}, 2);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    read_a(F0, 0, 0); read_b(F0, 0, s_u + boff_hi, s_u + boff_lo);
-    zero_acc();
     float nonfinite = 0.f;
 
     while (true) {
         // the ticket after next: requested now, read at the tile's end
         int ticket_v = 0;
         if (tid == 192 && q_hops < 8) ticket_v = draw_request();
+        // this tile's per-lane addresses, its second chunk's pixels (`it` is this tile's; the first chunk's were requested during the
+        // tile before, or by the prologue), the first step's fragments, accumulators = 0
+        setup_lane();
+        load_quad(I1{}, 0, 1); load_quad(I1{}, 1, 1); load_pair(I1{}, 1, 0, 6);
+        {
+            const f32x4* const bh = s_u + (G & (WD_RING - 1)) * WD_UGRP + boff_hi, * const bl = s_u + (G & (WD_RING - 1)) * WD_UGRP + boff_lo;
+            read_a(F0, 0, 0); read_b(F0, 0, bh, bl);
+        }
+        zero_acc();
 
         // One group of the chunk stream: plane position q of chunk c (register-set parity PAR = c & 1).
         //   matrix work    plane w14_plane(q) of chunk c: 3 kernel rows x 6 instructions (per accumulator the products in
@@ -507,7 +536,9 @@ __global__ __launch_bounds__(WD_THREADS, 1) void wino14_dual_kernel(const Wino14
             constexpr int ja = q < 2 ? 3 : q < 4 ? 0 : 1, jb = q < 2 ? 4 : q < 4 ? 5 : 2;
             constexpr int SET = q < 2 ? PAR : PAR ^ 1;
             constexpr int KQ = q & 1;
-            constexpr int N0 = j, N1 = 6 + j;
+            // accumulator of the i-th matrix instruction of a step: block i & 1 of plane j (measurement 128: six different ones -- no
+            // instruction waits for the result of the one before the last)
+            auto acc_of = [](int i) constexpr { return (OM_WD_ABLATE & 128) ? (i < 3 ? (j + i) % 6 : 6 + (j + i) % 6) : 6 * (i & 1) + j; };
             using SetC = std::integral_constant<int, SET>;
             using ParC = std::integral_constant<int, PAR>;
             const int slot = G & (WD_RING - 1), slot1 = (G + 1) & (WD_RING - 1);
@@ -516,56 +547,65 @@ __global__ __launch_bounds__(WD_THREADS, 1) void wino14_dual_kernel(const Wino14
             auto h = [](const f32x4& v) { return __builtin_bit_cast(f16x8, v); };
             Split4 sa, sb;
 #if OM_WD_TRACE
-            unsigned long long t0, t1, t2;
+            unsigned long long t0, t1, t2, ts1, ts2;
             WD_STAMP(t0);
 #endif
             asm volatile("" ::: "memory");
             issue_group(c + (q + WD_RING - 1) / 6, (q + WD_RING - 1) % 6, G + WD_RING - 1);
             asm volatile("" ::: "memory");
+            // Every matrix instruction is followed by ONE gap of a few other instructions and a scheduling fence: alone on its SIMD,
+            // the wave overlaps its matrix instructions only with what it issues in their shadow (about five instructions per 32
+            // cycles); left to the scheduler, the producer's work gathers between the steps, where no matrix instruction is in flight.
+#define WD_GAP __builtin_amdgcn_sched_barrier(0)
             // ---- kernel row 0 (set F0; reads F1 = kernel row 1); producer: plane ja of the quad item
-            read_a(F1, j, 1);
-            wd_mfma_first<N0>(h(F0.b[0]), h(F0.a[1]));
-            read_b(F1, 1, bh, bl);
-            wd_mfma<N1>(h(F0.b[0]), h(F0.a[3]));
-            const f32x4 va = point(xq[SET][KQ], ja);
-            wd_mfma<N0>(h(F0.b[1]), h(F0.a[0]));
-            split4_hi(va, sa);
-            wd_mfma<N1>(h(F0.b[1]), h(F0.a[2]));
-            wd_mfma<N0>(h(F0.b[0]), h(F0.a[0]));
-            split4_store(sa, KQ, ja);
-            wd_mfma<N1>(h(F0.b[0]), h(F0.a[2]));
+            wd_mfma_first<acc_of(0)>(h(F0.b[0]), h(F0.a[1]));
+            read_a1(F1, 0, j, 1); read_a1(F1, 1, j, 1); WD_GAP;
+            wd_mfma<acc_of(1)>(h(F0.b[0]), h(F0.a[3]));
+            read_a1(F1, 2, j, 1); read_a1(F1, 3, j, 1); WD_GAP;
+            wd_mfma<acc_of(2)>(h(F0.b[1]), h(F0.a[0]));
+            read_b(F1, 1, bh, bl); WD_GAP;
+            wd_mfma<acc_of(3)>(h(F0.b[1]), h(F0.a[2]));
+            const f32x4 va = point(xq[SET][KQ], ja); WD_GAP;
+            wd_mfma<acc_of(4)>(h(F0.b[0]), h(F0.a[0]));
+            split4_hi(va, sa); WD_GAP;
+            wd_mfma<acc_of(5)>(h(F0.b[0]), h(F0.a[2]));
+            split4_store(sa, KQ, ja); WD_GAP;
             // ---- kernel row 1 (set F1; reads F2 = kernel row 2); plane jb of the quad item
-            read_a(F2, j, 2);
-            wd_mfma_first<N0>(h(F1.b[0]), h(F1.a[1]));
-            read_b(F2, 2, bh, bl);
-            wd_mfma<N1>(h(F1.b[0]), h(F1.a[3]));
-            const f32x4 vb = point(xq[SET][KQ], jb);
-            wd_mfma<N0>(h(F1.b[1]), h(F1.a[0]));
-            split4_hi(vb, sb);
-            wd_mfma<N1>(h(F1.b[1]), h(F1.a[2]));
-            wd_mfma<N0>(h(F1.b[0]), h(F1.a[0]));
-            split4_store(sb, KQ, jb);
-            wd_mfma<N1>(h(F1.b[0]), h(F1.a[2]));
+            wd_mfma_first<acc_of(0)>(h(F1.b[0]), h(F1.a[1]));
+            read_a1(F2, 0, j, 2); read_a1(F2, 1, j, 2); WD_GAP;
+            wd_mfma<acc_of(1)>(h(F1.b[0]), h(F1.a[3]));
+            read_a1(F2, 2, j, 2); read_a1(F2, 3, j, 2); WD_GAP;
+            wd_mfma<acc_of(2)>(h(F1.b[1]), h(F1.a[0]));
+            read_b(F2, 2, bh, bl); WD_GAP;
+            wd_mfma<acc_of(3)>(h(F1.b[1]), h(F1.a[2]));
+            const f32x4 vb = point(xq[SET][KQ], jb); WD_GAP;
+            wd_mfma<acc_of(4)>(h(F1.b[0]), h(F1.a[0]));
+            split4_hi(vb, sb); WD_GAP;
+            wd_mfma<acc_of(5)>(h(F1.b[0]), h(F1.a[2]));
+            split4_store(sb, KQ, jb); WD_GAP;
             // ---- kernel row 2 (set F2; reads F0 = the next group's kernel row 0); the pair item's plane, the chunk's requests
-            read_a(F0, jn, 0);
-            wd_mfma_first<N0>(h(F2.b[0]), h(F2.a[1]));
-            read_b(F0, 0, bh1, bl1);
-            wd_mfma<N1>(h(F2.b[0]), h(F2.a[3]));
+            // (chunk c + 2; behind chunk nch - 2 the next tile's first chunk -- `it` is the next tile's by then; behind the last chunk
+            // NOTHING, requests that go nowhere (same counts): the next tile's second chunk is requested at the top of that tile,
+            // its register set is the epilogue's working space meanwhile)
+            [[maybe_unused]] const int tc = c + 2 < p.nch ? c + 2 : c + 2 == p.nch ? 0 : -1;
+            constexpr bool LOADS = q == 2 || q == 3;
+            wd_mfma_first<acc_of(0)>(h(F2.b[0]), h(F2.a[1]));
+            read_a1(F0, 0, jn, 0); read_a1(F0, 1, jn, 0); WD_GAP;
+            wd_mfma<acc_of(1)>(h(F2.b[0]), h(F2.a[3]));
+            read_a1(F0, 2, jn, 0); read_a1(F0, 3, jn, 0); WD_GAP;
+            wd_mfma<acc_of(2)>(h(F2.b[1]), h(F2.a[0]));
+            read_b(F0, 0, bh1, bl1); WD_GAP;
+            wd_mfma<acc_of(3)>(h(F2.b[1]), h(F2.a[2]));
             pair_plane(SetC{}, KQ ? jb : ja);
-            wd_mfma<N0>(h(F2.b[1]), h(F2.a[0]));
-            if constexpr (q == 2 || q == 3) {
-                // chunk c + 2; behind chunk nch - 2 the next tile's first chunk (`it` is the next tile's by then); behind the last
-                // chunk NOTHING -- requests that go nowhere (same counts): the next tile's second chunk is requested behind the
-                // epilogue, whose working registers this set is meanwhile
-                const int tc = c + 2 < p.nch ? c + 2 : c + 2 == p.nch ? 0 : -1;
-                load_quad(ParC{}, KQ, tc);
-                wd_mfma<N1>(h(F2.b[1]), h(F2.a[2]));
-                load_pair(ParC{}, tc, q == 2 ? 0 : 3, q == 2 ? 3 : 6);
-            } else {
-                wd_mfma<N1>(h(F2.b[1]), h(F2.a[2]));
-            }
-            wd_mfma<N0>(h(F2.b[0]), h(F2.a[0]));
-            wd_mfma<N1>(h(F2.b[0]), h(F2.a[2]));
+            if constexpr (LOADS) load_quad_px(ParC{}, KQ, tc, 0, 2);
+            WD_GAP;
+            wd_mfma<acc_of(4)>(h(F2.b[0]), h(F2.a[0]));
+            if constexpr (LOADS) load_quad_px(ParC{}, KQ, tc, 2, 4);
+            WD_GAP;
+            wd_mfma<acc_of(5)>(h(F2.b[0]), h(F2.a[2]));
+            if constexpr (LOADS) { load_quad_px(ParC{}, KQ, tc, 4, 6); load_pair(ParC{}, tc, q == 2 ? 0 : 3, q == 2 ? 3 : 6); }
+            WD_GAP;
+#undef WD_GAP
             // my pieces of weight group G + 2 have landed; my LDS stores are done; the next group's first fragments are here
             // (a tile's first RING - 3 groups: the epilogue's stores are among the younger operations, the exact count exceeds the
             // counter's six bits -- the largest count is still a stronger wait than necessary)
@@ -578,10 +618,12 @@ __global__ __launch_bounds__(WD_THREADS, 1) void wino14_dual_kernel(const Wino14
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(wd_younger(q)) : "memory");
 #if OM_WD_TRACE
             WD_STAMP(t2);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t0), "+s"(t1), "+s"(t2)::"memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t0), "+s"(t1), "+s"(t2), "+s"(ts1), "+s"(ts2)::"memory");
             if (blockIdx.x < 8 && G < 512 && lane == 0) {
                 unsigned long long* t = trace + ((blockIdx.x * 4 + wave) * 512 + G) * 4;
                 t[0] = t0; t[1] = t1; t[2] = t2;
+                unsigned long long* u = trace + 8 * 4 * 512 * 4 + ((blockIdx.x * 4 + wave) * 512 + G) * 2;
+                u[0] = ts1; u[1] = ts2;
             }
 #endif
             if constexpr (!(OM_WD_ABLATE & 64)) __builtin_amdgcn_s_barrier();
@@ -607,8 +649,11 @@ __global__ __launch_bounds__(WD_THREADS, 1) void wino14_dual_kernel(const Wino14
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
         f32x4* sT = smem + 3 * WD_VPLANE + wave * 256;
         if constexpr (!(OM_WD_ABLATE & 1)) {
+            __builtin_amdgcn_sched_barrier(0);
             wd_epilogue<MODE, 0>(p, tl, sT, 2 * wm, wn, lane, nonfinite);
+            __builtin_amdgcn_sched_barrier(0);
             wd_epilogue<MODE, 1>(p, tl, sT, 2 * wm + 1, wn, lane, nonfinite);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #if OM_WD_TRACE
         {
@@ -628,10 +673,6 @@ __global__ __launch_bounds__(WD_THREADS, 1) void wino14_dual_kernel(const Wino14
         wino14_decode(p, tile_next, tn);
         ubase = ubase_next;
         ubase_next = tile_next < p.total_tiles ? tn.tile_n * p.nch * 6 * GRP_BYTES : -1;
-        load_quad(I1{}, 0, 1); load_quad(I1{}, 1, 1); load_pair(I1{}, 1, 0, 6);      // this tile's second chunk (`it` is this tile's)
-        read_a(F0, 0, 0);       // (not held across the epilogue: 24 registers)
-        read_b(F0, 0, s_u + (G & (WD_RING - 1)) * WD_UGRP + boff_hi, s_u + (G & (WD_RING - 1)) * WD_UGRP + boff_lo);
-        zero_acc();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring's last requests (zeros for tiles that do not exist)
     if (p.status && nonfinite != nonfinite) atomicOr(p.status, OM_STATUS_SPLIT_RANGE);

@@ -125,7 +125,7 @@ int launch_conv_stem2_split(const float* in_nchw, int B, int H, int W, const flo
                             float* out_nhwc, int out_pix_stride, int* status, hipStream_t stream);
 size_t wino14_weight_halfs(int cout_pad, int cin);
 void wino14_geometry(int B, int H, int W, int* R, int* Ct, int* ncb, int* nrb);
-void wino14_set_variant(int v);      // conv_wino14.hip: 1 = the dual-role kernel (conv_wino14d.hip) where it applies, 0 = never
+void wino14_set_variant(int v);      // conv_wino14.hip: 0 = the twelve-wave kernel (default), 1 = the dual-role kernel (conv_wino14d.hip) where it applies
 bool wino_enabled();
 int wino_bn(long long T, int cout_pad);   // N tile of the (unfused) Winograd GEMM at this size
 bool wino_fused_for(int cin);     // true: the input transform is fused into the GEMM's loader   // tile shape launch_conv_igemm picks

@@ -231,7 +231,7 @@ __device__ __forceinline__ void wino14_epilogue(const Wino14Params& p, const f32
 // conv_wino14d.hip
 bool wino14_dual_supported(const Wino14Params& p);
 int launch_wino14_dual(const Wino14Params& p, bool has_res, hipStream_t stream);
-int wino14_variant();               // 1: the dual-role kernel where it applies (default; OM_W14_VARIANT), 0: the twelve-wave kernel everywhere
+int wino14_variant();               // 0: the twelve-wave kernel everywhere (default); 1: the dual-role kernel where it applies (OM_W14_VARIANT)
 void wino14_set_variant(int v);
 
 }  // namespace om

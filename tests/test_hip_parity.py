@@ -762,7 +762,7 @@ def test_wino14_dual_equals_twelve_wave(dev, case):
                 assert int(status.item()) == 0
                 outs.append(out.cpu())
     finally:
-        L.om_set_wino14_variant(1)
+        L.om_set_wino14_variant(0)
     ref = outs[0]
     assert torch.isfinite(ref[..., :cout]).all()
     for o in outs[1:]:

@@ -424,3 +424,57 @@ def test_upsample_on_read_graph_logic(built):
     small = OrienMaskYOLO(3, 80).set_precision("f32_split")
     assert sorted(k for k, v in small.layer_kernels(8, 544, 544) if "gather" in v) == ["neck16.0", "neck4.0", "neck8.0"]
     assert L.om_model_set_upsample_on_read(None, 1) != 0          # null model: an error code, not a crash
+
+
+def test_wino14d_isa_audit(tmp_path):
+    """conv_wino14d.hip owns the accumulation registers a0 .. a191 by name (inline-asm matrix instructions); the compiler knows them
+    only as clobbers.  That is sound only while the compiler has no reason to touch them and the asm needs no padding it does
+    not get -- checked on the emitted gfx950 code (hipcc cross-compiles here, no GPU): no scratch, no spilled register, no
+    compiler-issued v_accvgpr_* at all, exactly 192 accumulation registers, and no vector-ALU write of a matrix instruction's
+    operand within the two instructions in front of it (the wait states the compiler does not insert inside an asm)."""
+    src = os.path.join(REPO, "orienmask_amd", "csrc", "conv_wino14d.hip")
+    out = str(tmp_path / "w14d.s")
+    import subprocess
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", src, "-o", out,
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    remarks = r.stderr
+    kernels = re.findall(r"Function Name: (\S*wino14_dual_kernel\S*)", remarks)
+    assert len(kernels) == 2
+    assert re.findall(r"VGPRs Spill: (\d+)", remarks) == ["0", "0"], remarks
+    assert re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", remarks) == ["0", "0"], remarks
+    assert re.findall(r"AGPRs: (\d+)", remarks) == ["192", "192"], remarks
+    text = open(out).read()
+    for name in kernels:
+        body = text[text.index(name + ":"):]
+        body = body[:body.index("s_endpgm")]
+        lines = [l.split(";")[0].strip() for l in body.split("\n")]
+        in_asm = False
+        code = []           # (instruction, inside an asm statement)
+        for raw in body.split("\n"):
+            if "#ASMSTART" in raw:
+                in_asm = True
+                continue
+            if "#ASMEND" in raw:
+                in_asm = False
+                continue
+            ins = raw.split(";")[0].strip()
+            if not ins or ins.endswith(":") or ins.startswith("."):
+                continue
+            code.append((ins, in_asm))
+        assert sum(1 for ins, a in code if ins.startswith("v_mfma")) >= 216
+        for i, (ins, a) in enumerate(code):
+            if "accvgpr" in ins:
+                assert a, "compiler-issued %s" % ins
+            if ins.startswith("v_mfma"):
+                assert a
+                ops = set()
+                for m in re.finditer(r"v\[(\d+):(\d+)\]", ins):
+                    ops.update(range(int(m.group(1)), int(m.group(2)) + 1))
+                for prev, _ in code[max(0, i - 2):i]:
+                    if prev.startswith("v_") and not prev.startswith("v_mfma") and not prev.startswith("v_cmp"):
+                        d = re.match(r"\S+\s+v\[?(\d+)(?::(\d+))?\]?", prev)
+                        if d:
+                            lo, hi = int(d.group(1)), int(d.group(2) or d.group(1))
+                            assert not (ops & set(range(lo, hi + 1))), (prev, ins)
+    del lines

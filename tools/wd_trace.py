@@ -28,13 +28,15 @@ def main():
     s14 = torch.pow(torch.tensor(2.0), -e14.float()).to(dev)
     u14 = u14.to(dev)
     st = omlib.current_stream_ptr(dev)
-    trace = torch.zeros(8 * 4 * 512 * 4, dtype=torch.int64, device=dev)
+    trace = torch.zeros(8 * 4 * 512 * 6, dtype=torch.int64, device=dev)
     L.om_debug_wd_trace.argtypes = [ctypes.c_void_p]
     L.om_debug_wd_trace(p(trace))
+    L.om_set_wino14_variant(1)
     for _ in range(3):
         omlib.check(L.om_conv2d_wino14_split(p(x), B, hw, hw, cin, cin, p(u14), p(s14), p(hd), cout, 1, None, 0, p(out), cout, None, st), "w14")
     torch.cuda.synchronize()
-    t = trace.cpu().view(8, 4, 512, 4)
+    steps = trace.cpu()[8 * 4 * 512 * 4:].view(8, 4, 512, 2)
+    t = trace.cpu()[:8 * 4 * 512 * 4].view(8, 4, 512, 4)
     nch = cin // 16
     gpt = 6 * nch
     print("%dx%d %d->%d: %d groups per tile" % (hw, hw, cin, cout, gpt))
@@ -51,11 +53,14 @@ def main():
                 key = ("first chunk " if first else "steady      ") + "q=%d" % q
                 if (g + 1) % gpt == 0:
                     continue        # the group in front of an epilogue: its "barrier" time is the epilogue
-                acc[key].append((int(tt[g, 1] - tt[g, 0]), int(tt[g, 2] - tt[g, 1]), int(tt[g + 1, 0] - tt[g, 2])))
+                st = steps[wg, wave, g]
+                acc[key].append((int(tt[g, 1] - tt[g, 0]), int(tt[g, 2] - tt[g, 1]), int(tt[g + 1, 0] - tt[g, 2]),
+                                 int(st[0] - tt[g, 0]), int(st[1] - st[0]), int(tt[g, 1] - st[1])))
             for k in sorted(acc):
                 v = acc[k]
-                m = [sum(a[i] for a in v) / len(v) for i in range(3)]
-                print("  %s  issue %6.0f  end wait %6.0f  barrier %6.0f  total %6.0f   (n=%d)" % (k, m[0], m[1], m[2], sum(m), len(v)))
+                m = [sum(a[i] for a in v) / len(v) for i in range(6)]
+                print("  %s  issue %6.0f (kernel rows %4.0f %4.0f %4.0f)  end wait %6.0f  barrier %6.0f  total %6.0f   (n=%d)" % (
+                    k, m[0], m[3], m[4], m[5], m[1], m[2], sum(m[:3]), len(v)))
             epi = []
             for g in range(gpt - 1, min(n - 1, 500), gpt):
                 if tt[g, 3] > 0:

@@ -34,17 +34,17 @@ def main():
         scratch = torch.empty(L.om_conv2d_winograd24_scratch_bytes(B, hw, hw, cin), dtype=torch.uint8, device=dev)
         st = omlib.current_stream_ptr(dev)
 
+        def run14_dual():
+            L.om_set_wino14_variant(1); run14(); L.om_set_wino14_variant(0)
+
         def run14():
             omlib.check(L.om_conv2d_wino14_split(p(x), B, hw, hw, cin, cin, p(u14), p(s14), p(hd), cout, 1, None, 0, p(out), cout, None, st), "w14")
 
         def run24():
             omlib.check(L.om_conv2d_winograd24_split(p(x), B, hw, hw, cin, cin, p(u24), p(s24), p(hd), cout, 1, None, 0, p(out), cout,
                                                      p(scratch), scratch.numel(), None, st), "w24")
-        def run14_old():
-            L.om_set_wino14_variant(0); run14(); L.om_set_wino14_variant(1)
-
         res = []
-        for fn in (run14, run24, run14_old):
+        for fn in (run14_dual, run24, run14):
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
