@@ -121,14 +121,36 @@ class COCOFormatter:
     MAX_RUNS = 8192                 # first-guess run buffer per mask (a 544^2 orientation mask has a few hundred runs)
     BYTES_PER_MASK = 4096           # first-guess share of the batch's string buffer per mask
 
+    WORST_CASE_BYTES = 256 << 20    # most scratch one worst-case launch may take: overflowing masks are redone in chunks of this size
+
     def __init__(self, cat2label, with_mask=True):
         self.cat2label = list(cat2label)
         self.with_mask = with_mask
+        self._scratch = {}              # (device, name) -> tensor: the batch's run / string / header buffers, grown on demand
+
+    def _buffer(self, dev, name, numel, dtype):
+        """A scratch tensor of at least `numel` elements (the evaluation loop formats hundreds of batches: ~36 KB per detection
+        would otherwise be allocated and freed per batch).  Grows geometrically; contents are undefined."""
+        key = (str(dev), name)
+        t = self._scratch.get(key)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            grown = max(numel, int(t.numel() * 1.5) if t is not None and t.dtype == dtype else 0)
+            t = torch.empty(grown, dtype=dtype, device=dev)
+            self._scratch[key] = t
+        return t[:numel]
+
+    def _worst_case_strings(self, items):
+        """[(mask [1,H,W], info)] -> strings, with buffers for the worst case (every pixel its own run, six characters per
+        run): one launch and two host reads per chunk of at most WORST_CASE_BYTES of scratch (~3 MB per 480 x 640 mask)."""
+        per_mask = 10 * (max(int(i["height"]) * int(i["width"]) for _, i in items) + 1)     # 4 B of counts + 6 B of string per run
+        step = max(1, self.WORST_CASE_BYTES // per_mask)
+        out = []
+        for i0 in range(0, len(items), step):
+            out += self._worst_case_chunk(items[i0:i0 + step])
+        return out
 
     @staticmethod
-    def _worst_case_strings(items):
-        """[(mask [1,H,W], info)] -> strings, with buffers for the worst case (every pixel its own run, six characters per
-        run): one launch, two host reads."""
+    def _worst_case_chunk(items):
         L = _lib.load()
         dev = items[0][0].device
         n = len(items)
@@ -181,9 +203,10 @@ class COCOFormatter:
                                              ctypes.c_void_p(xywh.data_ptr() + s0 * 16), st), "om_recover_bbox")
             if self.with_mask:
                 cap = N * self.BYTES_PER_MASK
-                hdr = torch.zeros(2 + 3 * N, dtype=torch.int32, device=dev)   # cursor, overflow | off[N] | len[N] | n_runs[N]
-                sbytes = torch.empty(cap, dtype=torch.uint8, device=dev)
-                counts = torch.empty((N, self.MAX_RUNS), dtype=torch.int32, device=dev)
+                hdr = self._buffer(dev, "hdr", 2 + 3 * N, torch.int32)        # cursor, overflow | off[N] | len[N] | n_runs[N]
+                hdr.zero_()
+                sbytes = self._buffer(dev, "strings", cap, torch.uint8)
+                counts = self._buffer(dev, "counts", N * self.MAX_RUNS, torch.int32).view(N, self.MAX_RUNS)
                 masks = []                                                      # keep the uint8 views alive until the launch
                 imgs = (_lib.RleImage * len(pairs))()
                 for i, (info, det) in enumerate(pairs):

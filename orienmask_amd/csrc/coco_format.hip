@@ -25,6 +25,7 @@
 //
 // Built with -ffp-contract=off: the float arithmetic follows torch's operation order (source index by fmaf,
 // taps combined as in preprocess.hip), so the resized masks are bit-identical to the reference's.
+#include <atomic>
 #include "om_common.h"
 
 namespace om {
@@ -448,16 +449,30 @@ static int fill_rle_params(om::RleParams& q, const uint8_t* mask, int K, int H, 
 }
 
 static size_t rle_lds_bytes(int orig_h, int orig_w) { return (size_t)orig_h * 16 + (size_t)orig_w * ((orig_h + 31) / 32) * 4; }
-constexpr size_t RLE_LDS_MAX = 150 * 1024;      // the column-major bitmap of one mask in LDS (480 x 640: 46 KB with the row taps)
+// Most LDS one mask's column-major bitmap may take (480 x 640: 46 KB with the row taps): what the device reports per workgroup
+// (163 840 B on MI355X) less 10 KiB for the kernel's static arrays.  Queried once per process (every GPU of a node is the same
+// part); -1: not yet known.
+static size_t rle_lds_max() {
+    static std::atomic<long long> cached{-1};
+    long long v = cached.load(std::memory_order_acquire);
+    if (v < 0) {
+        int dev = 0, per_block = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess ||
+            per_block < 64 * 1024)
+            per_block = 64 * 1024;              // the architectural default: no attribute needed below it
+        v = per_block - 10 * 1024;
+        cached.store(v, std::memory_order_release);
+    }
+    return (size_t)v;
+}
 
 // images [i0, i1) of a batch whose bitmaps fit LDS: one launch
 static int launch_rle_lds_batch(om::RleBatch& bt, size_t lds, const om::RleStringOut& so, hipStream_t st) {
-    static bool attr_set = false;            // more than the default 64 KiB of dynamic LDS needs the attribute once
-    if (!attr_set) {
+    // more than the default 64 KiB of dynamic LDS needs the attribute on EVERY device that launches the kernel: set per launch
+    // (a host-side table update, no device work; a process-wide "done" flag would cover the first GPU only and race between threads)
+    if (lds > 64 * 1024)
         OM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(om::recover_rle_lds_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)RLE_LDS_MAX));
-        attr_set = true;
-    }
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)rle_lds_max()));
     hipLaunchKernelGGL(om::recover_rle_lds_kernel, dim3(bt.first[bt.n]), dim3(om::RLE_THREADS), lds, st, bt, so);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
@@ -473,7 +488,7 @@ static int launch_recover_rle(const uint8_t* mask, int K, int H, int W, int crop
         return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = rle_lds_bytes(orig_h, orig_w);
-    if (lds <= RLE_LDS_MAX) {
+    if (lds <= rle_lds_max()) {
         bt.n = 1; bt.first[0] = 0; bt.first[1] = K;
         return launch_rle_lds_batch(bt, lds, so, st);
     }
@@ -523,7 +538,7 @@ int om_recover_masks_rle_strings(const om_rle_image* images, int n_images, uint3
         if (im.K == 0) continue;
         const size_t need = rle_lds_bytes(im.orig_h, im.orig_w);
         uint32_t* cnt = counts + (size_t)first * max_runs;
-        if (need > RLE_LDS_MAX) {            // a bitmap too large for LDS: this image alone, through the old kernel
+        if (need > rle_lds_max()) {            // a bitmap too large for LDS: this image alone, through the old kernel
             if (int rc = flush()) return rc;
             om::RleStringOut s2 = so;
             s2.off += first; s2.len += first;

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -313,8 +314,13 @@ struct om_model {
         int32_t* out_count = nullptr; int32_t* out_keep = nullptr;
         void* ws = nullptr; size_t ws_bytes = 0;
     } post;
-    struct Side { hipStream_t main = nullptr, side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
+    struct Side { hipStream_t main = nullptr, side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; unsigned long long used = 0; };
     std::vector<Side> sides;      // one second stream per caller stream (batches in flight on several streams stay independent)
+    Side capture_side;            // a second stream of its own for forwards issued DURING a stream capture (created by
+                                  // om_model_attach_postprocess, outside any capture: nothing may be created inside one, and a caller
+                                  // stream's own side stream and events may be in use by an eager step at the same time)
+    unsigned long long side_clock = 0;
+    std::mutex side_mutex;        // sides / capture_side / post are read and changed under it (forwards from several host threads)
     int head_last = -2;      // graph index of the last bbox_head* layer (-1: none; -2: not looked up yet)
     void find_head_last() {
         head_last = -1;
@@ -455,6 +461,7 @@ int om_model_create_variant(om_model** out, int variant, int num_anchors, int nu
 void om_model_destroy(om_model* m) {
     if (!m) return;
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
+    if (m->capture_side.side) m->sides.push_back(m->capture_side);
     for (om_model::Side& sd : m->sides) {
         (void)hipEventDestroy(sd.ev_fork);
         (void)hipEventDestroy(sd.ev_join);
@@ -540,28 +547,46 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
     hipStream_t const main_stream = static_cast<hipStream_t>(stream_);
     const size_t esz = f16 ? 2 : 4;
     // an attached postprocess (om_model_attach_postprocess): decode + select on the library's second stream behind the last box head
-    const bool fused_post = m->post.on && !f16;
-    const bool early = fused_post && m->head_last >= 0;
     om_model::Side sd;
-    if (early) {
-        for (const om_model::Side& have : m->sides)
-            if (have.main == main_stream) sd = have;
-        if (!sd.side && !m->sides.empty()) {
-            // a capturing stream (torch.cuda.graph captures on a stream of its own, after warm-ups elsewhere): nothing is created
-            // during a capture -- any existing second stream serves, the capture isolates it
+    om_model::PostAttach post_q;      // the attachment as it was when this forward began
+    bool fused_post, early;
+    {
+        std::lock_guard<std::mutex> lock(m->side_mutex);
+        post_q = m->post;
+        fused_post = m->post.on && !f16;
+        early = fused_post && m->head_last >= 0;
+        if (early) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(main_stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
-                sd = m->sides.back();
+            const bool capturing = hipStreamIsCapturing(main_stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+            if (capturing) {
+                // torch.cuda.graph captures on a stream of its own, after warm-ups elsewhere: the capture's side stream is the one
+                // om_model_attach_postprocess created for this purpose (the capture isolates it)
+                OM_REQUIRE(m->capture_side.side, OM_ESTATE, "om_forward: stream capture with an attached postprocess, but no capture stream (re-attach)");
+                sd = m->capture_side;
                 sd.main = main_stream;
+            } else {
+                for (om_model::Side& have : m->sides)
+                    if (have.main == main_stream) { have.used = ++m->side_clock; sd = have; }
+                if (!sd.side) {      // first forward with an attachment on this stream
+                    if (m->sides.size() >= 64) {
+                        // the least recently used entry changes owner: its side stream has long joined its old caller stream
+                        // (every forward ends with the join), so the stream and its events are free to serve another
+                        size_t lru = 0;
+                        for (size_t i = 1; i < m->sides.size(); ++i)
+                            if (m->sides[i].used < m->sides[lru].used) lru = i;
+                        m->sides[lru].main = main_stream;
+                        m->sides[lru].used = ++m->side_clock;
+                        sd = m->sides[lru];
+                    } else {
+                        sd.main = main_stream;
+                        sd.used = ++m->side_clock;
+                        OM_CHECK_HIP(hipStreamCreateWithFlags(&sd.side, hipStreamNonBlocking));
+                        OM_CHECK_HIP(hipEventCreateWithFlags(&sd.ev_fork, hipEventDisableTiming));
+                        OM_CHECK_HIP(hipEventCreateWithFlags(&sd.ev_join, hipEventDisableTiming));
+                        m->sides.push_back(sd);
+                    }
+                }
             }
-        }
-        if (!sd.side) {      // first forward with an attachment on this stream
-            OM_REQUIRE(m->sides.size() < 64, OM_ESTATE, "om_forward: an attached postprocess was used from more than 64 streams");
-            sd.main = main_stream;
-            OM_CHECK_HIP(hipStreamCreateWithFlags(&sd.side, hipStreamNonBlocking));
-            OM_CHECK_HIP(hipEventCreateWithFlags(&sd.ev_fork, hipEventDisableTiming));
-            OM_CHECK_HIP(hipEventCreateWithFlags(&sd.ev_join, hipEventDisableTiming));
-            m->sides.push_back(sd);
         }
     }
     struct JoinGuard {      // whatever path leaves the function: the caller's stream waits for the side stream's work
@@ -753,7 +778,7 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             OM_CHECK_HIP(hipEventRecord(sd.ev_fork, main_stream));
             OM_CHECK_HIP(hipStreamWaitEvent(sd.side, sd.ev_fork, 0));
             join_guard.forked = true;
-            const om_model::PostAttach& q = m->post;
+            const om_model::PostAttach& q = post_q;
             if (int prc = om_postprocess_detect(&q.cfg, bbox32, bbox16, bbox8, B, q.out_bbox, q.out_cls, q.out_count, q.out_keep, q.ws,
                                                 q.ws_bytes, sd.side))
                 return prc;
@@ -761,7 +786,7 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
     }
     if (m->profiling) ++m->prof_forwards;
     if (fused_post) {
-        const om_model::PostAttach& q = m->post;
+        const om_model::PostAttach& q = post_q;
         join_guard.join();
         if (!early)
             if (int prc = om_postprocess_detect(&q.cfg, bbox32, bbox16, bbox8, B, q.out_bbox, q.out_cls, q.out_count, q.out_keep, q.ws,
@@ -844,6 +869,7 @@ int om_model_set_latency_cells(om_model* m, long long cells) {
 int om_model_attach_postprocess(om_model* m, const om_post_cfg* cfg, float* out_bbox, int64_t* out_cls, uint8_t* out_mask,
                                 int32_t* out_count, int32_t* out_keep, void* post_workspace, size_t post_ws_bytes) {
     OM_REQUIRE(m, OM_EINVAL, "om_model_attach_postprocess: null model");
+    std::lock_guard<std::mutex> lock(m->side_mutex);
     if (!cfg) {
         m->post.on = false;
         return OM_OK;
@@ -856,6 +882,11 @@ int om_model_attach_postprocess(om_model* m, const om_post_cfg* cfg, float* out_
     m->post.ws = post_workspace; m->post.ws_bytes = post_ws_bytes;
     m->post.on = true;
     if (m->head_last == -2) m->find_head_last();
+    if (!m->capture_side.side) {      // (attach is never called inside a capture: it is host-side set-up)
+        OM_CHECK_HIP(hipStreamCreateWithFlags(&m->capture_side.side, hipStreamNonBlocking));
+        OM_CHECK_HIP(hipEventCreateWithFlags(&m->capture_side.ev_fork, hipEventDisableTiming));
+        OM_CHECK_HIP(hipEventCreateWithFlags(&m->capture_side.ev_join, hipEventDisableTiming));
+    }
     return OM_OK;
 }
 

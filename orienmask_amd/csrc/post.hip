@@ -651,7 +651,9 @@ __global__ __launch_bounds__(SEL_THREADS) void post_select_kernel(const PostPara
         const float bh = expf_cr(q[3]) * (p.cfg.anchor_h[aid] / (float)p.cfg.image_h);
         s_bx[tid] = bx; s_by[tid] = by; s_bw[tid] = bw; s_bh[tid] = bh;
         if (p.cand_dets) {      // the candidate list itself, at its LIST position: what the reference hands to self.nms
-            const size_t o = (size_t)b * nms_pre + pos;
+            // (more than SEL_LIST_MAX passing pairs: the radix path's `pos` is the index-ordered compaction slot, but such an image
+            // is always case A, whose list is the sorted top-k -- postprocess.py:107-110 -- i.e. the visiting rank)
+            const size_t o = (size_t)b * nms_pre + ((caseA && !from_list) ? tid : pos);
             float* cd = p.cand_dets + o * 5;
             cd[0] = bx; cd[1] = by; cd[2] = bw; cd[3] = bh;
             cd[4] = __uint_as_float((unsigned)(s_comp[tid] >> 32));

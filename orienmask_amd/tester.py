@@ -135,32 +135,46 @@ def infer_loop(model, transform, postprocess, images, device, warmup=10, size_di
     if latency_mode and getattr(model, "precision", None) == "f32_split" and hasattr(model, "set_latency_mode"):
         restore = model.latency_cells
         model.set_latency_mode(True)
+    # Only this package's postprocess with its own NMS can be captured: capture needs the kernel-only `launch` / `collect` split
+    # and its workspace, and a foreign nms_func runs on the host in the middle of the step (a synchronisation, which stream
+    # capture refuses).  Any other callable -- the reference's contract is just `postprocess(model(x))` -- runs eagerly.
+    graphable = (use_graph and all(hasattr(postprocess, a) for a in ("launch", "collect", "_ws"))
+                 and getattr(postprocess, "nms_thresh", None) is not None)
 
     def run(x):
-        if not use_graph:
+        if not graphable:
             return postprocess(model(x))
         key = tuple(x.shape)
         if key not in graphs:
             from .graph import GraphedPipeline
-            graphs[key] = GraphedPipeline(model, postprocess, x) if len(graphs) < 4 else None      # a handful of shapes at most
+            g = None
+            if len(graphs) < 4:      # a handful of shapes at most
+                try:
+                    g = GraphedPipeline(model, postprocess, x)
+                except RuntimeError as e:      # a capture that failed leaves nothing behind: this shape runs eagerly
+                    import warnings
+                    warnings.warn("infer_loop: hipGraph capture failed for input shape %s (%s); running it eagerly" % (key, e))
+            graphs[key] = g
         g = graphs[key]
         if g is None:
             return postprocess(model(x))
         return [{k: v.clone() for k, v in d.items()} for d in g(x)]
 
-    with torch.no_grad():
-        if warmup and images:
-            x, _ = transform.padded(images[0].to(device).unsqueeze(0), size_divisor)
-            for _ in range(warmup):
-                run(x)
-        with _timer.timer("Main Loop"):
-            for img in images:
-                with _timer.timer("Load data"):
-                    x, pad_info = transform.padded(img.to(device).unsqueeze(0), size_divisor)
-                with _timer.timer("Forward & Postprocess"):
-                    det = run(x)
-                results.append(det[0])
-                pads.append(pad_info)
-    if restore is not None:
-        model.set_latency_mode(restore > 0, restore or None)
+    try:
+        with torch.no_grad():
+            if warmup and images:
+                x, _ = transform.padded(images[0].to(device).unsqueeze(0), size_divisor)
+                for _ in range(warmup):
+                    run(x)
+            with _timer.timer("Main Loop"):
+                for img in images:
+                    with _timer.timer("Load data"):
+                        x, pad_info = transform.padded(img.to(device).unsqueeze(0), size_divisor)
+                    with _timer.timer("Forward & Postprocess"):
+                        det = run(x)
+                    results.append(det[0])
+                    pads.append(pad_info)
+    finally:
+        if restore is not None:
+            model.set_latency_mode(restore > 0, restore or None)
     return results, pads, _timer.get_all_elapsed_time()

@@ -1457,6 +1457,24 @@ def test_tester_and_infer_loops(dev):
     dets_e, _, _ = infer_loop(net, tf, post, imgs, dev, warmup=0, use_graph=False)
     for a, b in zip(dets, dets_e):
         assert torch.equal(a["bbox"], b["bbox"]) and torch.equal(a["cls"], b["cls"]) and torch.equal(a["mask"], b["mask"])
+    # the reference's contract for `postprocess` is a callable (infer.py:154-156): a plain function, and a postprocess with a foreign
+    # nms_func (host work in the middle of the step), cannot be captured -- the loop runs them eagerly instead of failing
+    dets_f, _, _ = infer_loop(net, tf, lambda pred: post(pred), imgs, dev, warmup=1)
+    from orienmask_amd.eval import batched_nms
+    import functools
+    post_foreign = _hip_post((544, 544), dev, nms_func=functools.partial(batched_nms, threshold=0.5))
+    dets_g, _, _ = infer_loop(net, tf, post_foreign, imgs, dev, warmup=1)
+    for a, b, c in zip(dets, dets_f, dets_g):
+        assert torch.equal(a["bbox"], b["bbox"]) and torch.equal(a["mask"], b["mask"])
+        assert torch.equal(a["bbox"], c["bbox"]) and torch.equal(a["cls"], c["cls"]) and torch.equal(a["mask"], c["mask"])
+    # latency mode is restored when the loop throws
+    cells = net.latency_cells
+
+    def boom(pred):
+        raise ValueError("postprocess failed")
+    with pytest.raises(ValueError):
+        infer_loop(net, tf, boom, imgs, dev, warmup=0)
+    assert net.latency_cells == cells
 
 
 def test_build_tester_from_checkpoint_file(dev, tmp_path):
@@ -2214,10 +2232,13 @@ def test_coco_strings_packed_on_the_device(dev):
     infos.insert(2, dict(id=7, height=50, width=60))
     dets.insert(2, dict(bbox=torch.zeros((0, 5), device=dev), cls=torch.zeros((0,), dtype=torch.int64, device=dev),
                         mask=torch.zeros((0, 96, 128), dtype=torch.bool, device=dev)))
-    for max_runs, per_mask in ((8192, 4096), (4, 4096), (8192, 3)):
+    for max_runs, per_mask, worst in ((8192, 4096, None), (4, 4096, None), (8192, 3, None), (4, 4096, 1)):
         fmt = COCOFormatter(list(range(1, 81)), with_mask=True)
         fmt.MAX_RUNS, fmt.BYTES_PER_MASK = max_runs, per_mask
+        if worst is not None:
+            fmt.WORST_CASE_BYTES = worst         # every overflowing mask a worst-case launch of its own (the chunked fallback)
         res = fmt.to_coco_format(infos, dets)
+        res = fmt.to_coco_format(infos, dets)    # ... and again from the formatter's cached scratch buffers
         assert len(res["segm"]) == len(res["bbox"]) == len(want)
         for s, b, (iid, size, counts, box) in zip(res["segm"], res["bbox"], want):
             assert s["image_id"] == b["image_id"] == iid and s["segmentation"]["size"] == size and b["bbox"] == box
@@ -2235,7 +2256,7 @@ def test_coco_strings_packed_on_the_device(dev):
 # ------------------------------------------------------------------------------------------------
 # the two generalities of the reference's postprocess the fused path used to refuse
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("regime,seed", [("mixed", 201), ("sparse_many", 202), ("clustered", 203), ("empty", 204)])
+@pytest.mark.parametrize("regime,seed", [("mixed", 201), ("sparse_many", 202), ("clustered", 203), ("empty", 204), ("dense", 205)])
 def test_postprocess_foreign_nms_callable(dev, regime, seed):
     """nms_func may be ANY callable (dets[n,5], cls[n]) -> (dets[keep], cls[keep], keep), as in the reference
     (/root/reference/eval/orienmask_yolo_postprocess.py:9-11,146-154).  (a) a plain function that happens to do batched_nms: the
