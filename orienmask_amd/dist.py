@@ -4,7 +4,8 @@ The reference has no multi-GPU inference (assert n_gpu <= 1, /root/reference/tes
 /root/reference/infer.py:69); images are independent through forward and postprocess
 (/root/reference/eval/orienmask_yolo_postprocess.py:75 loops per image), so the path shards with no
 data-path collective.  The only collective is one broadcast of rank 0's packed weight blob
-(63.67 M weights plus the Winograd transforms of the 3x3 layers: 1.16 GB; in the default split-operand precision also the hi/lo fp16 form of every layer's weights) over RCCL/xGMI at start-up -- not in the timed region.  Results are merged
+(63.67 M weights plus the Winograd transforms of the 3x3 layers: 1.16 GB; in the default split-operand precision also
+the hi/lo fp16 form of every layer's weights, 0.66 GB: 1.82 GB in two blobs) over RCCL/xGMI at start-up -- not in the timed region.  Results are merged
 on the host per rank, as the reference's validation does with its _temp_coco_eval_%d.json files
 (/root/reference/trainer/trainer.py:175-181,201-205).
 """

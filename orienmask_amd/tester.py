@@ -78,6 +78,29 @@ class Tester:
         return stats
 
 
+    def test_and_gather(self, verbose=True, in_flight=1):
+        """The multi-GPU form of `test`: every rank evaluates ITS slice of the loader (SyntheticLoader and
+        tools/eval_val2017.py's Val2017Loader take contiguous slices by dist.shard_range) and whatever `on_batch` RETURNS per
+        batch (a record or a list of records, any picklable objects) is merged in rank order on every rank -- rank-order
+        concatenation of contiguous slices is dataset order.  This is /root/reference/trainer/trainer.py:175-181,201-205 (each
+        rank writes _temp_coco_eval_<rank>.json, rank 0 concatenates them) without the files.  No collective in the step: one
+        all_gather_object of host lists at the end.  Returns (this rank's stats, the merged records)."""
+        from .dist import gather_detections
+        records = []
+        user = self.on_batch
+
+        def collect(batch_info, detections):
+            r = user(batch_info, detections) if user is not None else None
+            if r is not None:
+                records.extend(r if isinstance(r, list) else [r])
+
+        self.on_batch = collect
+        try:
+            stats = self.test(verbose=verbose, in_flight=in_flight)
+        finally:
+            self.on_batch = user
+        return stats, gather_detections(records)
+
     def _test_in_flight(self, verbose, depth):
         import time
         from .pipeline import InFlightPipeline

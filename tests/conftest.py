@@ -34,6 +34,62 @@ def built():
     return True
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Test-session memoisation (the GPU suite had grown to 600 s of a 1200 s limit, most of it host work
+# repeated per parametrisation).  Test infrastructure only -- the product packs every time it is asked to:
+#   * synth.synth_state_dict(seed, ...): 1.8 s per call, ~40 calls with a dozen distinct arguments;
+#   * pack.pack_state_dict / _split / _f16: 1-2 s each per model built from an already-seen state dict (the two precisions of a
+#     fixture, the two models of an A/B test): keyed by a fingerprint of the CONTENT (every tensor's shape, its first elements
+#     and its float64 sum), so a test that changes a weight gets a fresh pack.
+# Small LRUs: a state dict is 255 MB, a set of packed blobs ~2 GB.
+def _lru(cache, key, make, size):
+    if key in cache:
+        cache[key] = cache.pop(key)          # most recent last
+        return cache[key]
+    val = make()
+    cache[key] = val
+    while len(cache) > size:
+        cache.pop(next(iter(cache)))
+    return val
+
+
+def _fingerprint(sd):
+    import torch
+    parts = []
+    for k, v in sd.items():
+        if torch.is_tensor(v):
+            f = v.detach().reshape(-1)
+            parts.append((k, tuple(v.shape), str(v.dtype), f[:4].double().tolist(), float(f.double().sum()) if f.numel() else 0.0))
+        else:
+            parts.append((k, repr(v)))
+    return hash(repr(parts))
+
+
+def _install_memo():
+    from orienmask_amd import pack, synth
+    if getattr(synth.synth_state_dict, "_memo", False):
+        return
+    sd_cache, blob_cache = {}, {}
+    raw_synth = synth.synth_state_dict
+
+    def synth_state_dict(*a, **kw):
+        return dict(_lru(sd_cache, (a, tuple(sorted(kw.items()))), lambda: raw_synth(*a, **kw), 4))      # tensors shared: never written by tests
+
+    synth_state_dict._memo = True
+    synth.synth_state_dict = synth_state_dict
+    for name in ("pack_state_dict", "pack_state_dict_split", "pack_state_dict_f16"):
+        raw = getattr(pack, name)
+
+        def packed(state_dict, layers, total, _raw=raw, _name=name):
+            key = (_name, _fingerprint(pack.unwrap_checkpoint(state_dict)), int(total), len(layers))
+            return _lru(blob_cache, key, lambda: _raw(state_dict, layers, total), 6).clone()
+
+        setattr(pack, name, packed)
+
+
+_install_memo()
+
+
 def golden_files(prefix):
     return sorted(f for f in os.listdir(GOLDEN) if f.startswith(prefix) and f.endswith(".npz"))
 

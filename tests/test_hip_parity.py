@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, fixture_weights_and_input, golden_files, post_cfg
+from conftest import GOLDEN, REPO, fixture_weights_and_input, golden_files, post_cfg
 from oracle import orienmask_ref as R
 from orienmask_amd import lib as omlib
 from orienmask_amd import synth
@@ -2434,3 +2434,31 @@ def test_latency_mode_matches_reference_golden(dev, fname):
             off = net(big)
             assert all(torch.equal(a, c) and torch.equal(b, d) for (a, b), (c, d) in zip(on, off))
     net.set_latency_mode(False)
+
+
+def test_eval_val2017_harness_synthetic(dev, tmp_path):
+    """tools/eval_val2017.py --synthetic: the val2017 evaluation (test.py:18-29 -> trainer/tester.py:26-52 -> eval/coco_eval.py:
+    57-63,80-127) up to the two json files pycocotools would be handed -- keys, counts, one entry per detection in image order,
+    boxes inside their images, and every RLE string decodable to exactly size[0] * size[1] pixels by the CPU restatement of
+    pycocotools' string format (oracle/rle_ref.c).  No AP: neither COCO nor pycocotools exist offline (exit code 3 says so)."""
+    import json
+    import subprocess
+    import sys
+    out = tmp_path / "val"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "eval_val2017.py"), "--synthetic", "4", "--batch", "4", "--out", str(out)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
+    summary = json.load(open(out / "ap.json"))
+    bbox = json.load(open(out / "bbox_prediction.json"))
+    segm = json.load(open(out / "segm_prediction.json"))
+    assert summary["images"] == 4 and summary["ranks"] == 1 and summary["detections"] == len(bbox) == len(segm) > 0
+    assert summary["verdict"].startswith("synthetic dry run")
+    assert [b["image_id"] for b in bbox] == sorted(b["image_id"] for b in bbox) and set(b["image_id"] for b in bbox) <= {0, 1, 2, 3}
+    for b, s in zip(bbox, segm):
+        assert set(b) == {"image_id", "category_id", "bbox", "score"} and set(s) == {"image_id", "category_id", "segmentation", "score"}
+        assert b["image_id"] == s["image_id"] and b["category_id"] == s["category_id"] and b["score"] == s["score"]
+        assert 1 <= b["category_id"] <= 90 and 0.0 < b["score"] <= 1.0 and len(b["bbox"]) == 4 and b["bbox"][2] >= 0 and b["bbox"][3] >= 0
+        assert s["segmentation"]["size"] == [544, 544]
+    for s in segm[:40]:
+        runs = R.rle_string_decode(s["segmentation"]["counts"], 544 * 544)      # asserts the runs cover the image exactly
+        assert all(c >= 0 for c in runs)

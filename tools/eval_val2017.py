@@ -73,7 +73,12 @@ class Val2017Loader:
         else:                                                     # plain COCO layout: every image of instances_val2017.json
             gt = json.load(open(os.path.join(self.root, "annotations", "instances_val2017.json")))
             items = [(im["file_name"], im["id"]) for im in sorted(gt["images"], key=lambda im: im["id"])]
-        return items[:limit] if limit else items
+        items = items[:limit] if limit else items
+        from orienmask_amd.dist import shard_range, world_info
+        rank, world = world_info()                       # one process per GPU: this rank's contiguous slice of the image list
+        start, stop = shard_range(len(items), rank, world)
+        self.total = len(items)
+        return items[start:stop]
 
     def __len__(self):
         return (len(self.items) + self.batch_size - 1) // self.batch_size
@@ -132,6 +137,14 @@ def main():
     from orienmask_amd.tester import SyntheticLoader
     if not torch.cuda.is_available():
         raise SystemExit("eval_val2017.py needs an MI355X (the product has no CPU path)")
+    # one process per GPU (python -m torch.distributed.run --nproc-per-node N tools/eval_val2017.py ...): every rank evaluates its
+    # slice of the image list, rank 0 merges and scores -- /root/reference/trainer/trainer.py:175-181,201-205
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
     dev = torch.device("cuda", torch.cuda.current_device())
     os.makedirs(args.out, exist_ok=True)
     if args.synthetic:
@@ -146,24 +159,26 @@ def main():
             ckpt = {"state_dict": sd, "config": {"model": dict(DEFAULT_MODEL)}}
         loader = Val2017Loader(args.coco_root, args.batch, limit=args.limit, device=dev)
     fmt = COCOFormatter(CAT2LABEL, with_mask=True)
-    results = {"bbox": [], "segm": []}
 
     def on_batch(batch_info, detections):
-        r = fmt.to_coco_format(batch_info, detections)
-        results["bbox"] += r["bbox"]
-        results["segm"] += r["segm"]
+        return fmt.to_coco_format(batch_info, detections)          # {'bbox': [...], 'segm': [...]} of this batch
 
     tester = build_tester(TEST_CONFIG, ckpt, loader, device=dev, on_batch=on_batch)
     if args.precision:
         tester.model.set_precision(args.precision)
     t0 = time.perf_counter()
-    stats = tester.test(verbose=True, in_flight=args.in_flight)
+    stats, merged = tester.test_and_gather(verbose=rank == 0, in_flight=args.in_flight)
     wall = time.perf_counter() - t0
+    results = {"bbox": [r for part in merged for r in part["bbox"]], "segm": [r for part in merged for r in part["segm"]]}
+    if rank != 0:                 # rank 0 writes and scores
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return 0
     for kind in ("bbox", "segm"):
         with open(os.path.join(args.out, "%s_prediction.json" % kind), "w") as f:
             json.dump(results[kind], f)
-    n_img = sum(len(b[2]) for b in loader)  if args.synthetic else len(loader.items)
-    summary = dict(images=n_img, detections=len(results["bbox"]), wall_s=round(wall, 2), precision=tester.model.precision,
+    n_img = args.synthetic if args.synthetic else loader.total
+    summary = dict(images=n_img, ranks=world, detections=len(results["bbox"]), wall_s=round(wall, 2), precision=tester.model.precision,
                    speed=stats, reference_ap=REFERENCE_AP)
     rc = 3
     gt_file = os.path.join(args.coco_root, "annotations", "instances_val2017.json")
@@ -188,6 +203,8 @@ def main():
     with open(os.path.join(args.out, "ap.json"), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps({k: v for k, v in summary.items() if k != "speed"}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
     return rc
 
 
