@@ -232,6 +232,8 @@ def plumbing_only(args, world, rank):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--no-solo-reference", action="store_true",
+                    help="N > 1: skip rank 0's solo run of the same steps (the denominator of `scaling_efficiency`)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="no GPU work: run only the N-rank launcher / rendezvous / broadcast / timing reduction on gloo (CPU test of --gpus N)")
     ap.add_argument("--gpus", type=int, default=1)
@@ -372,6 +374,35 @@ def main():
     for _ in range(args.warmup):
         dets = step()
     torch.cuda.synchronize()
+
+    # ---- N > 1: rank 0 alone (every other GPU idle at the barrier) runs the K steps one batch at a time and with batches in
+    # flight: the SAME binary's single-GPU figures, which `scaling_efficiency` divides by
+    solo = None
+    if use_dist and (world > 1 or os.environ.get("OM_BENCH_FORCE_DIST") == "1") and not args.no_solo_reference:
+        dist.barrier()
+        if rank == 0:
+            import itertools
+            from orienmask_amd.pipeline import InFlightPipeline
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                dets = step()
+            torch.cuda.synchronize()
+            solo_serial = time.perf_counter() - t0
+            solo_flight = solo_serial
+            if args.in_flight > 1:
+                pipe0 = InFlightPipeline(net, post, depth=args.in_flight, fuse_step=args.fuse_step)
+                for dets in pipe0.map(batches(2 * args.in_flight)):
+                    pass
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for dets in pipe0.map(batches(args.steps)):
+                    pass
+                torch.cuda.synchronize()
+                solo_flight = time.perf_counter() - t0
+                del pipe0
+            solo = dict(value=round(B * args.steps / solo_flight, 2), one_batch_in_flight=round(B * args.steps / solo_serial, 2))
+        dist.barrier()
 
     # ---- untimed pass with events around EVERY layer: the per-kernel table, and which kernel dominates
     specs = {s.name: s for s in arch.fpnplus_convs()}
@@ -788,10 +819,14 @@ def main():
                     vs_baseline=None, dtype=dtype_out, precision=args.dtype, plugin_default_precision=DEFAULT_PRECISION,
                     data="synthetic (two seeded input batches taken in turn)",
                     rccl_ranks=world if use_dist else 0,
+                    per_rank_value=[round(B * args.steps / t, 2) for t in per_rank],       # images/s of every rank's own steps
+                    scaling_efficiency=(round(total_images / elapsed / (world * solo["value"]), 4) if solo else None),
+                    solo_reference=solo,      # rank 0 alone on this node, same binary, same steps (null at N = 1: `value` is it)
                     rank_ms_per_step=dict(min=round(min(per_rank) / args.steps * 1e3, 3), max=round(max(per_rank) / args.steps * 1e3, 3),
                                           one_batch_in_flight_min=round(min(per_rank_serial) / args.steps * 1e3, 3),
                                           one_batch_in_flight_max=round(max(per_rank_serial) / args.steps * 1e3, 3)),
                     weight_broadcast=dict(bytes=bc_stats.get("bytes"), ms=bc_stats.get("ms"), blobs=bc_stats.get("blobs"),
+                                          gbs=(round(bc_stats["bytes"] / (bc_stats["ms"] * 1e-3) / 1e9, 1) if bc_stats.get("ms") else None),
                                           backend="rccl" if use_dist else "none (single rank: packed on the host, copied to the GPU)",
                                           note="rank 0's packed weights to every rank, once, before any timed region"),
                     config=dict(workload="OrienMaskYOLOFPNPlus forward + OrienMaskYOLOPostProcess, %d x [3,%d,%d] per GPU "

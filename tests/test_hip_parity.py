@@ -2462,3 +2462,31 @@ def test_eval_val2017_harness_synthetic(dev, tmp_path):
     for s in segm[:40]:
         runs = R.rle_string_decode(s["segmentation"]["counts"], 544 * 544)      # asserts the runs cover the image exactly
         assert all(c >= 0 for c in runs)
+
+
+def test_bench_line_with_the_rccl_path_on_one_gpu(dev):
+    """`bench.py` end to end as the driver runs it (a short one: 3 steps), with the N > 1 code path forced on ONE GPU
+    (OM_BENCH_FORCE_DIST=1: nccl process group of one rank, weight broadcast, rank 0's solo reference run, per-rank reduction): the
+    line carries BASELINE.json's metric, `roofline` with the like-for-like figures up front, and the multi-GPU fields of VERDICT
+    round 4, item 8 -- at one rank `scaling_efficiency` is the timed region over the solo run of the same steps, i.e. ~1."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, OM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
+                        "--no-f32-compare", "--no-f16-compare", "--no-small-batch"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["metric"].startswith("images/sec end-to-end (544^2, bs=32)") and line["unit"] == "images/s" and line["n_gpus"] == 1
+    assert line["rccl_ranks"] == 1 and line["value"] > 0 and line["one_batch_in_flight_value"] > 0
+    assert len(line["per_rank_value"]) == 1 and abs(line["per_rank_value"][0] - line["value"]) < 1e-6 * line["value"] + 0.02
+    assert line["solo_reference"]["value"] > 0 and 0.8 < line["scaling_efficiency"] < 1.25
+    assert line["weight_broadcast"]["blobs"] == 2 and line["weight_broadcast"]["gbs"] > 0
+    rf = line["roofline"]
+    assert list(rf)[:9] == ["bound", "achieved", "peak", "unit", "frac", "traffic", "frac_counts", "achieved_algorithmic", "algorithmic_frac"]
+    assert rf["kernel"].startswith("wino14_split_kernel") and 0 < rf["algorithmic_frac"] < rf["frac"] < 1
+    assert rf["one_batch_in_flight_images_per_s"] == line["one_batch_in_flight"]["value"]
