@@ -26,7 +26,18 @@
 
 namespace om {
 
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// o += a * c, one scalar fused multiply-add per element.  NOT `o += a * c` on the vector types: hipcc packs that into v_pk_fma_f32
+// with a source-half selection (op_sel_hi) on the register that holds c, and on gfx950 a packed fp32 instruction with a register
+// half-selection returns wrong lanes now and then while another wave on the same SIMD issues wide-K matrix instructions
+// (tools/hazard_probe/pk_opsel_repro.hip, profiles/r05_experiments.md 2).  This file is built with -fno-slp-vectorize for the same reason.
+__device__ __forceinline__ void axpy16(f32x16& o, const f32x16& a, float c) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = __builtin_fmaf(a[r], c, o[r]);
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -299,10 +310,10 @@ __global__ __launch_bounds__(256) void wino_gemm_kernel(const WinoParams p) {
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b) {
-                        if (c00 != 0.f) outa[0][0][a][b] += acc[a][b] * c00;
-                        if (c01 != 0.f) outa[0][1][a][b] += acc[a][b] * c01;
-                        if (c10 != 0.f) outa[1][0][a][b] += acc[a][b] * c10;
-                        if (c11 != 0.f) outa[1][1][a][b] += acc[a][b] * c11;
+                        if (c00 != 0.f) axpy16(outa[0][0][a][b], acc[a][b], c00);
+                        if (c01 != 0.f) axpy16(outa[0][1][a][b], acc[a][b], c01);
+                        if (c10 != 0.f) axpy16(outa[1][0][a][b], acc[a][b], c10);
+                        if (c11 != 0.f) axpy16(outa[1][1][a][b], acc[a][b], c11);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
                     }
@@ -505,9 +516,16 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoParams p) 
         auto write_row = [&](int j, int abuf) {
             const int i = a_xi >> 2, jj = a_xi & 3;
             const float sa = sgn_a(i), sb = sgn_b(i), ca_ = sgn_a(jj), cb_ = sgn_b(jj);
-            const f32x4 top = L[0] * ca_ + L[1] * cb_;
-            const f32x4 bot = L[2] * ca_ + L[3] * cb_;
-            smem[abuf * A_BUF + (lrow + 32 * j) * 8 + lsw] = top * sa + bot * sb;
+            // (element by element: a vector times a scalar in a register becomes a packed instruction with a source-half selection,
+            // see axpy16)
+            f32x4 out;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float top = __builtin_fmaf(L[0][e], ca_, L[1][e] * cb_);
+                const float bot = __builtin_fmaf(L[2][e], ca_, L[3][e] * cb_);
+                out[e] = __builtin_fmaf(top, sa, bot * sb);
+            }
+            smem[abuf * A_BUF + (lrow + 32 * j) * 8 + lsw] = out;
         };
         auto issue_b = [&](int piece, int bbuf, bool live) {
             const float* bbase = p.U + (size_t)n_xi * u_plane + (size_t)n0 * p.C;
@@ -606,10 +624,10 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoParams p) 
                 const float c00 = ci0 * cj0, c01 = ci0 * cj1, c10 = ci1 * cj0, c11 = ci1 * cj1;
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
-                    if (c00 != 0.f) outa[0][0][b] += acc[b] * c00;
-                    if (c01 != 0.f) outa[0][1][b] += acc[b] * c01;
-                    if (c10 != 0.f) outa[1][0][b] += acc[b] * c10;
-                    if (c11 != 0.f) outa[1][1][b] += acc[b] * c11;
+                    if (c00 != 0.f) axpy16(outa[0][0][b], acc[b], c00);
+                    if (c01 != 0.f) axpy16(outa[0][1][b], acc[b], c01);
+                    if (c10 != 0.f) axpy16(outa[1][0][b], acc[b], c10);
+                    if (c11 != 0.f) axpy16(outa[1][1][b], acc[b], c11);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
                 }

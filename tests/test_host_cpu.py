@@ -478,3 +478,44 @@ def test_wino14d_isa_audit(tmp_path):
                             lo, hi = int(d.group(1)), int(d.group(2) or d.group(1))
                             assert not (ops & set(range(lo, hi + 1))), (prev, ins)
     del lines
+
+
+def test_no_packed_fp32_register_half_select(tmp_path):
+    """gfx950 erratum found in round 5 (tools/hazard_probe/pk_opsel_repro.hip, profiles/r05_experiments.md 2): v_pk_add/mul/fma_f32
+    with a source-half selection (op_sel / op_sel_hi) on a REGISTER operand returns wrong lanes now and then while another wave on
+    the same SIMD issues wide-K matrix instructions -- which this library's kernels do on every other stream.  hipcc emits the form
+    when it packs scalar code (SLP) or broadcasts a scalar into vector arithmetic.  No kernel of the library may contain one: every
+    source file is compiled with the Makefile's flags and its gfx950 code scanned (constants may be half-selected, registers not)."""
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    csrc = os.path.join(REPO, "orienmask_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    nopk = re.search(r"^NOPK = (.*)$", mk, re.M).group(1)
+    extra = {m.group(1): m.group(2).replace("$(NOPK)", nopk) for m in re.finditer(r"^EXTRA_(\w+) = (.*)$", mk, re.M)}
+    files = sorted(f[:-4] for f in os.listdir(csrc) if f.endswith(".hip"))
+    assert len(files) >= 13
+
+    def scan(name):
+        out = str(tmp_path / (name + ".s"))
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only"] + \
+            extra.get(name, "").split() + [os.path.join(csrc, name + ".hip"), "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        bad = []
+        for line in open(out):
+            ins = line.split(";")[0].strip()
+            if not re.match(r"v_pk_(add|mul|fma)_f32", ins) or "op_sel" not in ins:
+                continue
+            n = 3 if "fma" in ins else 2
+            sel = re.search(r"op_sel:\[([0-9,]+)\]", ins)
+            selhi = re.search(r"op_sel_hi:\[([0-9,]+)\]", ins)
+            s = [int(v) for v in sel.group(1).split(",")] if sel else [0] * n
+            sh = [int(v) for v in selhi.group(1).split(",")] if selhi else [1] * n
+            srcs = re.findall(r"(v\[\d+:\d+\]|s\[\d+:\d+\]|-?\d+\.?\d*|0x[0-9a-f]+|v\d+|s\d+)", ins.split(None, 1)[1])[1:1 + n]
+            if any(i < len(srcs) and srcs[i].startswith("v[") and (s[i] != 0 or sh[i] != 1) for i in range(n)):
+                bad.append(ins)
+        return name, bad
+
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        results = list(ex.map(scan, files))
+    assert all(not bad for _, bad in results), {n: b[:3] for n, b in results if b}

@@ -9,7 +9,7 @@ mkdir -p $B
 cd $R/orienmask_amd/csrc
 OBJS=""
 for F in conv_igemm conv_igemm_f16 conv3x3_f16 conv_wino conv_wino24 conv_wino14 conv_wino14d conv_igemm_split conv_stem conv_stem2 preprocess coco_format post; do
-  EX=""; case "$F" in post|preprocess|coco_format) EX="-ffp-contract=off";; esac
+  EX=""; case "$F" in post|preprocess|coco_format) EX="-ffp-contract=off -fno-slp-vectorize";; conv_stem|conv_wino|conv_wino24) EX="-fno-slp-vectorize";; esac
   FL=""
   if [ $# -eq 0 ] || [[ " $* " == *" $F "* ]]; then FL="$FLAGS"; fi
   if [ -z "$FL" ] && [ -f build/$F.o ]; then OBJS="$OBJS build/$F.o"; continue; fi

@@ -51,6 +51,69 @@ __global__ __launch_bounds__(256) void probe_kernel(const float* __restrict__ se
                 const bool inside = (fabsf(Px[e] - d.x) < d.z) && (fabsf(Py[e] - d.y) < d.w);
                 packed[e >> 2] |= (inside ? 1u : 0u) << ((e & 3) * 8);
             }
+        } else if constexpr (FORM == 8) {
+            // the compare form exactly as form 0, but the differences are formed by scalar v_sub_f32 (opaque asm: the compiler cannot
+            // pack them into v_pk_add_f32): do the failures need the packed subtractions in front of the compares?
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float dx, dy;
+                asm("v_sub_f32 %0, %1, %2" : "=v"(dx) : "v"(Px[e]), "v"(d.x));
+                asm("v_sub_f32 %0, %1, %2" : "=v"(dy) : "v"(Py[e]), "v"(d.y));
+                const bool inside = (fabsf(dx) < d.z) && (fabsf(dy) < d.w);
+                packed[e >> 2] |= (inside ? 1u : 0u) << ((e & 3) * 8);
+            }
+        } else if constexpr (FORM == 9) {
+            // hand-written: PACKED subtractions (v_pk_add_f32 with neg modifiers, as the compiler emits them) straight in front of
+            // v_cmp_lt_f32_e64 into SGPR pairs, s_and_b64, v_cndmask -- no wait states anywhere
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                float2 ax, ay;
+                const float2 px = {Px[e], Px[e + 1]}, py = {Py[e], Py[e + 1]};
+                const float2 cx = {d.x, d.x}, cy = {d.y, d.y};
+                unsigned long long m0, m1, m2, m3, b0, b1;
+                unsigned bit0, bit1;
+                asm volatile("v_pk_add_f32 %0, %2, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                             "v_pk_add_f32 %1, %3, %5 neg_lo:[0,1] neg_hi:[0,1]"
+                             : "=&v"(ax), "=&v"(ay) : "v"(px), "v"(py), "v"(cx), "v"(cy));
+                asm volatile("v_cmp_lt_f32_e64 %0, |%8|, %12\n\t"
+                             "v_cmp_lt_f32_e64 %1, |%9|, %12\n\t"
+                             "v_cmp_lt_f32_e64 %2, |%10|, %13\n\t"
+                             "v_cmp_lt_f32_e64 %3, |%11|, %13\n\t"
+                             "s_and_b64 %4, %0, %2\n\t"
+                             "s_and_b64 %5, %1, %3\n\t"
+                             "v_cndmask_b32_e64 %6, 0, 1, %4\n\t"
+                             "v_cndmask_b32_e64 %7, 0, 1, %5"
+                             : "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(b0), "=&s"(b1), "=&v"(bit0), "=&v"(bit1)
+                             : "v"(ax.x), "v"(ax.y), "v"(ay.x), "v"(ay.y), "v"(d.z), "v"(d.w) : "scc");
+                packed[e >> 2] |= bit0 << ((e & 3) * 8);
+                packed[(e + 1) >> 2] |= bit1 << (((e + 1) & 3) * 8);
+            }
+        } else if constexpr (FORM == 10 || FORM == 11) {
+            // the compiler's PACKED subtractions verbatim (one register pair holds (cx, cy); op_sel_hi:[1,0] broadcasts cx, op_sel:[0,1]
+            // broadcasts cy), in asm; behind them form 10 evaluates the predicate on bit patterns in VGPRs (no compare at all), form 11
+            // with the compiler's floating-point compares
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                float2 ax, ay;
+                const float2 px = {Px[e], Px[e + 1]}, py = {Py[e], Py[e + 1]};
+                const float2 cxy = {d.x, d.y};
+                asm volatile("v_pk_add_f32 %0, %2, %4 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                             "v_pk_add_f32 %1, %3, %4 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]"
+                             : "=&v"(ax), "=&v"(ay) : "v"(px), "v"(py), "v"(cxy));
+                const float dxs[2] = {ax.x, ax.y}, dys[2] = {ay.x, ay.y};
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    unsigned bit;
+                    if constexpr (FORM == 10) {
+                        const unsigned tx = threshold_bits(d.z), ty = threshold_bits(d.w);
+                        const unsigned bx = __float_as_uint(dxs[k]) & 0x7fffffffu, by = __float_as_uint(dys[k]) & 0x7fffffffu;
+                        bit = (sub_u32_opaque(bx, tx) & sub_u32_opaque(by, ty)) >> 31;
+                    } else {
+                        bit = ((fabsf(dxs[k]) < d.z) && (fabsf(dys[k]) < d.w)) ? 1u : 0u;
+                    }
+                    packed[(e + k) >> 2] |= bit << (((e + k) & 3) * 8);
+                }
+            }
         } else if constexpr (FORM == 2) {
             // every compare goes VOPC -> VCC -> v_cndmask at once (the opaque asm keeps the compiler from merging lane masks)
 #pragma unroll
@@ -177,6 +240,10 @@ extern "C" int probe_launch(int form, const float* seed, const float4* dets, int
     else if (form == 4) hipLaunchKernelGGL(probe_kernel<4>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
     else if (form == 5) hipLaunchKernelGGL(probe_kernel<5>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
     else if (form == 6) hipLaunchKernelGGL(probe_kernel<6>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
-    else hipLaunchKernelGGL(probe_kernel<7>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
+    else if (form == 7) hipLaunchKernelGGL(probe_kernel<7>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
+    else if (form == 8) hipLaunchKernelGGL(probe_kernel<8>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
+    else if (form == 9) hipLaunchKernelGGL(probe_kernel<9>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
+    else if (form == 10) hipLaunchKernelGGL(probe_kernel<10>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
+    else hipLaunchKernelGGL(probe_kernel<11>, dim3(blocks), dim3(256), 0, s, seed, dets, n, out);
     return (int)hipGetLastError();
 }

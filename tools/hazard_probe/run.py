@@ -7,7 +7,8 @@ v_cndmask; arithmetic: bit patterns in VGPRs; vcc: VOPC -> VCC -> v_cndmask; bra
 second HIP stream runs, in turn: kernels that only issue one matrix instruction on registers, one fp16 / fp32 3x3 convolution of
 this library, rocBLAS GEMMs, an elementwise kernel; and counts the output words that differ from the launch that ran alone.  Also
 checks that the forms agree bit for bit on random and special operands (NaN, +-inf, denormals, +-0, negative and NaN thresholds).
-Result on MI355X (ROCm 7.2): profiles/r02_experiments.md section 6.
+Result on MI355X (ROCm 7.2): profiles/r02_experiments.md section 6; root cause (round 5: the compiler's PACKED subtractions with a
+register half-selection, forms 8-11; not the compares): profiles/r05_experiments.md section 2, pk_opsel_repro.hip.
 """
 import ctypes
 import os
@@ -96,7 +97,7 @@ NEIGHBOURS = [
     ("elementwise sin over 64 M floats", lambda s: torch.sin(big), 12),
 ]
 
-FORMS = ("compare", "arithmetic", "vcc", "branches", "asm+0nop", "asm+5nop", "asm+16nop", "asm vcc interleaved")
+FORMS = ("compare", "arithmetic", "vcc", "branches", "asm+0nop", "asm+5nop", "asm+16nop", "asm vcc interleaved", "compare, scalar subs", "asm packed subs", "op_sel packed subs + VGPR predicate", "op_sel packed subs + compares")
 with torch.cuda.stream(s0):
     refs = [probe(f) for f in range(len(FORMS))]
 torch.cuda.synchronize()
