@@ -61,6 +61,30 @@ _WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0
 _WINO_G6 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
                          [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
 
+# Every function below computes ON THE DEVICE ITS WEIGHTS ARE ON (a model moved to the GPU packs there: 0.6 s instead of the
+# 12 s the host takes for the three blobs) and returns tensors on that device.  The arithmetic is written so that both devices
+# produce the same bits: float64 elementwise products and sums in a fixed order (no einsum / GEMM, whose summation order is the
+# library's), exponents through frexp and powers of two built from their bit patterns (no log2 / pow).
+
+
+def _apply3(x, g):
+    """x: the three operands [3][...] (float64) -> [J][...]: y[j] = (x[0] g[j][0] + x[1] g[j][1]) + x[2] g[j][2], in that order
+    (scalar times contiguous plane: the same IEEE operations on the host and on the GPU)."""
+    rows = g.tolist()
+    return torch.stack([(x[0] * r[0] + x[1] * r[1]) + x[2] * r[2] for r in rows])
+
+
+def _pow2(e):
+    """2^e as float64 for an integer-valued tensor e in [-1000, 1000], exactly (the exponent field written directly)."""
+    return ((e.to(torch.int64) + 1023) << 52).view(torch.float64)
+
+
+def _pow2_exponent(amax):
+    """Exponents e (float64 tensor) that put each magnitude into [2^13, 2^14); 0 where it is zero."""
+    amax = amax.double()
+    ex = torch.frexp(amax).exponent.double()                     # amax = m 2^ex, m in [0.5, 1): floor(log2 amax) = ex - 1
+    return torch.where(amax > 0, 14 - ex, torch.zeros_like(amax)).clamp(-100, 100)
+
 
 def winograd_weights(w, cout_pad, planes=16):
     """[cout,cin,3,3] -> U [planes][cout_pad][cin] float32 (rows >= cout zero), computed in float64.
@@ -68,9 +92,10 @@ def winograd_weights(w, cout_pad, planes=16):
     (i: transform index down the rows, j: along the columns)."""
     cout, cin = w.shape[0], w.shape[1]
     gx = _WINO_G if planes == 16 else _WINO_G6
-    u = torch.einsum("ir,ncrs,js->ijnc", _WINO_G, w.detach().double().cpu(), gx).reshape(planes, cout, cin)
-    out = torch.zeros(planes, cout_pad, cin, dtype=torch.float32)
-    out[:, :cout] = u.float()
+    t = _apply3(w.detach().double().permute(3, 2, 0, 1).contiguous(), gx)          # [s][r][n][c] -> [j][r][n][c]
+    u = _apply3(t.transpose(0, 1), _WINO_G)                                          # [r][j][n][c] -> [i][j][n][c]
+    out = torch.zeros(planes, cout_pad, cin, dtype=torch.float32, device=w.device)
+    out[:, :cout] = u.reshape(planes, cout, cin).float()
     return out
 
 
@@ -81,27 +106,32 @@ def folded_epilogue(sd, l):
     if l["has_bn"]:
         w = sd[name + ".conv_block.0.weight"]
         p = name + ".conv_block.1."
-        gamma, beta = sd[p + "weight"].double().cpu(), sd[p + "bias"].double().cpu()
-        mean, var = sd[p + "running_mean"].double().cpu(), sd[p + "running_var"].double().cpu()
+        gamma, beta = sd[p + "weight"].double(), sd[p + "bias"].double()
+        mean, var = sd[p + "running_mean"].double(), sd[p + "running_var"].double()
         scale = gamma / torch.sqrt(var + BN_EPS)
         shift = beta - mean * scale
     else:
         w = sd[name + ".weight"]
-        scale = torch.ones(cout, dtype=torch.float64)
-        shift = sd[name + ".bias"].double().cpu()
-    return w, scale, shift
+        scale = torch.ones(cout, dtype=torch.float64, device=w.device)
+        shift = sd[name + ".bias"].double()
+    return w, scale.to(w.device), shift.to(w.device)
+
+
+def _blob_device(sd, layers):
+    l = layers[0]
+    return sd[l["name"] + (".conv_block.0.weight" if l["has_bn"] else ".weight")].device
 
 
 def pack_state_dict(state_dict, layers, total_floats):
-    """Returns a CPU float32 tensor of total_floats elements laid out as the graph expects."""
+    """Returns a float32 tensor of total_floats elements laid out as the graph expects (on the weights' device)."""
     sd = unwrap_checkpoint(state_dict)
-    blob = torch.zeros(total_floats, dtype=torch.float32)
+    blob = torch.zeros(total_floats, dtype=torch.float32, device=_blob_device(sd, layers))
     for l in layers:
         name, cin, cout, cpad, k = l["name"], l["cin"], l["cout"], l["cout_pad"], l["ksize"]
         w, scale, shift = folded_epilogue(sd, l)
         if tuple(w.shape) != (cout, cin, k, k):
             raise _lib.OrienMaskHipError("%s: weight shape %s, expected %s" % (name, tuple(w.shape), (cout, cin, k, k)))
-        ohwi = w.detach().float().cpu().permute(0, 2, 3, 1).reshape(cout, k * k * cin)
+        ohwi = w.detach().float().permute(0, 2, 3, 1).reshape(cout, k * k * cin)
         blob[l["w_off"]:l["w_off"] + cout * k * k * cin] = ohwi.reshape(-1)
         blob[l["scale_off"]:l["scale_off"] + cout] = scale.float()
         blob[l["shift_off"]:l["shift_off"] + cout] = shift.float()
@@ -117,16 +147,16 @@ def conv_weights_f16(w, cout_pad):
     """[cout,cin,k,k] -> fp16 [cout_pad][k*k*cin] (OHWI, rows >= cout zero): the fp16 path's weight rows
     (include/orienmask_hip.h: om_layer_info.w16_off)."""
     cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
-    out = torch.zeros(cout_pad, k * k * cin, dtype=torch.float16)
-    out[:cout] = w.detach().float().cpu().permute(0, 2, 3, 1).reshape(cout, -1).half()
+    out = torch.zeros(cout_pad, k * k * cin, dtype=torch.float16, device=w.device)
+    out[:cout] = w.detach().float().permute(0, 2, 3, 1).reshape(cout, -1).half()
     return out
 
 
 def pack_state_dict_f16(state_dict, layers, total_halfs):
-    """CPU float16 tensor of total_halfs elements: the convolution weights of every layer but the stem, rounded to
+    """float16 tensor of total_halfs elements (on the weights' device): the convolution weights of every layer but the stem, rounded to
     fp16 (scale / shift / the stem stay in the float32 blob of pack_state_dict)."""
     sd = unwrap_checkpoint(state_dict)
-    blob = torch.zeros(total_halfs, dtype=torch.float16)
+    blob = torch.zeros(total_halfs, dtype=torch.float16, device=_blob_device(sd, layers))
     for l in layers:
         if l["w16_off"] < 0:
             continue
@@ -153,10 +183,8 @@ def winograd_weights_split(w, cout_pad):
     U * 2^e[cout] as hi/lo fp16 pairs.  e[cout] puts the largest |U| of the output channel into [2^13, 2^14): every element
     down to 2^-17 of it keeps ~22 significant bits, and fp16's 65504 is never reached; the epilogue's scale carries 2^-e."""
     u = winograd_weights(w, cout_pad, 24)                         # the fp32 U of the exact path
-    amax = u.abs().amax(dim=(0, 2))
-    e = torch.where(amax > 0, 13 - torch.floor(torch.log2(amax.double().clamp_min(1e-300))), torch.zeros_like(amax, dtype=torch.float64))
-    e = e.clamp(-100, 100)
-    us = (u.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), e).view(1, -1, 1)).float()   # exact: a power of two
+    e = _pow2_exponent(u.abs().amax(dim=(0, 2)))
+    us = (u.double() * _pow2(e).view(1, -1, 1)).float()           # exact: a power of two
     return split_f16_pairs(us), e.to(torch.int32)
 
 
@@ -168,12 +196,10 @@ def winograd14_weights_split(w, cout_pad):
     64 x 64-byte rows [8 hi | 8 hi | 8 lo | 8 lo] -- 12 KiB that one weight group of the kernel's LDS-DMA ring fetches contiguously."""
     cout, cin = w.shape[0], w.shape[1]
     assert cout_pad % 64 == 0 and cin % 16 == 0
-    u = torch.zeros(3, 6, cout_pad, cin, dtype=torch.float32)
-    u[:, :, :cout] = torch.einsum("js,ncrs->rjnc", _WINO_G6, w.detach().double().cpu()).float()
-    amax = u.abs().amax(dim=(0, 1, 3))
-    e = torch.where(amax > 0, 13 - torch.floor(torch.log2(amax.double().clamp_min(1e-300))), torch.zeros_like(amax, dtype=torch.float64))
-    e = e.clamp(-100, 100)
-    us = (u.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), e).view(1, 1, -1, 1)).float()      # exact: a power of two
+    u = torch.zeros(3, 6, cout_pad, cin, dtype=torch.float32, device=w.device)
+    u[:, :, :cout] = _apply3(w.detach().double().permute(3, 2, 0, 1).contiguous(), _WINO_G6).transpose(0, 1).float()   # [j][r][n][c] -> [r][j]
+    e = _pow2_exponent(u.abs().amax(dim=(0, 1, 3)))
+    us = (u.double() * _pow2(e).view(1, 1, -1, 1)).float()         # exact: a power of two
     hi = us.half()
     lo = (us - hi.float()).half()
 
@@ -188,9 +214,7 @@ _SPLIT_PERM = [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]
 
 def _pow2_row_scale(rows):
     """Exponents e[row] (float64 tensor) that put each row's largest magnitude into [2^13, 2^14); 0 for all-zero rows."""
-    amax = rows.abs().amax(dim=1).double()
-    e = torch.where(amax > 0, 13 - torch.floor(torch.log2(amax.clamp_min(1e-300))), torch.zeros_like(amax))
-    return e.clamp(-100, 100)
+    return _pow2_exponent(rows.abs().amax(dim=1))
 
 
 def conv_weights_split(w, cout_pad):
@@ -198,10 +222,10 @@ def conv_weights_split(w, cout_pad):
     times 2^e[cout] as hi/lo fp16 pairs in the order conv_igemm_split.hip reads them -- per group of 16 input channels
     hi{0-3,8-11}, hi{4-7,12-15}, lo{0-3,8-11}, lo{4-7,12-15} (include/orienmask_hip.h: om_layer_info.wsplit_off)."""
     cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
-    rows = torch.zeros(cout_pad, k * k * cin, dtype=torch.float32)
-    rows[:cout] = w.detach().float().cpu().permute(0, 2, 3, 1).reshape(cout, -1)
+    rows = torch.zeros(cout_pad, k * k * cin, dtype=torch.float32, device=w.device)
+    rows[:cout] = w.detach().float().permute(0, 2, 3, 1).reshape(cout, -1)
     e = _pow2_row_scale(rows)
-    xs = (rows.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), e).view(-1, 1)).float()
+    xs = (rows.double() * _pow2(e).view(-1, 1)).float()
     hi = xs.half()
     lo = (xs - hi.float()).half()
     g = cin // 16
@@ -211,12 +235,12 @@ def conv_weights_split(w, cout_pad):
 
 
 def pack_state_dict_split(state_dict, layers, total_words):
-    """CPU float32-typed tensor of total_words 4-byte words: per layer (all but the stem) the split weights (two fp16 per
+    """float32-typed tensor of total_words 4-byte words (on the weights' device): per layer (all but the stem) the split weights (two fp16 per
     word; the F(2x4) planes of the stride-1 3x3 layers, the direct weights of the others) and [cout_pad] floats scale * 2^-e,
     scale being the folded BatchNorm scale ROUNDED TO FLOAT32 exactly as pack_state_dict stores it (the two precision modes
     then differ in their products only)."""
     sd = unwrap_checkpoint(state_dict)
-    blob = torch.zeros(total_words, dtype=torch.float32)
+    blob = torch.zeros(total_words, dtype=torch.float32, device=_blob_device(sd, layers))
     for l in layers:
         if l.get("wsplit_off", -1) < 0:
             continue
@@ -228,13 +252,13 @@ def pack_state_dict_split(state_dict, layers, total_words):
             us, e = conv_weights_split(w, cpad)
         n = us.numel() // 2
         blob[l["wsplit_off"]:l["wsplit_off"] + n] = us.reshape(-1).view(torch.float32)
-        scale = torch.zeros(cpad, dtype=torch.float64)
+        scale = torch.zeros(cpad, dtype=torch.float64, device=blob.device)
         scale[:l["cout"]] = scale64.float().double()
-        blob[l["wsplit_scale_off"]:l["wsplit_scale_off"] + cpad] = (scale * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e.double())).float()
+        blob[l["wsplit_scale_off"]:l["wsplit_scale_off"] + cpad] = (scale * _pow2(-e)).float()
         if l.get("wsplit_direct_off", -1) >= 0:              # the latency mode's direct form of a stride-1 3x3 layer
             ud, ed = conv_weights_split(w, cpad)
             nd = ud.numel() // 2
             blob[l["wsplit_direct_off"]:l["wsplit_direct_off"] + nd] = ud.reshape(-1).view(torch.float32)
             blob[l["wsplit_direct_scale_off"]:l["wsplit_direct_scale_off"] + cpad] = \
-                (scale * torch.pow(torch.tensor(2.0, dtype=torch.float64), -ed.double())).float()
+                (scale * _pow2(-ed)).float()
     return blob

@@ -41,7 +41,8 @@ def built():
 #   * pack.pack_state_dict / _split / _f16: 1-2 s each per model built from an already-seen state dict (the two precisions of a
 #     fixture, the two models of an A/B test): keyed by a fingerprint of the CONTENT (every tensor's shape, its first elements
 #     and its float64 sum), so a test that changes a weight gets a fresh pack.
-# Small LRUs: a state dict is 255 MB, a set of packed blobs ~2 GB.
+# Small LRUs: a state dict is 255 MB, a set of packed blobs ~2 GB.  (Round 5 also moved the packing itself onto the device the
+# weights are on -- pack.py -- which took most of the remaining cost away; the memo stays for the host-side packs.)
 def _lru(cache, key, make, size):
     if key in cache:
         cache[key] = cache.pop(key)          # most recent last
@@ -81,9 +82,11 @@ def _install_memo():
         raw = getattr(pack, name)
 
         def packed(state_dict, layers, total, _raw=raw, _name=name):
-            key = (_name, _fingerprint(pack.unwrap_checkpoint(state_dict)), int(total), len(layers))
+            sd = pack.unwrap_checkpoint(state_dict)
+            key = (_name, _fingerprint(sd), str(pack._blob_device(sd, layers)), int(total), len(layers))
             return _lru(blob_cache, key, lambda: _raw(state_dict, layers, total), 6).clone()
 
+        packed.__wrapped__ = raw
         setattr(pack, name, packed)
 
 

@@ -1477,6 +1477,26 @@ def test_tester_and_infer_loops(dev):
     assert net.latency_cells == cells
 
 
+def test_pack_on_device_equals_pack_on_host(dev):
+    """orienmask_amd.pack computes where the weights are (a model on the GPU packs on the GPU: model load 12 s -> under 1 s);
+    its arithmetic is fixed-order float64 elementwise work, so the three blobs are the same BITS from either device -- what a
+    checkpoint packed on a CPU-only host and one packed on the GPU box must be for RCCL-broadcast blobs to be interchangeable."""
+    from orienmask_amd import lib as _lib, pack
+    from orienmask_amd.model import OrienMaskYOLOFPNPlus
+    sd = synth.synth_state_dict(11, obj_bias=-3.0, head_gain=2.0)
+    net = OrienMaskYOLOFPNPlus(3, 80).eval()
+    h = net._ensure_handle(); L = _lib.load()
+    sd_dev = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sd.items()}
+    for name, total in (("pack_state_dict", L.om_model_weight_floats(h)), ("pack_state_dict_split", L.om_model_weight_split_words(h)),
+                        ("pack_state_dict_f16", L.om_model_weight_halfs(h))):
+        fn = getattr(pack, name)
+        fn = getattr(fn, "__wrapped__", fn)                    # not the test session's memo (conftest.py)
+        host, device = fn(sd, net._layers, total), fn(sd_dev, net._layers, total)
+        assert host.device.type == "cpu" and device.device.type == "cuda"
+        bits = torch.int32 if host.dtype == torch.float32 else torch.int16
+        assert torch.equal(host.view(bits), device.cpu().view(bits)), name
+
+
 def test_build_tester_from_checkpoint_file(dev, tmp_path):
     """test.py's build_tester(config, checkpoint) on a reference-format .pth file."""
     from orienmask_amd import builder
