@@ -315,6 +315,12 @@ int om_conv2d_wino14_split(const float* in, int B, int H, int W, int cin, int in
  * SIMD, accumulators owned by name) wherever it applies -- an even number >= 2 of 16-channel chunks, 16-byte aligned views.
  * The second form is kept as a measured alternative (8-25 % slower: profiles/r05_experiments.md), not as the product's path. */
 int om_set_wino14_variant(int variant);
+/* Which kernel runs the stride-1 3x3 layers of the fp16 configuration (process-wide; the results are the same sums in the same
+ * order, bit-identical): 0 the 256 x 128 / 128 x 128 / 128 x 64 shared-patch kernel everywhere (rounds 1-4); 1 (default;
+ * environment OM_C3_TALL) the tall-patch kernel of round 5 (conv3x3_f16.hip: 512 raster pixels x 128 channels per eight-wave
+ * workgroup, one input patch per 32-channel chunk for all nine taps) where the tile chooser picks it; 2 wherever it can run
+ * (cout_pad a multiple of 128, rows of at most 191 pixels). */
+int om_set_conv3x3_f16_variant(int mode);
 /* first layer: in [B,3,H,W] NCHW -> out [B,H,W,cout] NHWC, 3x3 stride 1. */
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale,
                    const float* shift, int cout, float* out, om_stream stream);

@@ -208,6 +208,186 @@ __global__ __launch_bounds__(256, (c3_blocks_per_cu<BM, BN>())) void conv3x3_f16
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The TALL-PATCH form (round 5): 512 raster pixels x 128 output channels per workgroup of EIGHT waves, ONE patch per 32-channel
+// chunk for all nine taps.
+//
+// conv3x3_f16_kernel keeps ~72 KB of operands in flight per CU against ~2 us of memory latency, about 15 B/clk, and its 256 x 128
+// tile needs 123 KB of requests per chunk of 32 channels (three patches of 258 pixels + nine weight slices of 128 rows) for 18.9
+// MFLOP: the matrix pipe waits for operands 57 % of the time (profiles/r04_experiments.md section 12).  What raises the rate is
+// fewer requested bytes per matrix instruction:
+//   * the input rows of the three KERNEL ROWS overlap too: for BM consecutive raster pixels all nine taps read the SAME
+//     BM + 2 W + 2 pixels (patch row r = input pixel m0 - 1 - W + r; tap (kh, kw) of tile pixel i is patch row i + kh W + kw),
+//     so one patch per chunk replaces three: 786 instead of 3 x 514 pixels at W = 136 for 512 pixels;
+//   * 512 pixels share every weight slice (twice the pixels per weight byte).
+// Per chunk: 50 + 74 KB for 37.7 MFLOP -- half the requests per matrix instruction, with the same 128 x 64 wave tile, fragment
+// reads, padding masks (a patch row is a neighbour for one tap and padding for another: 9-bit mask per pixel, as above) and
+// epilogue.  LDS: two patch buffers of NP x 128 rows + four weight slices of 128 rows, 64 B each = 114.7 + 32.8 KB at NP = 7.
+// Per tap every thread requests at most one patch piece (the NEXT chunk's, taps 0 .. NP-1) and one weight piece (three taps
+// ahead, four-slot ring), retired in order: a counted `vmcnt` before the tap's hand-over means "the next tap's weights have landed".
+constexpr int C3T_BM = 512, C3T_BN = 128, C3T_WM = 128, C3T_WN = 64, C3T_NT = 512;
+
+template <int NP, int FAST>
+__global__ __launch_bounds__(C3T_NT, 1) void conv3x3_f16_tall_kernel(const IgemmHParams p) {
+    constexpr int BM = C3T_BM, BN = C3T_BN, WM = C3T_WM, WN = C3T_WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int NS = 4;                         // weight slices in the ring (requested three taps ahead)
+    constexpr int PATCH = NP * 128 * 4;           // f32x4 units per patch buffer (rows of 64 B)
+    constexpr int BSL = BN * 4;                   // f32x4 units per weight slice
+    static_assert(WM * BN / 4 <= 2 * PATCH, "one wave-row of the fp32 C tile must fit in the patch buffers");
+    static_assert(NP >= 5 && NP <= 7, "patch pieces are requested during taps 0 .. NP-1, before the last two taps");
+    __shared__ f32x4 smem[2 * PATCH + NS * BSL + 1];
+    int* const s_ticket = reinterpret_cast<int*>(smem + 2 * PATCH + NS * BSL);
+    f32x4* const s_patch = smem;
+    f32x4* const s_w = smem + 2 * PATCH;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int grp = wave_u >> 2;                   // waves w and w + 4 share a SIMD: one of each group per SIMD
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = tid >> 2, lcol = tid & 3;     // loader: row within a 128-row piece, 16-byte position in the row
+    const int scol = lcol ^ ((lrow >> 2) & 3);     // logical chunk this lane fetches (the LDS image stays lane-linear)
+    const int fi = lane & 31, fk = lane >> 5;
+    const int fswB = (fi >> 2) & 3;
+    const int in_bytes = ((p.total_in_pixels - 1) * p.in_pix_stride + p.cin) * 2;     // < 2^31, checked by the host
+    const int row_halfs = 9 * p.cin;
+    const int W = p.W;
+
+    for (;;) {
+        if (tid == 0) *s_ticket = atomicAdd(p.ticket, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int tile = *s_ticket;
+        if (tile >= p.total_tiles) break;
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        const int tile_n = tile % p.n_tiles;
+        const int tile_m = tile / p.n_tiles;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+        // loader role: patch row r = lrow + 128 j is input pixel m0 - 1 - W + r (raster index over the batch); a negative or
+        // past-the-end offset is out of the descriptor's range -> zeros
+        const int rowbase0 = ((m0 - 1 - W + lrow) * p.in_pix_stride + scol * 8) * 2;
+        const int piece_bytes = 128 * p.in_pix_stride * 2;
+        const int rowoffB = ((n0 + lrow) * row_halfs + scol * 8) * 2;
+        // consumer role: "tap t is padding" bits of this lane's pixels (one per MFMA row block)
+        unsigned inv[TM];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            int m = m0 + wm * WM + a * 32 + fi;
+            if (m >= p.M) m = p.M - 1;              // rows beyond M are never stored
+            const int rr = m % p.HoWo;
+            const int y = rr / p.W, x = rr - y * p.W;
+            const unsigned badrow = (y == 0 ? 1u : 0u) | (y == p.H - 1 ? 4u : 0u);
+            const unsigned badcol = (x == 0 ? 1u : 0u) | (x == p.W - 1 ? 4u : 0u);
+            inv[a] = ((badrow & 1u) ? 0x007u : 0u) | ((badrow & 4u) ? 0x1C0u : 0u) | badcol * 0x49u;
+        }
+
+        auto issue_patch_piece = [&](int j, int cc, bool live) {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.in), 0, live ? in_bytes : 0, 0x00020000);
+            const int vo = rowbase0 + j * piece_bytes + cc * 64;
+            f32x4* dst = s_patch + (cc & 1) * PATCH + j * 512 + wave_u * 64;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
+        };
+        auto issue_w_piece = [&](int cc, int tap, bool live) {       // slice 9 cc + tap -> slot (cc + tap) & 3
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, live ? p.w_bytes : 0, 0x00020000);
+            const int vo = rowoffB + (tap * p.cin + cc * 32) * 2;
+            f32x4* dst = s_w + ((cc + tap) & (NS - 1)) * BSL + wave_u * 64;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
+        };
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+        f32x4 fa[2][TM], fb[2][TN];
+        const int rowA0 = wm * WM + fi;
+
+        // prologue: patch 0 and weight slices 0, 1, 2 requested; patch and slice 0 waited for by everybody
+#pragma unroll
+        for (int j = 0; j < NP; ++j) issue_patch_piece(j, 0, true);
+        issue_w_piece(0, 0, true);
+        issue_w_piece(0, 1, true);
+        issue_w_piece(0, 2, true);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // PING-PONG: the waves of group 1 run one phase behind group 0 -- while one wave of a SIMD issues its tap's sixteen
+        // matrix instructions the other one reads its fragments, masks them and requests operands, and the barrier between two
+        // phases is the hand-over.  (With every wave in the same phase -- the shared-patch kernel's loop -- both waves of a SIMD
+        // stand at the barrier, then both mask, then both want the matrix pipe: it is idle half of the time.)
+        if (grp) __builtin_amdgcn_s_barrier();
+
+        for (int cc = 0; cc < p.kc; ++cc) {
+            const int pb = cc & 1;
+            const bool more = cc + 1 < p.kc;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap - 3 * kh;
+                // ---- memory phase of this tap: requests (the next chunk's patch piece, the weight slice three taps ahead) ...
+                if (tap < NP) issue_patch_piece(tap, cc + 1, more);
+                if (tap < 6) issue_w_piece(cc, tap + 3, true);
+                else issue_w_piece(cc + 1, tap - 6, more);
+                // ... the tap's twelve fragments, A masked with the tap's padding bits
+                {
+                    const int rowA = rowA0 + kh * W + kw;
+                    const int sw = (rowA >> 2) & 3;
+                    const f32x4* pa = s_patch + pb * PATCH + rowA * 4;
+                    const f32x4* pw = s_w + ((cc + tap) & (NS - 1)) * BSL + (wn * WN + fi) * 4;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                        for (int a = 0; a < TM; ++a) fa[q][a] = pa[a * 32 * 4 + ((2 * q + fk) ^ sw)];      // + 32 rows keeps (row >> 2) & 3
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) fb[q][b] = pw[b * 32 * 4 + ((2 * q + fk) ^ fswB)];
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const unsigned keep = ((inv[a] >> tap) & 1u) ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        unsigned* d = reinterpret_cast<unsigned*>(&fa[q][a]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) d[k] &= keep;
+                    }
+                }
+                // the NEXT tap's weight slice (and, before tap 0, the next patch) has landed: requested two taps ago; younger
+                // are the previous and this tap's requests
+                constexpr int dummy = 0; (void)dummy;
+                if (tap == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 + 0 + 1) : "memory");
+                else if (tap < NP) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 + 1 + 1) : "memory");
+                else if (tap == NP) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 + 1 + 0) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2) : "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- matrix phase
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[q][b]),
+                                                                               __builtin_bit_cast(f16x8, fa[q][a]), acc[a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!grp) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        f16_epilogue<BM, BN, WM, WN, FAST, C3T_NT>(p, smem, acc, m0, n0, tid, wm, wn, fi, fk);
+    }
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_c3(IgemmHParams p, int cout_pad, hipStream_t stream) {
     const int m_tiles = (p.M + BM - 1) / BM;
@@ -234,8 +414,51 @@ bool conv3x3_f16_supported(const ConvArgsH& a) {
     return bytes < 0x70000000ll && a.out_mode == 0;      // headroom: patch rows run up to 320 + W pixels past the end
 }
 
-void conv3x3_tile_for_f16(int M, int cout_pad, int* bm, int* bn) {
+template <int NP>
+static int launch_c3_tall(IgemmHParams p, int cout_pad, hipStream_t stream) {
+    const int m_tiles = (p.M + C3T_BM - 1) / C3T_BM;
+    p.n_tiles = cout_pad / C3T_BN;
+    const long long total = (long long)m_tiles * p.n_tiles;
+    OM_REQUIRE(total > 0 && total < (1ll << 31), OM_EINVAL, "conv3x3 f16: %lld tiles out of range", total);
+    p.total_tiles = (int)total;
+    const long long grid = total < 256 ? total : 256;
+    const bool fast = p.out_mode == 0 && !p.out_f32 && p.vec_io && p.cout == cout_pad;
+    if (fast && !p.res) hipLaunchKernelGGL((conv3x3_f16_tall_kernel<NP, 1>), dim3((unsigned)grid), dim3(C3T_NT), 0, stream, p);
+    else if (fast) hipLaunchKernelGGL((conv3x3_f16_tall_kernel<NP, 2>), dim3((unsigned)grid), dim3(C3T_NT), 0, stream, p);
+    else hipLaunchKernelGGL((conv3x3_f16_tall_kernel<NP, 0>), dim3((unsigned)grid), dim3(C3T_NT), 0, stream, p);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
+// 0: never the tall-patch form; 1 (default): where conv3x3_tile_for_f16 picks it; 2: wherever it can run.  OM_C3_TALL in the
+// environment, or om_set_conv3x3_f16_variant (A/B runs, tools/conv16_bench.py, the unit tests of both forms).
+static int g_c3_tall = -1;
+static int c3_tall_mode() {
+    if (g_c3_tall < 0) {
+        const char* e = std::getenv("OM_C3_TALL");
+        g_c3_tall = e ? std::atoi(e) : 1;
+    }
+    return g_c3_tall;
+}
+void conv3x3_f16_set_tall(int mode) { g_c3_tall = mode; }
+
+void conv3x3_tile_for_f16(int M, int cout_pad, int W, int kc, int* bm, int* bn) {
     if (cout_pad % 128) { *bm = 128; *bn = 64; return; }
+    *bn = 128;
+    // the tall-patch form: 512 + 2 W + 2 patch rows must fit its seven 128-row pieces.  It is ONE workgroup per CU whose tile
+    // ends overlap with nothing, against two co-resident workgroups of the 256-pixel tile: per unit of work it is 8 % faster
+    // from 128 input channels on, 17 % from 512 on (longer k loops), and what decides is whole rounds -- ceil(tiles / 256) of its
+    // tiles against half as many rounds of twice as many (same-box single-layer A/B at bs = 8 ... 64, profiles/r05_experiments.md
+    // section 4: every measured shape falls on the side this rule puts it, but for two within 5 %).
+    const bool tall_fits = C3T_BM + 2 * W + 2 <= 7 * 128;
+    const long long t512 = (long long)((M + 511) / 512) * (cout_pad / 128);
+    if (tall_fits && c3_tall_mode() == 2) { *bm = 512; return; }
+    if (tall_fits && c3_tall_mode() == 1 && kc >= 4) {
+        const long long t256r = (long long)((M + 255) / 256) * (cout_pad / 128);
+        const double rounds_tall = (double)((t512 + 255) / 256) * (kc >= 16 ? 0.83 : 0.92);
+        const double rounds_pair = (double)((t256r + 255) / 256) / 2.0;
+        if (rounds_tall <= rounds_pair) { *bm = 512; return; }
+    }
     // the tile with the least matrix-pipe time over all its tiles: 256x128 unless its M padding costs more than the finer
     // tile's 15 % lower efficiency.  Whole rounds of tiles are NOT part of the cost any more: with two batches in flight
     // (pipeline.py) the other batch's kernels use the compute units a partial round leaves idle -- same-box A/B +4 % with two in
@@ -244,7 +467,6 @@ void conv3x3_tile_for_f16(int M, int cout_pad, int* bm, int* bn) {
     const long long t128 = (long long)((M + 127) / 128) * (cout_pad / 128);
     const double c256 = (double)t256 * 256 * 128 / 1.0;
     const double c128 = (double)t128 * 128 * 128 / 0.85;
-    *bn = 128;
     *bm = c256 <= c128 ? 256 : 128;
 }
 
@@ -273,7 +495,13 @@ int launch_conv3x3_f16(const ConvArgsH& a, hipStream_t stream) {
                 (!a.res || (a.res_pix_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)))
                    ? 1 : 0;
     int bm, bn;
-    conv3x3_tile_for_f16(p.M, a.cout_pad, &bm, &bn);
+    conv3x3_tile_for_f16(p.M, a.cout_pad, a.W, a.cin / 32, &bm, &bn);
+    if (bm == 512) {
+        const int np = (C3T_BM + 2 * a.W + 2 + 127) / 128;
+        if (np <= 5) return launch_c3_tall<5>(p, a.cout_pad, stream);
+        if (np == 6) return launch_c3_tall<6>(p, a.cout_pad, stream);
+        return launch_c3_tall<7>(p, a.cout_pad, stream);
+    }
     if (bn == 64) return launch_c3<128, 64, 64, 32>(p, a.cout_pad, stream);
     if (bm == 256) return launch_c3<256, 128, 128, 64>(p, a.cout_pad, stream);
     return launch_c3<128, 128, 64, 64>(p, a.cout_pad, stream);

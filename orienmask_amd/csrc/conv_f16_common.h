@@ -39,19 +39,19 @@ struct IgemmHParams {
 // (pixel = lane & 31, channel = 8*(r>>2) + 4*(lane>>5) + (r&3)): one wave-row (WM pixels x BN channels) at a time through
 // LDS in fp32 (16-byte chunk index swizzled with m & 7), then 8 channels per thread: scale/shift, LeakyReLU, residual,
 // one 16-byte fp16 store (fp32 for the head tensors; NCHW fp32 for the orientation head).  `smem` must hold
-// WM * BN / 4 f32x4 and be free of live operands; all 256 threads call it.
+// WM * BN / 4 f32x4 and be free of live operands; all NT threads of the workgroup call it.
 //
 // FAST (the launchers: fp16 NHWC output, no residual, 16-byte aligned view, cout == cout_pad): row sweeps without any load.  With
 // the residual's conditional loads in the sweep loop the compiler waits for vmcnt(0) at the top of every sweep, i.e. for the
 // PREVIOUS sweep's stores (one in-order counter for loads and stores): conv_igemm_split.hip's epilogue, DESIGN.md 3.5.
 // FAST = 2: the same with a residual (fp16 NHWC, 16-byte aligned): its rows are requested RG sweeps at a time BEFORE those
 // sweeps' stores, so a pass waits for the previous stores WM / RP / RG times instead of once per sweep.
-template <int BM, int BN, int WM, int WN, int FAST = 0>
+template <int BM, int BN, int WM, int WN, int FAST = 0, int NT = 256>
 __device__ __forceinline__ void f16_epilogue(const IgemmHParams& p, f32x4* smem, const f32x16 (&acc)[WM / 32][WN / 32],
                                              int m0, int n0, int tid, int wm, int wn, int fi, int fk) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int CH8 = BN / 8;                   // 8-channel chunks per C-tile row
-    constexpr int RP = 256 / CH8;                 // C-tile rows per epilogue sweep
+    constexpr int RP = NT / CH8;                  // C-tile rows per epilogue sweep
     constexpr int CH = BN / 4;                    // f32x4 chunks per C-tile row
     f32x4* sC = smem;
     const int n8 = tid % CH8, r0 = tid / CH8;
@@ -184,7 +184,7 @@ __device__ __forceinline__ void f16_epilogue(const IgemmHParams& p, f32x4* smem,
             const float* sCf = reinterpret_cast<const float*>(smem);
             float* const outf = static_cast<float*>(p.out);
             const int nch = min(BN, p.cout - n0);
-            for (int idx = tid; idx < nch * WM; idx += 256) {
+            for (int idx = tid; idx < nch * WM; idx += NT) {
                 const int nl = idx / WM, ml = idx - nl * WM;
                 const int m = m0 + pass * WM + ml;
                 if (m >= p.M) continue;

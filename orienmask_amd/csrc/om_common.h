@@ -103,7 +103,8 @@ struct ConvArgsH {
 int launch_conv_igemm_f16(const ConvArgsH& a, hipStream_t stream);     // dispatches stride-1 3x3 layers to conv3x3_f16.hip
 int launch_conv3x3_f16(const ConvArgsH& a, hipStream_t stream);
 bool conv3x3_f16_supported(const ConvArgsH& a);
-void conv3x3_tile_for_f16(int M, int cout_pad, int* bm, int* bn);
+void conv3x3_tile_for_f16(int M, int cout_pad, int W, int kc, int* bm, int* bn);
+void conv3x3_f16_set_tall(int mode);      // conv3x3_f16.hip: 0 never / 1 where the tile chooser picks it (default) / 2 wherever it can run
 void conv_tile_for_f16(int M, int cout_pad, int cin, int* bm, int* bn);
 inline size_t conv_f16_weight_halfs(int cout_pad, int ks, int cin) {
     return (size_t)cout_pad * ks * ks * cin;

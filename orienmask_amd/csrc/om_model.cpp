@@ -829,8 +829,8 @@ int om_layer_tile_f16(const om_model* m, int index, int B, int H, int W, int* bm
     a.B = B; a.H = Hin; a.W = Win; a.cin = L.info.cin; a.in_pix_stride = m->pix_stride(L.in.buf);
     a.cout = L.info.cout; a.cout_pad = L.info.cout_pad; a.ks = L.info.ksize; a.stride = L.info.stride; a.out_mode = L.out_mode;
     if (om::conv3x3_f16_supported(a)) {
-        om::conv3x3_tile_for_f16(B * Ho * Wo, L.info.cout_pad, bm, bn);
-        *algo = 4;
+        om::conv3x3_tile_for_f16(B * Ho * Wo, L.info.cout_pad, Wo, L.info.cin / 32, bm, bn);
+        *algo = *bm == 512 ? 6 : 4;       // 6: conv3x3_f16_tall_kernel
         return OM_OK;
     }
     om::conv_tile_for_f16(B * Ho * Wo, L.info.cout_pad, L.info.cin, bm, bn);
@@ -1207,6 +1207,12 @@ int om_conv2d_wino14_split(const float* in, int B, int H, int W, int cin, int in
 int om_set_wino14_variant(int variant) {
     OM_REQUIRE(variant == 0 || variant == 1, OM_EINVAL, "om_set_wino14_variant: %d", variant);
     om::wino14_set_variant(variant);
+    return OM_OK;
+}
+
+int om_set_conv3x3_f16_variant(int mode) {
+    OM_REQUIRE(mode >= 0 && mode <= 2, OM_EINVAL, "om_set_conv3x3_f16_variant: %d", mode);
+    om::conv3x3_f16_set_tall(mode);
     return OM_OK;
 }
 

@@ -1633,14 +1633,24 @@ F16_CONV_CASES = [
     (2, 7, 1, 64, 64, 3, 1, 0, False, 0),        # one-column images
     (9, 17, 17, 512, 1024, 3, 1, 1, True, 0),    # conv6-like: several images per tile
     (2, 24, 40, 256, 128, 3, 1, 1, False, 1),    # fp32 output from the shared-patch kernel
+    (2, 136, 136, 32, 128, 3, 1, 1, True, 0),    # tall-patch kernel: seven patch pieces (W = 136), one chunk
+    (3, 68, 68, 64, 128, 3, 1, 1, False, 0),     # ... six pieces, two chunks (the patch double buffer)
+    (1, 40, 190, 96, 256, 3, 1, 0, True, 0),     # ... the longest rows it takes, three chunks, two N tiles
+    (1, 8, 200, 32, 128, 3, 1, 1, False, 0),     # rows too long for it: the shared-patch kernel whatever the variant
 ]
 
 
+@pytest.mark.parametrize("variant", [0, 2])
 @pytest.mark.parametrize("case", F16_CONV_CASES)
-def test_conv_f16_layer_matches_torch(dev, case):
+def test_conv_f16_layer_matches_torch(dev, case, variant):
+    """variant: om_set_conv3x3_f16_variant -- 0 the shared-patch 3x3 kernel of rounds 1-4, 2 the tall-patch kernel wherever it
+    can run (the default, 1, is one of the two per layer)."""
     from orienmask_amd.pack import conv_weights_f16
     B, H, W, cin, cout, k, stride, leaky, use_res, out_f32 = case
     L = omlib.load()
+    if variant and not (k == 3 and stride == 1):
+        pytest.skip("one kernel for this layer")
+    omlib.check(L.om_set_conv3x3_f16_variant(variant), "om_set_conv3x3_f16_variant")
     g = torch.Generator().manual_seed(sum(case) + 11)
     x = torch.randn(B, cin, H, W, generator=g).half()
     w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).half()
@@ -1666,6 +1676,7 @@ def test_conv_f16_layer_matches_torch(dev, case):
     rc = L.om_conv2d_f16(_p(xd), B, H, W, cin, cin, _p(wd), _p(sd_), _p(hd), cout, k, stride, leaky,
                          _p(rd) if use_res else None, cout if use_res else 0, _p(out), ostride, out_f32,
                          omlib.current_stream_ptr(dev))
+    L.om_set_conv3x3_f16_variant(1)
     omlib.check(rc, "om_conv2d_f16")
     got = out[..., :cout].cpu().permute(0, 3, 1, 2).double()
     assert torch.isfinite(got).all()

@@ -6,7 +6,10 @@ from orienmask_amd.pack import conv_weights_f16
 B, H, W, cin, cout, k, stride = [int(v) for v in sys.argv[1:8]]
 use_res = len(sys.argv) > 8 and sys.argv[8] == "res"
 dev = torch.device("cuda:0"); L = omlib.load()
+import os
 x = torch.randn(B, H, W, cin, device=dev).half()
+if os.environ.get('ZERO_X'): x.zero_()
+if os.environ.get('SMALL_X'): x.mul_(float(os.environ['SMALL_X']))
 w = conv_weights_f16(torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5, (cout + 31) // 32 * 32).to(dev)
 cp = w.shape[0]
 sc = torch.ones(cp, device=dev); sh = torch.zeros(cp, device=dev)

@@ -23,6 +23,8 @@ def main():
     shapes = SHAPES if not os.environ.get("OM_SHAPES") else [SHAPES[int(i)] for i in os.environ["OM_SHAPES"].split(",")]
     for hw, cin, cout, n in shapes:
         x = torch.randn(B, hw, hw, cin, device=dev)
+        if os.environ.get("ZERO_X"):        # the same instruction stream on zeros: what the clock under load costs (profiles/r05_experiments.md section 4)
+            x.zero_()
         w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
         out = torch.empty(B, hw, hw, cout, device=dev)
         hd = torch.zeros(cout, device=dev)
