@@ -94,6 +94,63 @@ def cpu_baseline(sd, x_cpu, f16=False, budget_s=30.0):
                            images_per_s=round(nb / (fb + pb), 4)))
 
 
+class ClockSampler:
+    """The shader clock of THIS GPU while a timed region runs, from the driver's own table (sysfs pp_dpm_sclk: the level marked
+    `*` is the current clock), sampled every few milliseconds by a host thread.  Under dense fp16 matrix work on non-zero data
+    MI355X does not hold its 2.4 GHz: the peaks of /opt/skills/guides/MI355X_MICROARCH.md are quoted at 2.4 GHz, so the line
+    also says what the matrix pipe could do at the clock it actually ran at (profiles/r05_experiments.md section 4)."""
+
+    def __init__(self, dev):
+        import glob, threading
+        self.path = None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for card in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.basename(os.path.realpath(card)) == bus and os.path.exists(os.path.join(card, "pp_dpm_sclk")):
+                    self.path = os.path.join(card, "pp_dpm_sclk")
+        except Exception:
+            self.path = None
+        self._threading = threading
+        self.samples, self._stop, self._thread = [], None, None
+
+    def _read(self):
+        try:
+            for line in open(self.path).read().splitlines():
+                if line.rstrip().endswith("*"):
+                    return float(line.split(":")[1].strip().split("M")[0])
+        except Exception:
+            return None
+        return None
+
+    def start(self):
+        self.samples = []
+        if self.path is None:
+            return self
+        self._stop = self._threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                v = self._read()
+                if v is not None:
+                    self.samples.append(v)
+                self._stop.wait(0.004)
+
+        self._thread = self._threading.Thread(target=run, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+            self._thread = None
+        v = sorted(self.samples)
+        if not v:
+            return None
+        return dict(mean=round(sum(v) / len(v), 1), min=v[0], median=v[len(v) // 2], max=v[-1], samples=len(v))
+
+
 def lib_sha256():
     from orienmask_amd import lib as omlib
     return hashlib.sha256(open(omlib.LIB_PATH, "rb").read()).hexdigest()
@@ -437,6 +494,9 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    clock = ClockSampler(dev)
+    sclk_idle = clock._read() if clock.path else None
+    clock.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         dets = step()
@@ -444,6 +504,8 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    sclk_serial = clock.stop()
+    sclk_flight = None
     elapsed, per_rank_serial = over_ranks(elapsed)
     per_rank = per_rank_serial
     timed_ms, timed_fw = net.profile_read()
@@ -462,6 +524,7 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+        clock.start()
         t0 = time.perf_counter()
         for dets in pipe.map(batches(args.steps)):
             pass
@@ -469,6 +532,7 @@ def main():
         if use_dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        sclk_flight = clock.stop()
         elapsed, per_rank = over_ranks(elapsed)
     # ---- split mode: the same K steps with fp32 operands (v_mfma_f32_32x32x2_f32 everywhere), for comparison
     f32_operands = None
@@ -520,8 +584,12 @@ def main():
             if use_dist:
                 dist.barrier()
             return over_ranks(time.perf_counter() - t0_)[0]
+        clock.start()
         e1 = timed16(lambda: [step() for _ in range(args.steps)])
+        sclk16_serial = clock.stop()
+        clock.start()
         e3 = timed16(lambda: [None for _ in pipe16.map(batches(args.steps))])
+        sclk16_flight = clock.stop()
         # this configuration's own roofline: HIP events around every layer of three forwards (untimed), the kernel with the most
         # time, its executed flops (direct convolution on v_mfma_f32_32x32x16_f16: executed = algorithmic) against the dense
         # fp16 peak, and the forward's algorithmic bytes (2-byte activations and weights) against HBM
@@ -564,6 +632,9 @@ def main():
                             measured="HIP events around every layer of three untimed one-batch-at-a-time forwards in this run; "
                                      "traffic = PMC bytes per launch when profiles/%s_pmc_traffic_f16.json was measured with this "
                                      "library binary, else null" % PROFILE_TAG)
+        if sclk16_serial:
+            f16_roofline["sclk_mhz"] = dict(one_batch_in_flight=sclk16_serial, batches_in_flight=sclk16_flight, nominal=2400)
+            f16_roofline["frac_at_measured_clock"] = round(f16_roofline["frac"] * 2400.0 / sclk16_serial["mean"], 4)
         f16_config = dict(value=round(world * B * args.steps / e3, 2), ms_per_step=round(e3 / args.steps * 1e3, 3),
                           batches_in_flight=3, one_batch_in_flight=round(world * B * args.steps / e1, 2), roofline=f16_roofline,
                           note="BASELINE configs[4] at this batch size: the same K steps with precision 'f16' (fp16 activations and "
@@ -778,11 +849,19 @@ def main():
                                  "~1.3x the algorithmic bytes: the 3x3 kernel is bound by the CU's outstanding-request limit, the 1x1 "
                                  "layers at 136^2 / 68^2 by HBM") if split else
                                 "fp32 FLOPs on the f32-input matrix cores; the HBM bound is several x further away")
+        if sclk_serial:
+            # the dominant kernel's events come from the one-batch-at-a-time region: its clock is that region's
+            clk = sclk_serial["mean"]
+            roofline["sclk_mhz"] = dict(one_batch_in_flight=sclk_serial, batches_in_flight=sclk_flight, idle_before=sclk_idle, nominal=2400,
+                                        source="sysfs pp_dpm_sclk of this GPU, sampled every 4 ms during the timed regions")
+            roofline["peak_at_measured_clock"] = round(peak_tf * clk / 2400.0, 1)
+            roofline["frac_at_measured_clock"] = round(executed / (peak_tf * clk / 2400.0), 4)
         front = ["bound", "achieved", "peak", "unit", "frac", "traffic", "frac_counts", "achieved_algorithmic", "algorithmic_frac", "kernel",
                  "launches_per_step", "avg_launch_ms", "kernel_ms_per_step", "algorithmic_bytes_per_launch", "traffic_over_algorithmic",
                  "one_batch_in_flight_images_per_s", "one_batch_in_flight_ms_per_step", "forward_kernels_ms_per_step",
                  "postprocess_ms_per_step", "forward_tflops_algorithmic", "forward_tflops_executed", "forward_executed_frac",
-                 "forward_hbm_algorithmic_gbs", "forward_hbm_frac"]
+                 "forward_hbm_algorithmic_gbs", "forward_hbm_frac", "peak_at_measured_clock", "frac_at_measured_clock", "sclk_mhz"]
+        front = [k for k in front if k in roofline]
         roofline = {**{k: roofline[k] for k in front}, **{k: v for k, v in roofline.items() if k not in front}}
         if split:
             roofline["hbm"] = dict(bound="hbm", unit="GB/s", peak=PEAK_HBM_GBS,
