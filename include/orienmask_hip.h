@@ -196,7 +196,8 @@ int om_model_load_weights_f16(om_model* m, const void* packed_f16_dev, size_t by
 size_t om_forward_f16_workspace_bytes(const om_model* m, int B, int H, int W);
 int om_forward_f16(om_model* m, const float* x, int B, int H, int W, float* bbox32, float* bbox16, float* bbox8,
                    float* oriens, void* workspace, size_t ws_bytes, om_stream stream);
-/* kernel that runs layer `index` in the fp16 configuration: algo 0 = conv_stem_kernel<f16>, 1 = conv_igemm_f16_kernel<bm,bn>,
+/* kernel that runs layer `index` in the fp16 configuration (6 = conv3x3_f16_tall_kernel<512,128>, 7 = conv_stem2_f16_kernel: the first
+ * two layers in one launch, 8 = a layer computed inside the previous layer's kernel): algo 0 = conv_stem_kernel<f16>, 1 = conv_igemm_f16_kernel<bm,bn>,
  * 4 = conv3x3_f16_kernel<bm,bn> (stride-1 3x3: the three taps of a kernel row share one LDS copy of the input rows) */
 int om_layer_tile_f16(const om_model* m, int index, int B, int H, int W, int* bm, int* bn, int* algo);
 
@@ -334,6 +335,13 @@ int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const f
 int om_conv2d_stem2_split(const float* in, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
                           const void* w2_split, const float* scale2_split, const float* shift2, int cout2, int leaky2, float* out,
                           int out_pix_stride, int32_t* status_dev, om_stream stream);
+/* The same two layers as om_forward_f16 runs them (conv_stem2.hip: conv_stem2_f16_kernel; round 5): conv1 from the fp32 image with
+ * fp32 weights (fp32-level sums, one rounding to fp16 -- the activation om_conv2d_stem_f16 stores, never written here), conv2.0 on
+ * fp16 operands: w2_f16 = its fp16 rows [64][9 * 32] (om_layer_info.w16_off), scale2 / shift2 [64] fp32; out [B,H/2,W/2,out_pix_stride]
+ * fp16 NHWC, 8-byte aligned.  Equal to om_conv2d_stem_f16 followed by om_conv2d_f16 up to conv1's rounding ties. */
+int om_conv2d_stem2_f16(const float* in, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
+                        const void* w2_f16, const float* scale2, const float* shift2, int cout2, int leaky2, void* out,
+                        int out_pix_stride, om_stream stream);
 
 /* ---- preprocess: FastCOCOTransform.__call__ + pad, fused ------------------------------
  * Replaces /root/reference/data/transform.py:444-510 (permute, Resize = F.interpolate bilinear

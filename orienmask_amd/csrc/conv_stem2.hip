@@ -299,6 +299,248 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv_stem2_split_kernel(const S
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same two layers in the fp16-activation configuration (precision mode 2; round 5): conv1 from the fp32 image with fp32
+// weights (split operands on the matrix pipe as above: fp32-level sums, then ONE rounding to fp16 -- what conv_stem_kernel<f16>
+// stores), conv2.0 on fp16 operands (one matrix instruction per step, fp16 weight rows of pack.py: conv_weights_f16), fp16 NHWC
+// out.  Separately the 32-channel full-resolution activation costs 0.30 + 0.30 ms at bs = 32 (606 MB written, 606 MB read).
+// Without the lo halves a workgroup needs 36 864 (weights: 18 steps x 64 rows x 32 B) + 36 992 (activations: 17 rows x 34 slots
+// of 64 B) + 7 980 (patch) = 81 836 bytes: TWO workgroups per CU, whose phases overlap by themselves.
+constexpr int S2H_SLOTS = 34;                           // 17 even columns, then 16 odd ones (+ 1)
+constexpr int S2H_W_BYTES = 18 * 64 * 32;
+constexpr int S2H_S_BYTES = S2_SR * S2H_SLOTS * 64;
+typedef unsigned u32x2s __attribute__((__vector_size__(2 * sizeof(unsigned))));
+
+struct Stem2HParams {
+    const float* img;       // [B,3,H,W]
+    const float* w1;        // [32][27]
+    const float* sc1;
+    const float* sh1;
+    const _Float16* w2;     // conv2.0's fp16 rows [64][9][32]
+    const float* sc2;
+    const float* sh2;
+    _Float16* out;          // NHWC [B, H/2, W/2, out_ps]
+    int B, H, W, Ho, Wo, out_ps, leaky2;
+    int tiles_x, tiles_y, total_tiles;
+};
+
+__global__ __launch_bounds__(S2_THREADS, 4) void conv_stem2_f16_kernel(const Stem2HParams p) {
+    __shared__ f32x4 smem[(S2H_W_BYTES + S2H_S_BYTES + S2_P_FLOATS * 4 + 15) / 16];
+    char* const sW = reinterpret_cast<char*>(smem);
+    char* const sS = sW + S2H_W_BYTES;
+    float* const sP = reinterpret_cast<float*>(sS + S2H_S_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- conv2.0's weights: global [row][step][half] (16-byte pieces) -> LDS [step][row][half ^ ((row >> 3) & 1)], once
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.w2);
+#pragma unroll
+        for (int i = 0; i < (S2H_W_BYTES / 16 + S2_THREADS - 1) / S2_THREADS; ++i) {
+            const int idx = tid + i * S2_THREADS;
+            if (idx < S2H_W_BYTES / 16) {
+                const int n = idx / 36, rem = idx - n * 36;
+                const int step = rem >> 1, h = rem & 1;
+                *reinterpret_cast<f32x4*>(sW + step * 2048 + n * 32 + ((h ^ ((n >> 3) & 1)) * 16)) = src[idx];
+            }
+        }
+    }
+    const int fi = lane & 31, fk = lane >> 5;
+    f16x8 w1h[2], w1l[2];
+    // patch offset of contraction index k = (kh * 3 + kw) * 3 + ci: a compile-time table, selected by fk where it is used (sixteen
+    // registers of offsets held across the tile loop were what spilled at this kernel's 128)
+    auto koff_of = [](int k) constexpr {
+        const int kk = k < 27 ? k : 0;
+        const int t = kk / 3, ci = kk - 3 * t;
+        const int kh = t / 3, kw = t - 3 * kh;
+        return (ci * S2_PR + kh) * S2_PC + kw;
+    };
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = 16 * s2 + 8 * fk + i;
+            const int kk = k < 27 ? k : 0;
+            const float w = k < 27 ? p.w1[fi * 27 + kk] : 0.f;
+            const _Float16 h = (_Float16)w;
+            w1h[s2][i] = h;
+            w1l[s2][i] = (_Float16)(w - (float)h);
+        }
+    // conv2.0's role: wave = 32 outputs (two tile rows) x 32 channels
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m = 32 * wm + fi;
+    const int oy = m >> 4, ox = m & 15;
+    const int nrow = 32 * wn + fi;
+    const int boff = nrow * 32 + ((fk ^ ((nrow >> 3) & 1)) * 16);
+    const int c8 = lane & 7;
+    const int nb = 32 * wn + 4 * c8;
+    asm volatile("" ::"v"(w1h[0]), "v"(w1h[1]), "v"(w1l[0]), "v"(w1l[1]));
+
+    constexpr int NSTAGE = (S2_P_FLOATS + S2_THREADS - 1) / S2_THREADS;
+    float stage[NSTAGE];
+    auto request_patch = [&](int tile) {
+        const int b = tile / (p.tiles_x * p.tiles_y);
+        const int tr = tile - b * (p.tiles_x * p.tiles_y);
+        const int ty = tr / p.tiles_x, tx = tr - ty * p.tiles_x;
+        const int y0 = 2 * ty * S2_TY - 1, x0 = 2 * tx * S2_TX - 1;
+        const auto rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.img + (size_t)b * 3 * p.H * p.W), 0, 3 * p.H * p.W * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int e = tid + i * S2_THREADS;
+            const int c = e / (S2_PR * S2_PC), r = e - c * (S2_PR * S2_PC);
+            const int py = r / S2_PC, px = r - py * S2_PC;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            const bool ok = tile < p.total_tiles && e < S2_P_FLOATS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            stage[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_img, ok ? ((c * p.H + gy) * p.W + gx) * 4 : (int)0x80000000, 0, 0));
+        }
+    };
+    request_patch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+        const int b = tile / (p.tiles_x * p.tiles_y);
+        const int tr = tile - b * (p.tiles_x * p.tiles_y);
+        const int ty = tr / p.tiles_x, tx = tr - ty * p.tiles_x;
+        const int oy0 = ty * S2_TY, ox0 = tx * S2_TX;
+        const int y0 = 2 * oy0 - 1, x0 = 2 * ox0 - 1;
+        // ---- 1. the image patch
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int e = tid + i * S2_THREADS;
+            if (e < S2_P_FLOATS) sP[e] = stage[i];
+        }
+        __syncthreads();
+        // ---- 2. conv1 + BatchNorm + LeakyReLU -> fp16, into conv2.0's operand layout: slot x 64 B, the 16-byte chunk (8 channels)
+        // index XOR-ed with (slot >> 2) & 3 (conv_f16_common.h's 64-byte rows)
+#pragma unroll 1
+        for (int blk = wave; blk < (S2_SR * S2_SC + 31) / 32; blk += S2_THREADS / 64) {
+            const int pix = blk * 32 + fi;
+            const int pc = pix < S2_SR * S2_SC ? pix : S2_SR * S2_SC - 1;
+            const int r = pc / S2_SC, col = pc - r * S2_SC;
+            const float* win = sP + r * S2_PC + col;
+            int fk_here = fk;
+            asm volatile("" : "+v"(fk_here));          // the selects below stay in the loop
+            f32x16 acc1;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc1[q] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[i] = win[fk_here ? koff_of(16 * s2 + 8 + i) : koff_of(16 * s2 + i)];
+                    if (s2 == 1 && i >= 3) v[i] = fk ? 0.f : v[i];
+                }
+                f16x8 ah, al;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    ah[i] = (_Float16)v[i];
+                    al[i] = (_Float16)(v[i] - (float)ah[i]);
+                }
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[s2], al, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l[s2], ah, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h[s2], ah, acc1, 0, 0, 0);
+            }
+            const bool inside = pix < S2_SR * S2_SC && (unsigned)(y0 + r) < (unsigned)p.H && (unsigned)(x0 + col) < (unsigned)p.W;
+            const int slot = r * S2H_SLOTS + (col & 1) * 17 + (col >> 1);
+            const int sw = (slot >> 2) & 3;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                // channels 8 gq + 4 fk ..: chunk gq, half fk of the chunk
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.sc1 + 8 * gq + 4 * fk);
+                const f32x4 h1 = *reinterpret_cast<const f32x4*>(p.sh1 + 8 * gq + 4 * fk);
+                f32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float t = fmaf(acc1[4 * gq + k], s1[k], h1[k]);
+                    o[k] = inside ? (t > 0.f ? t : t * 0.1f) : 0.f;
+                }
+                const f16x4 h = __builtin_convertvector(o, f16x4);
+                if (pix < S2_SR * S2_SC) *reinterpret_cast<u32x2*>(sS + slot * 64 + ((gq ^ sw) * 16) + fk * 8) = __builtin_bit_cast(u32x2, h);
+            }
+        }
+        __syncthreads();
+        request_patch(tile + gridDim.x);
+        // ---- 3. conv2.0: 9 taps x 2 chunks of 16 channels, fragments one step ahead
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+        f32x4 cur[2], nxt[2];
+        auto read_step = [&](f32x4(&f)[2], int step) {
+            const int tap = step >> 1, c = step & 1;
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const int slot = (2 * oy + kh) * S2H_SLOTS + (kw & 1) * 17 + ox + (kw >> 1);
+            const int sw = (slot >> 2) & 3;
+            f[0] = *reinterpret_cast<const f32x4*>(sS + slot * 64 + (((2 * c + fk) ^ sw) * 16));
+            f[1] = *reinterpret_cast<const f32x4*>(sW + step * 2048 + boff);
+        };
+        read_step(cur, 0);
+#pragma unroll
+        for (int step = 0; step < 18; ++step) {
+            if (step + 1 < 18) read_step(nxt, step + 1);
+            // weights first: D[i = channel][j = output]
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur[1]), __builtin_bit_cast(f16x8, cur[0]), acc2, 0, 0, 0);
+            cur[0] = nxt[0]; cur[1] = nxt[1];
+        }
+        __syncthreads();        // every wave is done with the activations: their LDS takes the transposes
+        // ---- 4. epilogue: 32 x 32 transpose through 4 KiB of the wave's own, then one channel quad of four outputs per lane
+        {
+            f32x4* sT = reinterpret_cast<f32x4*>(sS) + wave * 256;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 v = {acc2[4 * gq], acc2[4 * gq + 1], acc2[4 * gq + 2], acc2[4 * gq + 3]};
+                sT[fi * 8 + ((2 * gq + fk) ^ (fi & 7))] = v;
+            }
+            const f32x4 sc2 = *reinterpret_cast<const f32x4*>(p.sc2 + nb);      // per tile, from cache: eight registers less across the loop
+            const f32x4 sh2 = *reinterpret_cast<const f32x4*>(p.sh2 + nb);
+            const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * p.Ho * p.Wo * p.out_ps, 0, p.Ho * p.Wo * p.out_ps * 2, 0x00020000);
+#pragma unroll
+            for (int rd = 0; rd < 4; ++rd) {
+                const int e = 8 * rd + (lane >> 3);
+                const f32x4 v = sT[e * 8 + (c8 ^ (e & 7))];
+                const int mm = 32 * wm + e;
+                const int oyy = oy0 + (mm >> 4), oxx = ox0 + (mm & 15);
+                const bool ok = oyy < p.Ho && oxx < p.Wo;
+                f32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float t = fmaf(v[k], sc2[k], sh2[k]);
+                    o[k] = p.leaky2 ? (t > 0.f ? t : t * 0.1f) : t;
+                }
+                const f16x4 h = __builtin_convertvector(o, f16x4);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2s, h), rs_out,
+                                                      ok ? ((oyy * p.Wo + oxx) * p.out_ps + nb) * 2 : (int)0x80000000, 0, 0);
+            }
+        }
+    }
+}
+
+int launch_conv_stem2_f16(const float* in_nchw, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
+                          const void* w2_f16, const float* scale2, const float* shift2, int cout2, int leaky2, void* out_nhwc_f16,
+                          int out_pix_stride, hipStream_t stream) {
+    OM_REQUIRE(in_nchw && w1 && scale1 && shift1 && w2_f16 && scale2 && shift2 && out_nhwc_f16, OM_EINVAL, "stem2 f16: null pointer");
+    OM_REQUIRE(cout2 == 64, OM_EINVAL, "stem2 f16: cout=%d, only 64 supported", cout2);
+    OM_REQUIRE(B > 0 && H > 1 && W > 1 && H % 2 == 0 && W % 2 == 0, OM_EINVAL, "stem2 f16: bad shape B=%d H=%d W=%d", B, H, W);
+    OM_REQUIRE(out_pix_stride % 4 == 0 && out_pix_stride >= 64 && (reinterpret_cast<uintptr_t>(out_nhwc_f16) & 7) == 0 &&
+                   (reinterpret_cast<uintptr_t>(w2_f16) & 15) == 0,
+               OM_EINVAL, "stem2 f16: output view must be 8-byte, the weights 16-byte aligned");
+    OM_REQUIRE((long long)(H / 2) * (W / 2) * out_pix_stride * 2 < 0x7FFFFFF0ll && (long long)3 * H * W * 4 < 0x7FFFFFF0ll, OM_EINVAL,
+               "stem2 f16: an image of %d x %d exceeds a buffer descriptor", H, W);
+    Stem2HParams p;
+    p.img = in_nchw; p.w1 = w1; p.sc1 = scale1; p.sh1 = shift1;
+    p.w2 = static_cast<const _Float16*>(w2_f16); p.sc2 = scale2; p.sh2 = shift2;
+    p.out = static_cast<_Float16*>(out_nhwc_f16);
+    p.B = B; p.H = H; p.W = W; p.Ho = H / 2; p.Wo = W / 2; p.out_ps = out_pix_stride; p.leaky2 = leaky2;
+    p.tiles_x = (p.Wo + S2_TX - 1) / S2_TX; p.tiles_y = (p.Ho + S2_TY - 1) / S2_TY;
+    const long long total = (long long)B * p.tiles_x * p.tiles_y;
+    OM_REQUIRE(total < (1ll << 31), OM_EINVAL, "stem2 f16: %lld tiles out of range", total);
+    p.total_tiles = (int)total;
+    const unsigned grid = (unsigned)(total < 512 ? total : 512);
+    hipLaunchKernelGGL(conv_stem2_f16_kernel, dim3(grid), dim3(S2_THREADS), 0, stream, p);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
 // w2_split / scale2_split: conv2.0's packed hi/lo weights and scale * 2^-e (include/orienmask_hip.h: om_layer_info.wsplit_off)
 int launch_conv_stem2_split(const float* in_nchw, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
                             const void* w2_split, const float* scale2_split, const float* shift2, int cout2, int leaky2,

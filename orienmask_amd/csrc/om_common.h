@@ -121,6 +121,10 @@ size_t wino24_scratch_floats(int B, int H, int W, int C);
 // fused F(4,3)-along-the-rows form with split operands (conv_wino14.hip): a.w = packed hi/lo weights [n_tiles][cin/16][6][3][64][32]
 int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream);
 // backbone.conv1 + backbone.conv2.0 as one kernel with split operands (conv_stem2.hip): image NCHW -> conv2.0's NHWC output
+// conv1 + conv2.0 of the fp16-activation configuration as one kernel (conv_stem2.hip: conv_stem2_f16_kernel)
+int launch_conv_stem2_f16(const float* in_nchw, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
+                          const void* w2_f16, const float* scale2, const float* shift2, int cout2, int leaky2, void* out_nhwc_f16,
+                          int out_pix_stride, hipStream_t stream);
 int launch_conv_stem2_split(const float* in_nchw, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
                             const void* w2_split, const float* scale2_split, const float* shift2, int cout2, int leaky2,
                             float* out_nhwc, int out_pix_stride, int* status, hipStream_t stream);

@@ -352,6 +352,17 @@ struct om_model {
                b.info.wsplit_off >= 0 && b.info.wino_planes != 24;
     }
 
+    // the fp16-activation forward: the same two layers as conv_stem2_f16_kernel (round 5), under the same conditions
+    bool stem2_fused_f16(size_t index) const {
+        static const bool off = [] { const char* e = std::getenv("OM_NO_STEM2_F16"); return e && e[0] == '1'; }();      // A/B runs
+        if (off || keep_all || index != 0 || layers.size() < 2 || !layers[0].stem) return false;
+        const om::LayerDef& a = layers[0];
+        const om::LayerDef& b = layers[1];
+        return a.info.cout == 32 && b.info.cin == 32 && b.info.cout == 64 && b.info.cout_pad == 64 && b.info.ksize == 3 &&
+               b.info.stride == 2 && !b.has_res && b.out_mode == 0 && b.in.buf == a.out.buf && b.in.ch_off == a.out.ch_off &&
+               b.info.w16_off >= 0 && b.out.buf >= 0;
+    }
+
     size_t buf_floats(int i, int B, int H, int W) const {
         return (size_t)B * (H / bufs[i].div) * (W / bufs[i].div) * bufs[i].C;
     }
@@ -666,6 +677,22 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             fused_into_previous = true;
             continue;
         }
+        if (L.stem && f16 && m->stem2_fused_f16(&L - m->layers.data())) {
+            // fp16 activations: conv1 and conv2.0 as one kernel too (conv_stem2_f16_kernel)
+            const om::LayerDef& N = m->layers[(&L - m->layers.data()) + 1];
+            if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
+            int rc = om::launch_conv_stem2_f16(x, B, Hin, Win, w, scale, shift, m->weights16 + N.info.w16_off,
+                                               m->weights + N.info.scale_off, m->weights + N.info.shift_off, N.info.cout, N.info.leaky,
+                                               ptr_of(N.out), m->pix_stride(N.out.buf), stream);
+            if (rc != OM_OK) {
+                char msg[512];
+                std::snprintf(msg, sizeof(msg), "%s", om::g_err);
+                om::set_error("layers %s + %s: %s", li.name, N.info.name, msg);
+                return rc;
+            }
+            fused_into_previous = true;
+            continue;
+        }
         if (L.stem) {
             if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
             int rc = f16 ? om::launch_conv_stem_f16(x, B, Hin, Win, w, scale, shift, li.cout, ptr_of(L.out), stream)
@@ -822,7 +849,9 @@ int om_layer_tile_f16(const om_model* m, int index, int B, int H, int W, int* bm
     OM_REQUIRE(m && bm && bn && algo, OM_EINVAL, "om_layer_tile_f16: null argument");
     OM_REQUIRE(index >= 0 && index < (int)m->layers.size(), OM_EINVAL, "om_layer_tile_f16: index %d", index);
     const om::LayerDef& L = m->layers[index];
+    if (L.stem && m->stem2_fused_f16((size_t)index)) { *bm = 128; *bn = 64; *algo = 7; return OM_OK; }      // conv1 + conv2.0 in one kernel
     if (L.stem) { *bm = 0; *bn = 0; *algo = 0; return OM_OK; }
+    if (index == 1 && m->stem2_fused_f16(0)) { *bm = 0; *bn = 0; *algo = 8; return OM_OK; }                // ... which this layer is part of
     const int Hin = H / L.in_div, Win = W / L.in_div;
     const int Ho = Hin / L.info.stride, Wo = Win / L.info.stride;
     om::ConvArgsH a{};
@@ -1208,6 +1237,13 @@ int om_set_wino14_variant(int variant) {
     OM_REQUIRE(variant == 0 || variant == 1, OM_EINVAL, "om_set_wino14_variant: %d", variant);
     om::wino14_set_variant(variant);
     return OM_OK;
+}
+
+int om_conv2d_stem2_f16(const float* in, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
+                        const void* w2_f16, const float* scale2, const float* shift2, int cout2, int leaky2, void* out, int out_pix_stride,
+                        om_stream stream) {
+    return om::launch_conv_stem2_f16(in, B, H, W, w1, scale1, shift1, w2_f16, scale2, shift2, cout2, leaky2, out, out_pix_stride,
+                                     static_cast<hipStream_t>(stream));
 }
 
 int om_set_conv3x3_f16_variant(int mode) {

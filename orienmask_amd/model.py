@@ -452,8 +452,9 @@ class OrienMaskYOLOFPNPlus(nn.Module):
                 _lib.check(_lib.load().om_layer_tile_f16(h, i, B, H, W, ctypes.byref(bm), ctypes.byref(bn),
                                                          ctypes.byref(algo)), "om_layer_tile_f16")
                 fmt = {0: "conv_stem_kernel<f16>", 1: "conv_igemm_f16_kernel<%d,%d>", 4: "conv3x3_f16_kernel<%d,%d>",
-                       5: "conv_igemm_f16_kernel<%d,%d,gather>", 6: "conv3x3_f16_tall_kernel<%d,%d>"}[algo.value]
-                out.append((l["name"], fmt % (bm.value, bn.value) if algo.value else fmt))
+                       5: "conv_igemm_f16_kernel<%d,%d,gather>", 6: "conv3x3_f16_tall_kernel<%d,%d>",
+                       7: "conv_stem2_f16_kernel<%d,%d>", 8: "(in the previous layer's kernel)"}[algo.value]
+                out.append((l["name"], fmt % (bm.value, bn.value) if algo.value not in (0, 8) else fmt))
             return out
         _lib.check(_lib.load().om_model_set_precision(h, 1 if self.precision == "f32_split" else 0), "om_model_set_precision")
         for i, l in enumerate(self._layers):

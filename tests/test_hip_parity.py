@@ -1710,6 +1710,53 @@ def test_stem_f16_matches_torch(dev):
     assert ((got - want).abs() <= bound).all()
 
 
+@pytest.mark.parametrize("shape", [(2, 40, 72), (1, 34, 50), (3, 16, 32), (1, 96, 160)])
+def test_stem2_f16_matches_two_kernels(dev, shape):
+    """conv_stem2_f16_kernel -- backbone.conv1 + backbone.conv2.0 of the fp16-activation configuration as ONE kernel (round 5) --
+    against the definition of that configuration (float64 conv1, ONE rounding to fp16, fp16 weights, float64 conv2.0, one rounding)
+    and against om_conv2d_stem_f16 followed by om_conv2d_f16; partial tiles in both directions, an output view with its own stride."""
+    from orienmask_amd.pack import conv_weights_f16
+    B, H, W = shape
+    L = omlib.load()
+    g = torch.Generator().manual_seed(sum(shape) + 7)
+    x = torch.rand(B, 3, H, W, generator=g) * 2 - 0.5
+    w1 = torch.randn(32, 3, 3, 3, generator=g) * 0.3
+    sc1 = torch.rand(32, generator=g) + 0.5
+    sh1 = torch.randn(32, generator=g) * 0.2
+    w2 = (torch.randn(64, 32, 3, 3, generator=g) / (32 * 9) ** 0.5).half()
+    sc2 = torch.rand(64, generator=g) + 0.5
+    sh2 = torch.randn(64, generator=g) * 0.2
+    a = torch.nn.functional.conv2d(x.double(), w1.double(), None, 1, 1) * sc1.double().view(1, -1, 1, 1) + sh1.double().view(1, -1, 1, 1)
+    a = torch.where(a > 0, a, a * 0.1).half().double()
+    want = torch.nn.functional.conv2d(a, w2.double(), None, 2, 1) * sc2.double().view(1, -1, 1, 1) + sh2.double().view(1, -1, 1, 1)
+    want = torch.where(want > 0, want, want * 0.1)
+    w1p = w1.permute(0, 2, 3, 1).reshape(32, 27).contiguous().to(dev)
+    w2d = conv_weights_f16(w2.float(), 64).contiguous().to(dev)
+    xd, sc1d, sh1d, sc2d, sh2d = x.to(dev), sc1.to(dev), sh1.to(dev), sc2.to(dev), sh2.to(dev)
+    st = omlib.current_stream_ptr(dev)
+    Ho, Wo = H // 2, W // 2
+    mid = torch.empty(B, H, W, 32, device=dev, dtype=torch.float16)
+    omlib.check(L.om_conv2d_stem_f16(_p(xd), B, H, W, _p(w1p), _p(sc1d), _p(sh1d), 32, _p(mid), st), "om_conv2d_stem_f16")
+    two = torch.full((B, Ho, Wo, 64), float("nan"), device=dev, dtype=torch.float16)
+    omlib.check(L.om_conv2d_f16(_p(mid), B, H, W, 32, 32, _p(w2d), _p(sc2d), _p(sh2d), 64, 3, 2, 1, None, 0, _p(two), 64, 0, st), "om_conv2d_f16")
+    ostride = 80
+    buf = torch.full((B, Ho, Wo, ostride), float("nan"), device=dev, dtype=torch.float16)
+    view = buf[..., 8:]
+    omlib.check(L.om_conv2d_stem2_f16(_p(xd), B, H, W, _p(w1p), _p(sc1d), _p(sh1d), _p(w2d), _p(sc2d), _p(sh2d), 64, 1,
+                                      ctypes.c_void_p(view.data_ptr()), ostride, st), "om_conv2d_stem2_f16")
+    one = buf[..., 8:72]
+    assert torch.isnan(buf[..., :8]).all() and torch.isnan(buf[..., 72:]).all()      # nothing outside the 64 channels
+    got = one.cpu().permute(0, 3, 1, 2).double()
+    assert torch.isfinite(got).all()
+    # one rounding to fp16 of a value whose conv1 operands may differ from the float64 ones by a rounding tie (rare): the same
+    # bound as the single fp16 layers, plus a few 1e-4 of scale for those
+    bound = want.abs() * 2.0 ** -10 + 3e-4 * want.abs().max()
+    assert ((got - want).abs() <= bound).all(), ((got - want).abs() / bound).max().item()
+    same = (one == two).float().mean().item()
+    print("stem2 f16 %s: %.4f of the outputs equal the two-kernel path's bit for bit" % (shape, same))
+    assert same > 0.97 and _rel_err(one.cpu().double(), two.cpu().double()) < 2e-3
+
+
 F16_FWD_TOL = 1e-2       # of each head tensor's scale, HIP fp16 path vs oracle.forward_f16 (same arithmetic, other sum order)
 F16_VS_F32_TOL = 5e-2    # fp16 path vs the fp32 path on the same weights and image
 
