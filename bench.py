@@ -42,7 +42,7 @@ ANCHOR_MASK = [[6, 7, 8], [3, 4, 5], [0, 1, 2]]
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-PROFILE_TAG = "r04"                # profiles/<tag>_pmc_traffic*.json: the PMC passes whose `traffic` this build may quote
+PROFILE_TAG = "r05"                # profiles/<tag>_pmc_traffic*.json: the PMC passes whose `traffic` this build may quote
 WEIGHT_SEED, OBJ_BIAS, HEAD_GAIN = 3, -16.0, 4.0
 OBJ_BIAS_SPARSE = -18.5     # a few tens of detections per image (-18: 67, -19: 11, -20: 3, <= -24: none)
 
