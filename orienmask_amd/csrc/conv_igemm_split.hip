@@ -35,12 +35,6 @@ namespace om {
 #if defined(OM_SPLIT_NO_XCD_PLACEMENT) && !defined(OM_MEASUREMENT_BUILD)
 #error "OM_SPLIT_NO_XCD_PLACEMENT is a measurement switch: tools/build_variant.sh only"
 #endif
-#ifndef OM_SPLIT_A_AUX
-#define OM_SPLIT_A_AUX 0       // cache-policy bits of the wide kernel's activation requests (2 = nt: streamed once)
-#endif
-#ifndef OM_SPLIT_NT_OUT
-#define OM_SPLIT_NT_OUT 0      // 1: the load-free epilogue's stores are non-temporal
-#endif
 #ifndef OM_SPLIT_TRACE
 #define OM_SPLIT_TRACE 0       // measurement builds only: s_memtime stamps per tile of the wide kernel (tools/split_trace.py)
 #endif
@@ -158,13 +152,8 @@ __device__ __forceinline__ void split_epilogue(const IgemmSParams& p, f32x4* sme
                 }
                 if (m < p.M) {
                     float* o = p.out + (size_t)m * p.out_pix_stride + n;
-#if OM_SPLIT_NT_OUT
-                    __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(o));
-                    __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(o + 4));
-#else
                     *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
-#endif
                 }
             }
         } else if (p.out_mode != 2) {
@@ -720,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_wide_kernel(const Ige
                 const int tap_off = GATHER ? (n_cc - seg_c0) * 128      // 1x1: one tap; the chunk within its segment
                                            : ((n_kh * p.W + n_kw) * p.in_pix_stride_h + n_cc * 64) * 2;      // scalar
                 const int voff = (rowoff[j] + tap_off) | ((invmask[j] << (31 - tap)) & 0x80000000u);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(dst + j * 256), 16, voff, 0, 0, OM_SPLIT_A_AUX);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(dst + j * 256), 16, voff, 0, 0, 0);
             } else {
                 const int j = piece - A_CH;
                 const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, live ? p.w_bytes : 0, 0x00020000);
