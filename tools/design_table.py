@@ -33,7 +33,7 @@ rows = """| | value |
 | whole step (`roofline.step`, over the step time behind `value`) | split: %s TF executed = %s of 2.5 PF, PMC conv-stack bytes %s GB/s = **%s of 8 TB/s** (algorithmic %s); fp32 operands: %s TF = %s of 157.3 TF, PMC %s GB/s = %s; fp16 configuration: %s TF = %s of 2.5 PF, PMC %s GB/s = %s |
 | postprocess occupancy (north_star: "occupancy for NMS/mask-assembly") | §3.2 last bullet; `roofline.postprocess_occupancy` in the bench line |
 | cpu_baseline (oracle, GPU box's host, %s hardware threads) | thread sweep on one image (forward): %s; best: %s images/s end to end on %s threads; bs=1 forward %s ms, postprocess %s ms (the oracle's decode runs single-threaded for reproducibility, §3.2); reported baseline, not a target |
-| fp16 configuration (`--dtype f16`, `%s_bench_f16.json`) | %s images/s (bs=32) with three batches in flight, %s one at a time (round 3: its stem kernel and its epilogues without store waits, §3.5) |
+| fp16 configuration (`--dtype f16`, `%s_bench_f16.json`) | %s images/s (bs=32) with three batches in flight, %s one at a time (round 4: 4192 / 3249; round 5: the tall-patch / ping-pong 3×3 kernel and the first two layers in one kernel, §3.3) |
 """ % (d["value"], d["ms_per_step"], sp["value"], d["one_batch_in_flight"]["value"], d["one_batch_in_flight"]["ms_per_step"],
        r["forward_kernels_ms_per_step"], r["postprocess_ms_per_step"],
        tag, d["f32_operands"]["value"], d["f32_operands"]["one_batch_in_flight"], e["value"], e["one_batch_in_flight"]["value"],
