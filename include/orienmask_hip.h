@@ -335,6 +335,15 @@ int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const f
 int om_conv2d_stem2_split(const float* in, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
                           const void* w2_split, const float* scale2_split, const float* shift2, int cout2, int leaky2, float* out,
                           int out_pix_stride, int32_t* status_dev, om_stream stream);
+/* ... with the layer behind them in the same launch (round 5): backbone.conv2.1.conv.0, the 64 -> 32 1x1 convolution of the first
+ * residual block (/root/reference/model/backbone/darknet.py:9-13), computed on each tile's conv2.0 outputs while they are in the
+ * workgroup: `out` is written as by om_conv2d_stem2_split (the block's residual reads it), `out3` [B,H/2,W/2,out3_pix_stride] gets
+ * what om_conv2d_split would compute from it -- the same split8 / three-instruction arithmetic per 16 channels, bit for bit.
+ * w3_split / scale3_split: conv_weights_split rows [32][4][4][8] halfs and scale * 2^-e; cout3 = 32. */
+int om_conv2d_stem3_split(const float* in, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
+                          const void* w2_split, const float* scale2_split, const float* shift2, int cout2, int leaky2, float* out,
+                          int out_pix_stride, const void* w3_split, const float* scale3_split, const float* shift3, int cout3, int leaky3,
+                          float* out3, int out3_pix_stride, int32_t* status_dev, om_stream stream);
 /* The same two layers as om_forward_f16 runs them (conv_stem2.hip: conv_stem2_f16_kernel; round 5): conv1 from the fp32 image with
  * fp32 weights (fp32-level sums, one rounding to fp16 -- the activation om_conv2d_stem_f16 stores, never written here), conv2.0 on
  * fp16 operands: w2_f16 = its fp16 rows [64][9 * 32] (om_layer_info.w16_off), scale2 / shift2 [64] fp32; out [B,H/2,W/2,out_pix_stride]

@@ -1044,6 +1044,13 @@ int launch_conv_igemm_split(const ConvArgs& a, hipStream_t stream) {
     }
     if (bm == 128 && bn == 64 && deep) return launch_tile_split<128, 64, 64, 32, false, false, 5>(p, a.cout_pad, 2, stream);
     if (bm == 64 && bn == 64 && deep) return launch_tile_split<64, 64, 32, 32, false, false, 8>(p, a.cout_pad, 2, stream);
+#ifndef OM_SPLIT_WIDE_SMALLN
+#define OM_SPLIT_WIDE_SMALLN 0
+#endif
+#if OM_SPLIT_WIDE_SMALLN
+    if (bm == 128 && bn == 64 && a.cin % 32 == 0 && !a.force_bm) return launch_tile_split<128, 64, 64, 32, true>(p, a.cout_pad, OM_SPLIT_WIDE_SMALLN, stream);
+    if (bm == 128 && bn == 32 && a.cin % 32 == 0 && !a.force_bm) return launch_tile_split<128, 32, 32, 32, true>(p, a.cout_pad, OM_SPLIT_WIDE_SMALLN + 1, stream);
+#endif
     if (bm == 128 && bn == 64) return launch_tile_split<128, 64, 64, 32>(p, a.cout_pad, 4, stream);
     if (bm == 64 && bn == 64) return launch_tile_split<64, 64, 32, 32>(p, a.cout_pad, 4, stream);
     return launch_tile_split<128, 32, 32, 32>(p, a.cout_pad, 4, stream);

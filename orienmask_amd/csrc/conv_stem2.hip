@@ -52,8 +52,20 @@ struct Stem2Params {
     int* status;
     int B, H, W, Ho, Wo, out_ps, leaky2;
     int tiles_x, tiles_y, total_tiles;
+    // optional THIRD layer (round 5): the 1x1 convolution 64 -> 32 behind conv2.0 (backbone.conv2.1.conv.0, darknet.py:9-13) on the
+    // tile's outputs while they are still in the workgroup -- conv2.0's activation is written once (the residual needs it) and not
+    // read back: w3 = conv_weights_split rows [32][4][4][8] halfs, sc3 = scale * 2^-e, out3 NHWC [B, H/2, W/2, out3_ps]; nullptr: off
+    const _Float16* w3;
+    const float* sc3;
+    const float* sh3;
+    float* out3;
+    int out3_ps, leaky3;
 };
 
+// rows r and r + 1 differ in bit 3 of the chunk, rows r and r + 2 in its low bits: a bijection of r & 15
+__device__ __forceinline__ int s2_row_swizzle(int r) { return ((r & 1) << 3) | ((r >> 1) & 7); }
+
+template <bool THIRD>
 __global__ __launch_bounds__(S2_THREADS, 2) void conv_stem2_split_kernel(const Stem2Params p) {
     __shared__ f32x4 smem[(S2_W_BYTES + S2_S_BYTES + S2_P_FLOATS * 4 + 15) / 16];
     char* const sW = reinterpret_cast<char*>(smem);
@@ -97,13 +109,8 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv_stem2_split_kernel(const S
             w1h[s2][i] = h;
             w1l[s2][i] = (_Float16)(w - (float)h);
         }
-    // the 16 channels a lane holds of an activation after the products: 8 (r >> 2) + 4 fk + (r & 3)
-    f32x4 sc1[4], sh1[4];
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-        sc1[gq] = *reinterpret_cast<const f32x4*>(p.sc1 + 8 * gq + 4 * fk);
-        sh1[gq] = *reinterpret_cast<const f32x4*>(p.sh1 + 8 * gq + 4 * fk);
-    }
+    // (the 16 channels a lane holds of an activation after the products: 8 (r >> 2) + 4 fk + (r & 3); their scale / shift are
+    // requested per block of activations, in front of its window gather: 32 registers less across the kernel's life)
     // ---- conv2.0's role: wave = 32 outputs (two tile rows) x 32 channels
     const int wm = wave >> 1, wn = wave & 1;
     const int m = 32 * wm + fi;
@@ -117,8 +124,6 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv_stem2_split_kernel(const S
     const f32x4 sc2 = *reinterpret_cast<const f32x4*>(p.sc2 + nb);
     const f32x4 sh2 = *reinterpret_cast<const f32x4*>(p.sh2 + nb);
     // the pre-loop loads have landed as far as the compiler's wait bookkeeping goes (conv_stem.hip)
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) asm volatile("" ::"v"(sc1[gq]), "v"(sh1[gq]));
     asm volatile("" ::"v"(w1h[0]), "v"(w1h[1]), "v"(w1l[0]), "v"(w1l[1]), "v"(sc2), "v"(sh2));
     float nonfinite = 0.f;
 
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv_stem2_split_kernel(const S
         const int oy0 = ty * S2_TY, ox0 = tx * S2_TX;
         const int y0 = 2 * oy0 - 1, x0 = 2 * ox0 - 1;       // conv1 activation (row 0, column 0) of the tile
 #ifdef OM_S2_TRACE
-        unsigned long long t0, t1, t2, t3, t4;
+        unsigned long long t0, t1, t2, t3, t4;      // tools/stem2_trace.py
         asm volatile("s_memtime %0" : "=s"(t0)::"memory");
 #endif
         // ---- 1. the image patch: rows y0 - 1 .., columns x0 - 1 ..
@@ -171,6 +176,12 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv_stem2_split_kernel(const S
             const int pc = pix < S2_SR * S2_SC ? pix : S2_SR * S2_SC - 1;       // lanes beyond the last activation repeat it
             const int r = pc / S2_SC, col = pc - r * S2_SC;
             const float* win = sP + r * S2_PC + col;
+            f32x4 sc1[4], sh1[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                sc1[gq] = *reinterpret_cast<const f32x4*>(p.sc1 + 8 * gq + 4 * fk);
+                sh1[gq] = *reinterpret_cast<const f32x4*>(p.sh1 + 8 * gq + 4 * fk);
+            }
             f32x16 acc1;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc1[q] = 0.f;
@@ -222,16 +233,31 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv_stem2_split_kernel(const S
         asm volatile("s_memtime %0" : "=s"(t2)::"memory");
 #endif
         request_patch(tile + gridDim.x);        // the patch is dead: its registers take the next tile's
+        // the third layer's weights of this lane (fi = output channel, fk), hi and lo of its four k-steps: requested a matrix phase
+        // and an epilogue before their use (~2 500 cycles from L2 under this kernel's load)
+        f16x8 w3h[4], w3l[4];
+        if constexpr (THIRD) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f32x4* row = reinterpret_cast<const f32x4*>(p.w3 + fi * 128 + ks * 32);      // 64 B per k-step: [hi | hi | lo | lo]
+                w3h[ks] = __builtin_bit_cast(f16x8, row[fk]);
+                w3l[ks] = __builtin_bit_cast(f16x8, row[2 + fk]);
+            }
+        }
         // ---- 3. conv2.0
         f32x16 acc2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
         // fragments one step ahead of the matrix instructions that use them
         f32x4 cur[4], nxt[4];
+        // (the output's position made opaque per tile: as loop invariants the 18 steps' swizzled LDS addresses were kept in ~40
+        // registers across the whole tile loop, and the kernel spilled)
+        int oy_t = oy, ox_t = ox;
+        asm volatile("" : "+v"(oy_t), "+v"(ox_t));
         auto read_step = [&](f32x4(&f)[4], int step) {
             const int tap = step >> 1, c = step & 1;
             const int kh = tap / 3, kw = tap - 3 * kh;
-            const int slot = (2 * oy + kh) * S2_SLOTS + (kw & 1) * 17 + ox + (kw >> 1);
+            const int slot = (2 * oy_t + kh) * S2_SLOTS + (kw & 1) * 17 + ox_t + (kw >> 1);
             const int sq = (slot >> 1) & 3, sg = (slot >> 3) & 1;
             const char* arow = sS + slot * 128 + ((c ^ sg) * 64);
             const char* brow = sW + step * 4096;
@@ -257,6 +283,18 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv_stem2_split_kernel(const S
         asm volatile("s_memtime %0" : "=s"(t3)::"memory");
 #endif
         __syncthreads();        // every wave is done with the activations: their LDS takes the transposes
+        // the third layer's operands of this lane (fi = output channel, fk): hi and lo weights of its four k-steps, scale and shift --
+        // requested HERE, an epilogue before their use (requested where they are used, their round trip to L2 stood in front of every
+        // tile's last stores: 0.12 ms per launch; held for the kernel's life, or across conv2.0's matrix phase, they cost that phase
+        // its registers)
+        f32x4 s3v[4], h3v[4];
+        if constexpr (THIRD) {       // (every wave, no branch around the requests: the compiler's wait-count bookkeeping takes the worst path)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s3v[ks] = *reinterpret_cast<const f32x4*>(p.sc3 + 8 * ks + 4 * fk);
+                h3v[ks] = *reinterpret_cast<const f32x4*>(p.sh3 + 8 * ks + 4 * fk);
+            }
+        }
         // ---- 4. epilogue: 32 x 32 transpose through 4 KiB of the wave's own, then one channel quad of four outputs per lane
         {
             f32x4* sT = reinterpret_cast<f32x4*>(sS) + wave * 256;
@@ -283,13 +321,71 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv_stem2_split_kernel(const S
                 nonfinite += ok ? nf : 0.f;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), rs_out,
                                                        ok ? ((oyy * p.Wo + oxx) * p.out_ps + nb) * 4 : (int)0x80000000, 0, 0);
+                // the third layer's operand: the tile's activation as fp32 rows [output][64 channels] behind the transposes, the
+                // 16-byte chunk index XOR-ed with s2_row_swizzle(row): a wave WRITES eight chunks of eight rows here and READS one
+                // chunk of 32 rows below, both without bank conflicts (with the plain row & 15 the writes were 8-way conflicts,
+                // eight waves at once: 3 000 cycles per tile, tools/stem2_trace.py)
+                if constexpr (THIRD) *reinterpret_cast<f32x4*>(sS + 32768 + mm * 256 + (((nb >> 2) ^ s2_row_swizzle(mm)) * 16)) = v;
+            }
+        }
+#ifdef OM_S2_TRACE
+        unsigned long long t3b;
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t3b)::"memory");
+#endif
+        if constexpr (THIRD) {
+            __syncthreads();        // the activation rows are complete
+            if (wave < 4) {
+                // 32 outputs x 32 channels x K = 64 per wave, conv_igemm_split_kernel's arithmetic: per 16 channels the lane's two
+                // chunks {4 fk .., 8 + 4 fk ..} split in registers (split8), three matrix instructions in its order
+                const int mrow = 32 * wave + fi;
+                const char* arow = sS + 32768 + mrow * 256;
+                f32x16 acc3;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc3[r] = 0.f;
+                f32x4 xr[4][2];          // all eight fragments first: one LDS round trip instead of four
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    xr[ks][0] = *reinterpret_cast<const f32x4*>(arow + (((4 * ks + fk) ^ s2_row_swizzle(mrow)) * 16));
+                    xr[ks][1] = *reinterpret_cast<const f32x4*>(arow + (((4 * ks + 2 + fk) ^ s2_row_swizzle(mrow)) * 16));
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const f32x4 x0 = xr[ks][0], x1 = xr[ks][1];
+                    f16x8 ah, al;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { ah[i] = (_Float16)x0[i]; ah[4 + i] = (_Float16)x1[i]; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { al[i] = (_Float16)(x0[i] - (float)ah[i]); al[4 + i] = (_Float16)(x1[i] - (float)ah[4 + i]); }
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3h[ks], al, acc3, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3l[ks], ah, acc3, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3h[ks], ah, acc3, 0, 0, 0);
+                }
+                // D[i = channel][j = output]: the lane holds channels 8 g + 4 fk .. + 3 (g = 0 .. 3) of output fi
+                const int oyy = oy0 + (mrow >> 4), oxx = ox0 + (mrow & 15);
+                const bool ok = oyy < p.Ho && oxx < p.Wo;
+                const auto rs_out3 = __builtin_amdgcn_make_buffer_rsrc(p.out3 + (size_t)b * p.Ho * p.Wo * p.out3_ps, 0, p.Ho * p.Wo * p.out3_ps * 4, 0x00020000);
+                float nf = 0.f;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 s3 = s3v[gq], h3 = h3v[gq];
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float t = fmaf(acc3[4 * gq + k], s3[k], h3[k]);
+                        nf = fmaf(t, 0.f, nf);
+                        o[k] = p.leaky3 ? (t > 0.f ? t : t * 0.1f) : t;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, o), rs_out3,
+                                                           ok ? ((oyy * p.Wo + oxx) * p.out3_ps + 8 * gq + 4 * fk) * 4 : (int)0x80000000, 0, 0);
+                }
+                nonfinite += ok ? nf : 0.f;
             }
         }
 #ifdef OM_S2_TRACE
         asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t4)::"memory");
         if (blockIdx.x == 0 && tid == 0 && tile == blockIdx.x + 3 * gridDim.x) {
             unsigned long long* tr = reinterpret_cast<unsigned long long*>(p.status);
-            tr[0] = t0; tr[1] = t1; tr[2] = t2; tr[3] = t3; tr[4] = t4;
+            tr[0] = t0; tr[1] = t1; tr[2] = t2; tr[3] = t3; tr[4] = t4; tr[5] = t3b;
         }
 #endif
         // the next tile's barrier (after its patch is staged) orders these transposes before the next activations
@@ -418,6 +514,12 @@ __global__ __launch_bounds__(S2_THREADS, 4) void conv_stem2_f16_kernel(const Ste
             const int pc = pix < S2_SR * S2_SC ? pix : S2_SR * S2_SC - 1;
             const int r = pc / S2_SC, col = pc - r * S2_SC;
             const float* win = sP + r * S2_PC + col;
+            f32x4 s1v[4], h1v[4];          // requested in front of the window gather: their round trip runs under it
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                s1v[gq] = *reinterpret_cast<const f32x4*>(p.sc1 + 8 * gq + 4 * fk);
+                h1v[gq] = *reinterpret_cast<const f32x4*>(p.sh1 + 8 * gq + 4 * fk);
+            }
             int fk_here = fk;
             asm volatile("" : "+v"(fk_here));          // the selects below stay in the loop
             f32x16 acc1;
@@ -447,8 +549,7 @@ __global__ __launch_bounds__(S2_THREADS, 4) void conv_stem2_f16_kernel(const Ste
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 // channels 8 gq + 4 fk ..: chunk gq, half fk of the chunk
-                const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.sc1 + 8 * gq + 4 * fk);
-                const f32x4 h1 = *reinterpret_cast<const f32x4*>(p.sh1 + 8 * gq + 4 * fk);
+                const f32x4 s1 = s1v[gq], h1 = h1v[gq];
                 f32x4 o;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -466,10 +567,12 @@ __global__ __launch_bounds__(S2_THREADS, 4) void conv_stem2_f16_kernel(const Ste
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
         f32x4 cur[2], nxt[2];
+        int oy_t = oy, ox_t = ox;          // opaque per tile (see conv_stem2_split_kernel)
+        asm volatile("" : "+v"(oy_t), "+v"(ox_t));
         auto read_step = [&](f32x4(&f)[2], int step) {
             const int tap = step >> 1, c = step & 1;
             const int kh = tap / 3, kw = tap - 3 * kh;
-            const int slot = (2 * oy + kh) * S2H_SLOTS + (kw & 1) * 17 + ox + (kw >> 1);
+            const int slot = (2 * oy_t + kh) * S2H_SLOTS + (kw & 1) * 17 + ox_t + (kw >> 1);
             const int sw = (slot >> 2) & 3;
             f[0] = *reinterpret_cast<const f32x4*>(sS + slot * 64 + (((2 * c + fk) ^ sw) * 16));
             f[1] = *reinterpret_cast<const f32x4*>(sW + step * 2048 + boff);
@@ -544,7 +647,7 @@ int launch_conv_stem2_f16(const float* in_nchw, int B, int H, int W, const float
 // w2_split / scale2_split: conv2.0's packed hi/lo weights and scale * 2^-e (include/orienmask_hip.h: om_layer_info.wsplit_off)
 int launch_conv_stem2_split(const float* in_nchw, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
                             const void* w2_split, const float* scale2_split, const float* shift2, int cout2, int leaky2,
-                            float* out_nhwc, int out_pix_stride, int* status, hipStream_t stream) {
+                            float* out_nhwc, int out_pix_stride, int* status, hipStream_t stream, const Stem2Third* third) {
     OM_REQUIRE(in_nchw && w1 && scale1 && shift1 && w2_split && scale2_split && shift2 && out_nhwc, OM_EINVAL, "stem2: null pointer");
     OM_REQUIRE(cout2 == 64, OM_EINVAL, "stem2: cout=%d, only 64 supported", cout2);
     OM_REQUIRE(B > 0 && H > 1 && W > 1 && H % 2 == 0 && W % 2 == 0, OM_EINVAL, "stem2: bad shape B=%d H=%d W=%d", B, H, W);
@@ -562,8 +665,19 @@ int launch_conv_stem2_split(const float* in_nchw, int B, int H, int W, const flo
     const long long total = (long long)B * p.tiles_x * p.tiles_y;
     OM_REQUIRE(total < (1ll << 31), OM_EINVAL, "stem2: %lld tiles out of range", total);
     p.total_tiles = (int)total;
+    p.w3 = nullptr; p.sc3 = nullptr; p.sh3 = nullptr; p.out3 = nullptr; p.out3_ps = 0; p.leaky3 = 0;
+    if (third) {
+        OM_REQUIRE(third->w_split && third->scale_split && third->shift && third->out && third->cout == 32 && third->out_pix_stride % 4 == 0 &&
+                       third->out_pix_stride >= 32 && (reinterpret_cast<uintptr_t>(third->out) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(third->w_split) & 15) == 0 &&
+                       (long long)(H / 2) * (W / 2) * third->out_pix_stride * 4 < 0x7FFFFFF0ll,
+                   OM_EINVAL, "stem2: the third layer must be a 64 -> 32 1x1 with a 16-byte aligned output view");
+        p.w3 = static_cast<const _Float16*>(third->w_split); p.sc3 = third->scale_split; p.sh3 = third->shift;
+        p.out3 = third->out; p.out3_ps = third->out_pix_stride; p.leaky3 = third->leaky;
+    }
     const unsigned grid = (unsigned)(total < 256 ? total : 256);
-    hipLaunchKernelGGL(conv_stem2_split_kernel, dim3(grid), dim3(S2_THREADS), 0, stream, p);
+    if (third) hipLaunchKernelGGL(conv_stem2_split_kernel<true>, dim3(grid), dim3(S2_THREADS), 0, stream, p);
+    else hipLaunchKernelGGL(conv_stem2_split_kernel<false>, dim3(grid), dim3(S2_THREADS), 0, stream, p);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }

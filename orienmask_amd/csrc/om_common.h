@@ -125,9 +125,17 @@ int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream);
 int launch_conv_stem2_f16(const float* in_nchw, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
                           const void* w2_f16, const float* scale2, const float* shift2, int cout2, int leaky2, void* out_nhwc_f16,
                           int out_pix_stride, hipStream_t stream);
+// the optional third layer of conv_stem2_split_kernel: a 64 -> 32 1x1 convolution on conv2.0's outputs (conv_stem2.hip)
+struct Stem2Third {
+    const void* w_split;        // conv_weights_split rows [32][4][4][8] halfs
+    const float* scale_split;   // scale * 2^-e
+    const float* shift;
+    float* out;                 // NHWC [B, H/2, W/2, out_pix_stride]
+    int cout, leaky, out_pix_stride;
+};
 int launch_conv_stem2_split(const float* in_nchw, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
                             const void* w2_split, const float* scale2_split, const float* shift2, int cout2, int leaky2,
-                            float* out_nhwc, int out_pix_stride, int* status, hipStream_t stream);
+                            float* out_nhwc, int out_pix_stride, int* status, hipStream_t stream, const Stem2Third* third = nullptr);
 size_t wino14_weight_halfs(int cout_pad, int cin);
 void wino14_geometry(int B, int H, int W, int* R, int* Ct, int* ncb, int* nrb);
 void wino14_set_variant(int v);      // conv_wino14.hip: 0 = the twelve-wave kernel (default), 1 = the dual-role kernel (conv_wino14d.hip) where it applies

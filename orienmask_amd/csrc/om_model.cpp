@@ -352,6 +352,17 @@ struct om_model {
                b.info.wsplit_off >= 0 && b.info.wino_planes != 24;
     }
 
+    // ... and the 64 -> 32 1x1 convolution behind them (backbone.conv2.1.conv.0) inside the same kernel (round 5)
+    bool stem3_fused() const {
+        static const bool off = [] { const char* e = std::getenv("OM_NO_STEM3"); return e && e[0] == '1'; }();      // A/B runs
+        if (off || !stem2_fused(0) || layers.size() < 3) return false;
+        const om::LayerDef& b = layers[1];
+        const om::LayerDef& c = layers[2];
+        return c.info.cin == 64 && c.info.cout == 32 && c.info.cout_pad == 32 && c.info.ksize == 1 && c.info.stride == 1 && !c.has_res &&
+               c.out_mode == 0 && c.in.buf == b.out.buf && c.in.ch_off == b.out.ch_off && c.info.wsplit_off >= 0 && c.out.buf >= 0 &&
+               c.gather.empty() && c.side < 0;
+    }
+
     // the fp16-activation forward: the same two layers as conv_stem2_f16_kernel (round 5), under the same conditions
     bool stem2_fused_f16(size_t index) const {
         static const bool off = [] { const char* e = std::getenv("OM_NO_STEM2_F16"); return e && e[0] == '1'; }();      // A/B runs
@@ -629,7 +640,7 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
         }
     };
 
-    bool fused_into_previous = false;
+    int fused_into_previous = 0;
     for (const om::LayerDef& L : m->layers) {
         const om_layer_info& li = L.info;
         const int layer_index = (int)(&L - m->layers.data());
@@ -656,8 +667,8 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
         const float* scale = m->weights + li.scale_off;
         const float* shift = m->weights + li.shift_off;
         const int Hin = H / L.in_div, Win = W / L.in_div;
-        if (fused_into_previous) {          // conv2.0 after the fused conv1 + conv2.0 kernel: nothing to launch (its events bracket nothing)
-            fused_into_previous = false;
+        if (fused_into_previous > 0) {      // conv2.0 (and conv2.1.conv.0) after the fused kernel: nothing to launch (its events bracket nothing)
+            --fused_into_previous;
             if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
             continue;
         }
@@ -665,16 +676,25 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
             // split-operand mode: conv1 and conv2.0 as one kernel (conv_stem2.hip) -- conv1's activation never reaches memory
             const om::LayerDef& N = m->layers[(&L - m->layers.data()) + 1];
             if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
+            om::Stem2Third third{};
+            const bool three = m->stem3_fused();
+            if (three) {
+                const om::LayerDef& T = m->layers[(&L - m->layers.data()) + 2];
+                third.w_split = m->weights_split + T.info.wsplit_off; third.scale_split = m->weights_split + T.info.wsplit_scale_off;
+                third.shift = m->weights + T.info.shift_off; third.out = static_cast<float*>(ptr_of(T.out));
+                third.cout = T.info.cout; third.leaky = T.info.leaky; third.out_pix_stride = m->pix_stride(T.out.buf);
+            }
             int rc = om::launch_conv_stem2_split(x, B, Hin, Win, w, scale, shift, m->weights_split + N.info.wsplit_off,
                                                  m->weights_split + N.info.wsplit_scale_off, m->weights + N.info.shift_off, N.info.cout,
-                                                 N.info.leaky, static_cast<float*>(ptr_of(N.out)), m->pix_stride(N.out.buf), status, stream);
+                                                 N.info.leaky, static_cast<float*>(ptr_of(N.out)), m->pix_stride(N.out.buf), status, stream,
+                                                 three ? &third : nullptr);
             if (rc != OM_OK) {
                 char msg[512];
                 std::snprintf(msg, sizeof(msg), "%s", om::g_err);
                 om::set_error("layers %s + %s: %s", li.name, N.info.name, msg);
                 return rc;
             }
-            fused_into_previous = true;
+            fused_into_previous = three ? 2 : 1;
             continue;
         }
         if (L.stem && f16 && m->stem2_fused_f16(&L - m->layers.data())) {
@@ -690,7 +710,7 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
                 om::set_error("layers %s + %s: %s", li.name, N.info.name, msg);
                 return rc;
             }
-            fused_into_previous = true;
+            fused_into_previous = 1;
             continue;
         }
         if (L.stem) {
@@ -938,6 +958,7 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
     if (L.stem && m->stem2_fused((size_t)index)) { *bm = 128; *bn = 64; *algo = 9; return OM_OK; }      // conv1 + conv2.0 in one kernel
     if (L.stem) { *bm = 0; *bn = 0; *algo = 0; return OM_OK; }
     if (index == 1 && m->stem2_fused(0)) { *bm = 0; *bn = 0; *algo = 10; return OM_OK; }                // ... which this layer is part of
+    if (index == 2 && m->stem3_fused()) { *bm = 0; *bn = 0; *algo = 10; return OM_OK; }
     if (L.info.wino_off >= 0 && om::wino_enabled() && L.info.wino_planes == 24 && m->precision == 1 && m->direct_3x3_layer(L, B, H, W)) {
         om::conv_tile_for_split(B * (H / L.in_div) * (W / L.in_div), L.info.cout_pad, bm, bn);
         *algo = 7;
@@ -1237,6 +1258,15 @@ int om_set_wino14_variant(int variant) {
     OM_REQUIRE(variant == 0 || variant == 1, OM_EINVAL, "om_set_wino14_variant: %d", variant);
     om::wino14_set_variant(variant);
     return OM_OK;
+}
+
+int om_conv2d_stem3_split(const float* in, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,
+                          const void* w2_split, const float* scale2_split, const float* shift2, int cout2, int leaky2, float* out,
+                          int out_pix_stride, const void* w3_split, const float* scale3_split, const float* shift3, int cout3, int leaky3,
+                          float* out3, int out3_pix_stride, int32_t* status_dev, om_stream stream) {
+    om::Stem2Third third{w3_split, scale3_split, shift3, out3, cout3, leaky3, out3_pix_stride};
+    return om::launch_conv_stem2_split(in, B, H, W, w1, scale1, shift1, w2_split, scale2_split, shift2, cout2, leaky2, out,
+                                       out_pix_stride, status_dev, static_cast<hipStream_t>(stream), &third);
 }
 
 int om_conv2d_stem2_f16(const float* in, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,

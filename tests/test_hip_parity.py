@@ -894,6 +894,55 @@ def test_stem2_split_matches_two_kernels(dev, shape):
     assert e1 < 2e-6 and e1 <= 2 * e2 + 5e-7 and e12 < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 40, 72), (1, 34, 50), (1, 96, 160)])
+def test_stem3_split_equals_stem2_then_1x1(dev, shape):
+    """conv_stem2_split_kernel with its optional third layer (round 5): backbone.conv2.1.conv.0 -- the 64 -> 32 1x1 convolution
+    behind conv2.0 -- computed on each tile's outputs inside the same launch.  conv2.0's tensor must be the two-layer kernel's bit for
+    bit, and the third layer's what om_conv2d_split computes from it, bit for bit (same split, same three products per 16 channels)."""
+    from orienmask_amd.pack import conv_weights_split
+    B, H, W = shape
+    L = omlib.load()
+    g = torch.Generator().manual_seed(sum(shape) + 9)
+    x = torch.rand(B, 3, H, W, generator=g) * 2 - 0.5
+    w1 = torch.randn(32, 3, 3, 3, generator=g) * 0.3
+    sc1, sh1 = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.2
+    w2 = torch.randn(64, 32, 3, 3, generator=g) / (32 * 9) ** 0.5
+    sc2, sh2 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    w3 = torch.randn(32, 64, 1, 1, generator=g) / 8.0
+    sc3, sh3 = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.2
+    w1p = w1.permute(0, 2, 3, 1).reshape(32, 27).contiguous().to(dev)
+    ws2, e2 = conv_weights_split(w2, 64)
+    ws3, e3 = conv_weights_split(w3, 32)
+    sp2 = (sc2.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e2.double())).float().to(dev)
+    sp3 = (sc3.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e3.double())).float().to(dev)
+    xd, sc1d, sh1d, ws2d, sh2d, ws3d, sh3d = x.to(dev), sc1.to(dev), sh1.to(dev), ws2.to(dev), sh2.to(dev), ws3.to(dev), sh3.to(dev)
+    st = omlib.current_stream_ptr(dev)
+    Ho, Wo = H // 2, W // 2
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    two = torch.full((B, Ho, Wo, 64), float("nan"), device=dev)
+    omlib.check(L.om_conv2d_stem2_split(_p(xd), B, H, W, _p(w1p), _p(sc1d), _p(sh1d), _p(ws2d), _p(sp2), _p(sh2d), 64, 1,
+                                        _p(two), 64, _p(status), st), "om_conv2d_stem2_split")
+    sep = torch.full((B, Ho, Wo, 32), float("nan"), device=dev)
+    omlib.check(L.om_conv2d_split(_p(two), B, Ho, Wo, 64, 64, _p(ws3d), _p(sp3), _p(sh3d), 32, 1, 1, 1, None, 0, _p(sep), 32, 0, 1, 0, 0,
+                                  _p(status), st), "om_conv2d_split")
+    out2 = torch.full((B, Ho, Wo, 64), float("nan"), device=dev)
+    buf3 = torch.full((B, Ho, Wo, 48), float("nan"), device=dev)          # the third layer's view: channels 8..39 of a wider buffer
+    omlib.check(L.om_conv2d_stem3_split(_p(xd), B, H, W, _p(w1p), _p(sc1d), _p(sh1d), _p(ws2d), _p(sp2), _p(sh2d), 64, 1, _p(out2), 64,
+                                        _p(ws3d), _p(sp3), _p(sh3d), 32, 1, ctypes.c_void_p(buf3[..., 8:].data_ptr()), 48, _p(status), st),
+                "om_conv2d_stem3_split")
+    assert int(status.item()) == 0
+    assert torch.equal(out2, two)
+    assert torch.isnan(buf3[..., :8]).all() and torch.isnan(buf3[..., 40:]).all()
+    assert torch.equal(buf3[..., 8:40], sep)
+    a = torch.nn.functional.conv2d(x.double(), w1.double(), None, 1, 1) * sc1.double().view(1, -1, 1, 1) + sh1.double().view(1, -1, 1, 1)
+    a = torch.where(a > 0, a, a * 0.1)
+    b2 = torch.nn.functional.conv2d(a, w2.double(), None, 2, 1) * sc2.double().view(1, -1, 1, 1) + sh2.double().view(1, -1, 1, 1)
+    b2 = torch.where(b2 > 0, b2, b2 * 0.1)
+    want = torch.nn.functional.conv2d(b2, w3.double()) * sc3.double().view(1, -1, 1, 1) + sh3.double().view(1, -1, 1, 1)
+    want = torch.where(want > 0, want, want * 0.1)
+    assert _rel_err(buf3[..., 8:40].cpu().permute(0, 3, 1, 2).double(), want) < 4e-6
+
+
 # ------------------------------------------------------------------------------------------------
 # forward
 # ------------------------------------------------------------------------------------------------
