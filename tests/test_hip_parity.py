@@ -1689,16 +1689,13 @@ F16_CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 2])
-@pytest.mark.parametrize("case", F16_CONV_CASES)
+@pytest.mark.parametrize("case,variant", [(c, v) for c in F16_CONV_CASES for v in ((0, 2) if c[5] == 3 and c[6] == 1 else (0,))])
 def test_conv_f16_layer_matches_torch(dev, case, variant):
     """variant: om_set_conv3x3_f16_variant -- 0 the shared-patch 3x3 kernel of rounds 1-4, 2 the tall-patch kernel wherever it
     can run (the default, 1, is one of the two per layer)."""
     from orienmask_amd.pack import conv_weights_f16
     B, H, W, cin, cout, k, stride, leaky, use_res, out_f32 = case
     L = omlib.load()
-    if variant and not (k == 3 and stride == 1):
-        pytest.skip("one kernel for this layer")
     omlib.check(L.om_set_conv3x3_f16_variant(variant), "om_set_conv3x3_f16_variant")
     g = torch.Generator().manual_seed(sum(case) + 11)
     x = torch.randn(B, cin, H, W, generator=g).half()
