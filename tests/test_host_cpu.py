@@ -519,3 +519,20 @@ def test_no_packed_fp32_register_half_select(tmp_path):
     with ThreadPoolExecutor(max_workers=6) as ex:
         results = list(ex.map(scan, files))
     assert all(not bad for _, bad in results), {n: b[:3] for n, b in results if b}
+
+
+def test_bench_clock_sampler_reads_the_drivers_table(tmp_path):
+    """bench.ClockSampler: the level marked `*` of a pp_dpm_sclk table is the current shader clock; without a table (no GPU, no sysfs
+    access) it samples nothing and reports None -- the bench line then simply has no `sclk_mhz`."""
+    import bench
+    s = bench.ClockSampler.__new__(bench.ClockSampler)
+    import threading
+    s._threading, s.samples, s._stop, s._thread = threading, [], None, None
+    table = tmp_path / "pp_dpm_sclk"
+    table.write_text("0: 500Mhz\n1: 1987Mhz *\n2: 2400Mhz\n")
+    s.path = str(table)
+    assert s._read() == 1987.0
+    out = s.start().stop()
+    assert out is not None and out["mean"] == 1987.0 and out["samples"] >= 1
+    s.path = None
+    assert s.start().stop() is None
