@@ -641,6 +641,19 @@ def main():
                                "convolution weights, fp32 accumulate, fp32 heads and postprocess; `bench.py --dtype f16` prints its own "
                                "roofline).  Narrower arithmetic than the headline and unpinned against the reference (DESIGN.md 3.3): "
                                "never `value`")
+        # ... and at the batch size BASELINE configs[4] names (64 images per GPU): a few steps with three batches in flight
+        if B == 32 and args.batch == 32:
+            try:
+                xs64 = [torch.cat([xs[0], xs[1]]), torch.cat([xs[1], xs[0]])]
+                n64 = max(6, args.steps // 3)
+                for _ in pipe16.map(itertools.islice(itertools.cycle(xs64), 6)):
+                    pass
+                e64 = timed16(lambda: [None for _ in pipe16.map(itertools.islice(itertools.cycle(xs64), n64))])
+                f16_config["bs64"] = dict(value=round(world * 64 * n64 / e64, 2), ms_per_step=round(e64 / n64 * 1e3, 3), steps=n64,
+                                          batches_in_flight=3, note="64 images per GPU per step, the configuration's own batch size")
+                del xs64
+            except RuntimeError as err:      # (out of memory on a small device: the figure is an extra)
+                f16_config["bs64"] = dict(error=str(err)[:200])
         del pipe16
         net.set_precision(args.dtype)
     # ---- small batches (the reference's own published metric is bs = 1 FPS: README.md:5, infer.py:143-172): one image / eight
