@@ -10,13 +10,15 @@ synthetic 544x544 images already resident in HBM (BASELINE.json configs[2]).  Ea
 batch (weak scaling, no collective in the timed region); rank 0's packed weights are broadcast once
 over RCCL before timing.  Rank 0 prints ONE JSON line.
 
-roofline:     the dominant kernel (the Winograd convolution on the f32 matrix cores).  achieved = the FLOPs the matrix
-              pipe EXECUTED for the layers it runs (Winograd F(2x4,3x3): 1/3 of the direct-convolution count, F(2x2,3x3):
-              1/2.25) / their summed duration INCLUDING the layer's input-transform pre-pass where there is one, measured
-              live with HIP events on the launch stream over the timed steps (om_profile_*); peak = 157.3 TFLOP/s
-              (f32-input MFMA, MI355X_MICROARCH.md); frac = achieved / peak, always <= 1.  The direct-convolution
-              ("algorithmic") rate of the same layers is reported next to it as achieved_algorithmic.  The forward is
-              FLOP-bound in fp32; the HBM figures (forward_hbm_*, conv_stack_hbm_pmc) are beside it.
+roofline:     the dominant kernel (default precision: the fused F(4,3) 3x3 convolution on the fp16 matrix cores with split
+              fp32 operands).  achieved = ALGORITHMIC flops -- the direct convolution's 2 * B * Ho * Wo * cout * cin * k^2 of the
+              layers the kernel runs (SURVEY.md 8d's per-image count x the images of a launch) -- / their summed duration
+              INCLUDING a layer's input-transform pre-pass where there is one, measured live with HIP events on the launch
+              stream over the timed steps (om_profile_*); peak = the dense peak of the matrix instruction the kernel uses
+              (2.5 PFLOP/s fp16, 157.3 TFLOP/s f32-input: MI355X_MICROARCH.md); frac = achieved / peak.  What the matrix pipe
+              EXECUTES for those flops (x3 for split operands, x1/2 for F(4,3) along the rows, x1/3 for F(2x4)) is reported
+              next to it as achieved_executed / executed_frac.  The HBM view of the same launches is `roofline.hbm`, the
+              forward's `forward_hbm_*` / `conv_stack_hbm_pmc`.
               traffic = HBM bytes per launch from the committed rocprofv3 PMC passes of this same bench -- printed only
               when that file was measured with the library binary that is running now (sha256), else null.
 cpu_baseline: the CPU oracle (torch-CPU restatement of the reference, oracle/) on the host cores: thread-count sweep,
@@ -42,7 +44,7 @@ ANCHOR_MASK = [[6, 7, 8], [3, 4, 5], [0, 1, 2]]
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-PROFILE_TAG = "r05"                # profiles/<tag>_pmc_traffic*.json: the PMC passes whose `traffic` this build may quote
+PROFILE_TAG = "r06"                # profiles/<tag>_pmc_traffic*.json: the PMC passes whose `traffic` this build may quote
 WEIGHT_SEED, OBJ_BIAS, HEAD_GAIN = 3, -16.0, 4.0
 OBJ_BIAS_SPARSE = -18.5     # a few tens of detections per image (-18: 67, -19: 11, -20: 3, <= -24: none)
 
@@ -634,7 +636,6 @@ def main():
                                      "library binary, else null" % PROFILE_TAG)
         if sclk16_serial:
             f16_roofline["sclk_mhz"] = dict(one_batch_in_flight=sclk16_serial, batches_in_flight=sclk16_flight, nominal=2400)
-            f16_roofline["frac_at_measured_clock"] = round(f16_roofline["frac"] * 2400.0 / sclk16_serial["mean"], 4)
         f16_config = dict(value=round(world * B * args.steps / e3, 2), ms_per_step=round(e3 / args.steps * 1e3, 3),
                           batches_in_flight=3, one_batch_in_flight=round(world * B * args.steps / e1, 2), roofline=f16_roofline,
                           note="BASELINE configs[4] at this batch size: the same K steps with precision 'f16' (fp16 activations and "
@@ -814,10 +815,14 @@ def main():
         peak_tf = PEAK_F16_MFMA_TFLOPS if (f16 or split) else PEAK_F32_MFMA_TFLOPS
         alg_bytes_per_launch = d["bytes"] / d["launches"]      # layer-fused model: input once, output once, residual once, weights
         # key order: the driver's record keeps the first keys of this object -- the figures a reader compares come first, prose last
-        roofline = dict(bound="mfma", achieved=round(executed, 2), peak=peak_tf, unit="TFLOP/s",
-                        frac=round(executed / peak_tf, 4), traffic=traffic,
-                        frac_counts="EXECUTED flops (split operands x3, F(4,3) x1/2) / peak; algorithmic_frac counts direct-convolution flops",
-                        achieved_algorithmic=round(achieved_alg, 2), algorithmic_frac=round(achieved_alg / peak_tf, 4),
+        # `achieved` / `frac` count ALGORITHMIC flops (the direct convolution's 2 * B * Ho * Wo * cout * cin * 9 per launch:
+        # SURVEY.md 8d's per-image figure x the images of a launch) -- what the matrix pipe EXECUTES for them (x3 for split
+        # operands, x1/2 for F(4,3) along the rows) is `achieved_executed` / `executed_frac` (task 2)
+        roofline = dict(bound="mfma", achieved=round(achieved_alg, 2), peak=peak_tf, unit="TFLOP/s",
+                        frac=round(achieved_alg / peak_tf, 4), traffic=traffic,
+                        frac_counts="ALGORITHMIC (direct-convolution) flops / time / peak; executed_frac counts what the matrix pipe "
+                                    "executes for them (split operands x3, F(4,3) x1/2)",
+                        achieved_executed=round(executed, 2), executed_frac=round(executed / peak_tf, 4),
                         kernel=dom, launches_per_step=d["launches"], avg_launch_ms=round(dom_main_ms / d["launches"], 4),
                         kernel_ms_per_step=round(dom_timed_ms, 3),
                         algorithmic_bytes_per_launch=round(alg_bytes_per_launch),
@@ -832,7 +837,7 @@ def main():
                         achieved_without_pre_pass=round(executed_main_only, 2),
                         note=("fp16 operands, fp32 accumulate on v_mfma_f32_32x32x16_f16 (dense peak 2.5 PFLOP/s); direct "
                               "convolution, executed = algorithmic") if f16 else
-                             ("achieved = flops the fp16 matrix pipe executed (split operands: three v_mfma_f32_32x32x16_f16 per "
+                             ("achieved_executed = flops the fp16 matrix pipe executed (split operands: three v_mfma_f32_32x32x16_f16 per "
                               "product group; the fused kernel's F(4,3) along the rows multiplies 4.5 of the direct convolution's 9 "
                               "products per output, so executed = 3 x 1/2 of the direct-convolution flops; the input transform is "
                               "inside the kernel, there is no pre-pass) over the kernel's time, against the dense fp16 peak.  The "
@@ -840,12 +845,12 @@ def main():
                               "bytes / 8 TB/s) are both ~1/6 of the measured time: what binds is the CU's vector-memory request path "
                               "(DESIGN.md 3.6, profiles/r03_pmc_wino14_*.txt); `hbm` holds the memory-side view of the same launches")
                              if split and dom.startswith("wino14") else
-                             ("achieved = flops the fp16 matrix pipe executed (split operands: three v_mfma_f32_32x32x16_f16 per "
+                             ("achieved_executed = flops the fp16 matrix pipe executed (split operands: three v_mfma_f32_32x32x16_f16 per "
                               "product group, i.e. 3 x 1/3 of the direct-convolution flops for Winograd F(2x4,3x3)) over the time of "
                               "the GEMM kernel AND its input-transform pre-pass, against the dense fp16 peak") if split else
-                             ("achieved = flops the f32 matrix pipe executed (exact fp32 MFMA; Winograd F(2x4,3x3) runs 1/3 of the "
+                             ("achieved_executed = flops the f32 matrix pipe executed (exact fp32 MFMA; Winograd F(2x4,3x3) runs 1/3 of the "
                               "direct-convolution multiplies) over the time of the GEMM kernel AND its input-transform pre-pass; "
-                              "achieved_algorithmic counts direct-convolution flops over the same time"),
+                              "achieved counts direct-convolution flops over the same time"),
                         forward_kernels_ms_per_step=round(fwd_ms, 3), postprocess_ms_per_step=round(post_ms, 3),
                         forward_tflops_algorithmic=round(total_flops / (fwd_ms * 1e-3) / 1e12, 2),
                         forward_tflops_executed=round(total_exec / (fwd_ms * 1e-3) / 1e12, 2),
@@ -868,12 +873,12 @@ def main():
             roofline["sclk_mhz"] = dict(one_batch_in_flight=sclk_serial, batches_in_flight=sclk_flight, idle_before=sclk_idle, nominal=2400,
                                         source="sysfs pp_dpm_sclk of this GPU, sampled every 4 ms during the timed regions")
             roofline["peak_at_measured_clock"] = round(peak_tf * clk / 2400.0, 1)
-            roofline["frac_at_measured_clock"] = round(executed / (peak_tf * clk / 2400.0), 4)
-        front = ["bound", "achieved", "peak", "unit", "frac", "traffic", "frac_counts", "achieved_algorithmic", "algorithmic_frac", "kernel",
+            roofline["executed_frac_at_measured_clock"] = round(executed / (peak_tf * clk / 2400.0), 4)
+        front = ["bound", "achieved", "peak", "unit", "frac", "traffic", "frac_counts", "achieved_executed", "executed_frac", "kernel",
                  "launches_per_step", "avg_launch_ms", "kernel_ms_per_step", "algorithmic_bytes_per_launch", "traffic_over_algorithmic",
                  "one_batch_in_flight_images_per_s", "one_batch_in_flight_ms_per_step", "forward_kernels_ms_per_step",
                  "postprocess_ms_per_step", "forward_tflops_algorithmic", "forward_tflops_executed", "forward_executed_frac",
-                 "forward_hbm_algorithmic_gbs", "forward_hbm_frac", "peak_at_measured_clock", "frac_at_measured_clock", "sclk_mhz"]
+                 "forward_hbm_algorithmic_gbs", "forward_hbm_frac", "sclk_mhz"]
         front = [k for k in front if k in roofline]
         roofline = {**{k: roofline[k] for k in front}, **{k: v for k, v in roofline.items() if k not in front}}
         if split:

@@ -314,14 +314,25 @@ int om_conv2d_wino14_split(const float* in, int B, int H, int W, int cin, int in
 /* Which kernel runs that layer (process-wide; the outputs are bit-identical): 0 (default; environment OM_W14_VARIANT) the
  * twelve-wave kernel (conv_wino14.hip) everywhere; 1 the four-dual-role-wave kernel of round 5 (conv_wino14d.hip: one wave per
  * SIMD, accumulators owned by name) wherever it applies -- an even number >= 2 of 16-channel chunks, 16-byte aligned views.
- * The second form is kept as a measured alternative (8-25 % slower: profiles/r05_experiments.md), not as the product's path. */
+ * The second form is kept as a measured alternative (8-25 % slower: profiles/r05_experiments.md), not as the product's path:
+ * only a library built with `make -C orienmask_amd/csrc W14D=1` contains it (om_wino14_dual_built() == 1); in the default
+ * library om_set_wino14_variant(1) returns OM_EINVAL. */
 int om_set_wino14_variant(int variant);
+int om_get_wino14_variant(void);
+int om_wino14_dual_built(void);
+/* A/B switches of the two first-layers fusions (process-wide; default on; OM_NO_STEM3=1 / OM_NO_STEM2_F16=1 in the environment
+ * turn them off before the first use): which = 0 the third layer (backbone.conv2.1.conv.0) inside the split-operand
+ * first-two-layers kernel, which = 1 the fp16 first-two-layers kernel.  Off -> the separate kernels, bit-identical results.  A
+ * view the fused launcher cannot take (alignment, pixel stride, descriptor size) runs the separate kernels by itself. */
+int om_set_stem_fusion(int which, int on);
+int om_get_stem_fusion(int which);      /* 1 on, 0 off, -1 bad argument */
 /* Which kernel runs the stride-1 3x3 layers of the fp16 configuration (process-wide; the results are the same sums in the same
  * order, bit-identical): 0 the 256 x 128 / 128 x 128 / 128 x 64 shared-patch kernel everywhere (rounds 1-4); 1 (default;
  * environment OM_C3_TALL) the tall-patch kernel of round 5 (conv3x3_f16.hip: 512 raster pixels x 128 channels per eight-wave
  * workgroup, one input patch per 32-channel chunk for all nine taps) where the tile chooser picks it; 2 wherever it can run
  * (cout_pad a multiple of 128, rows of at most 191 pixels). */
 int om_set_conv3x3_f16_variant(int mode);
+int om_get_conv3x3_f16_variant(void);
 /* first layer: in [B,3,H,W] NCHW -> out [B,H,W,cout] NHWC, 3x3 stride 1. */
 int om_conv2d_stem(const float* in, int B, int H, int W, const float* w, const float* scale,
                    const float* shift, int cout, float* out, om_stream stream);

@@ -441,6 +441,7 @@ static int c3_tall_mode() {
     return g_c3_tall;
 }
 void conv3x3_f16_set_tall(int mode) { g_c3_tall = mode; }
+int conv3x3_f16_get_tall() { return c3_tall_mode(); }
 
 void conv3x3_tile_for_f16(int M, int cout_pad, int W, int kc, int* bm, int* bn) {
     if (cout_pad % 128) { *bm = 128; *bn = 64; return; }

@@ -172,6 +172,8 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
                 for (int x = 0; x < 6; ++x) ok |= (rowok && (unsigned)(x0 + x) < (unsigned)p.W ? 1u : 0u) << x;
                 xok[k] = ok;
                 xbase[k] = (((b * p.H + y) * p.W + x0) * p.in_ps + ch) * 4;
+                // measurement (262144): the addresses a channel-chunk-major activation [B][cin / 16][H][W][16] would be read at
+                if (OM_W14_ABLATE & 262144) xbase[k] = (((b * p.nch * p.H + y) * p.W + x0) * 16 + ch) * 4;
                 const int sw = (e >> 2) & 3;
                 xlds[k] = e < ecount ? e * 64 + (((q >> 1) ^ sw) * 16) + (ch & 7) * 2 : -1;
             }
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
         auto item_offset = [&](int k, int x, int c) {
             // a pixel outside the image (or a pad row) gets an offset beyond the descriptor's range: the load returns zeros
             int off = ((xok[k] >> x) & 1u) ? xbase[k] + x * p.in_ps * 4 + c * 64 : (int)0x80000000;
+            if (OM_W14_ABLATE & 262144) off = ((xok[k] >> x) & 1u) ? xbase[k] + x * 64 + c * (p.H * p.W * 64) : (int)0x80000000;
             if (OM_W14_ABLATE & 512) off = lane * 16 + (k * 6 + x) * 1024;      // measurement: every request hits the same 18 KiB
             if ((OM_W14_ABLATE & 16384) && (c & 1)) off = (int)0x80000000;     // measurement: half the input requests (odd chunks none)
             if ((OM_W14_ABLATE & 32768) && (x == 0 || x == 5)) off = (int)0x80000000;   // measurement: no halo pixels (4 of 6 requests)
@@ -654,8 +657,11 @@ int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream) {
     OM_REQUIRE(p.trace, OM_EINVAL, "wino14 trace build: om_debug_w14_trace() first");
 #endif
     // round 5: the four-dual-role-wave form (conv_wino14d.hip) on request only (om_set_wino14_variant(1) / OM_W14_VARIANT=1): bit-identical,
-    // but measured 8-25 % slower than this file's twelve-wave kernel on every layer shape (profiles/r05_experiments.md 1)
+    // but measured 8-25 % slower than this file's twelve-wave kernel on every layer shape (profiles/r05_experiments.md 1).  Since round 6
+    // it is only in libraries built with `make W14D=1` (the default library holds no kernel the forward cannot reach).
+#ifdef OM_WITH_W14D
     if (wino14_variant() == 1 && wino14_dual_supported(p)) return launch_wino14_dual(p, a.res != nullptr, stream);
+#endif
     const long long grid = total < 256 ? total : 256;        // one 768-thread workgroup per CU (156 KiB of LDS)
     if (!p.fast_io) hipLaunchKernelGGL(wino14_split_kernel<2>, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);
     else if (a.res) hipLaunchKernelGGL(wino14_split_kernel<1>, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);

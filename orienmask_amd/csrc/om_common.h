@@ -104,6 +104,7 @@ int launch_conv_igemm_f16(const ConvArgsH& a, hipStream_t stream);     // dispat
 int launch_conv3x3_f16(const ConvArgsH& a, hipStream_t stream);
 bool conv3x3_f16_supported(const ConvArgsH& a);
 void conv3x3_tile_for_f16(int M, int cout_pad, int W, int kc, int* bm, int* bn);
+int conv3x3_f16_get_tall();
 void conv3x3_f16_set_tall(int mode);      // conv3x3_f16.hip: 0 never / 1 where the tile chooser picks it (default) / 2 wherever it can run
 void conv_tile_for_f16(int M, int cout_pad, int cin, int* bm, int* bn);
 inline size_t conv_f16_weight_halfs(int cout_pad, int ks, int cin) {
@@ -138,6 +139,7 @@ int launch_conv_stem2_split(const float* in_nchw, int B, int H, int W, const flo
                             float* out_nhwc, int out_pix_stride, int* status, hipStream_t stream, const Stem2Third* third = nullptr);
 size_t wino14_weight_halfs(int cout_pad, int cin);
 void wino14_geometry(int B, int H, int W, int* R, int* Ct, int* ncb, int* nrb);
+int wino14_variant();
 void wino14_set_variant(int v);      // conv_wino14.hip: 0 = the twelve-wave kernel (default), 1 = the dual-role kernel (conv_wino14d.hip) where it applies
 bool wino_enabled();
 int wino_bn(long long T, int cout_pad);   // N tile of the (unfused) Winograd GEMM at this size

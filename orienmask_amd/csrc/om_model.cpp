@@ -340,6 +340,21 @@ struct om_model {
         return precision == 1 || (long long)B * (H / 32) * (W / 32) >= 1700ll;
     }
 
+    // A/B switches of the two fusions below (process-wide; om_set_stem_fusion, or OM_NO_STEM3=1 / OM_NO_STEM2_F16=1 in the
+    // environment read once): 0 = the third layer inside the split-operand stem kernel, 1 = the fp16 first-two-layers kernel
+    static int& stem_fusion_flag(int which) {
+        static int flags[2] = {-1, -1};
+        return flags[which];
+    }
+    static bool stem_fusion_on(int which) {
+        int& f = stem_fusion_flag(which);
+        if (f < 0) {
+            const char* e = std::getenv(which == 0 ? "OM_NO_STEM3" : "OM_NO_STEM2_F16");
+            f = (e && e[0] == '1') ? 0 : 1;
+        }
+        return f != 0;
+    }
+
     // split-operand mode: conv1 (the stem) and conv2.0 run as ONE kernel (conv_stem2.hip) when the second is the 32 -> 64 3x3
     // stride-2 layer reading the first one's output -- unless every activation is kept for om_layer_output_view
     // (never in the fp16-activation forward, whatever the precision mode says: its buffers hold 2-byte elements)
@@ -354,8 +369,7 @@ struct om_model {
 
     // ... and the 64 -> 32 1x1 convolution behind them (backbone.conv2.1.conv.0) inside the same kernel (round 5)
     bool stem3_fused() const {
-        static const bool off = [] { const char* e = std::getenv("OM_NO_STEM3"); return e && e[0] == '1'; }();      // A/B runs
-        if (off || !stem2_fused(0) || layers.size() < 3) return false;
+        if (!stem_fusion_on(0) || !stem2_fused(0) || layers.size() < 3) return false;
         const om::LayerDef& b = layers[1];
         const om::LayerDef& c = layers[2];
         return c.info.cin == 64 && c.info.cout == 32 && c.info.cout_pad == 32 && c.info.ksize == 1 && c.info.stride == 1 && !c.has_res &&
@@ -365,8 +379,7 @@ struct om_model {
 
     // the fp16-activation forward: the same two layers as conv_stem2_f16_kernel (round 5), under the same conditions
     bool stem2_fused_f16(size_t index) const {
-        static const bool off = [] { const char* e = std::getenv("OM_NO_STEM2_F16"); return e && e[0] == '1'; }();      // A/B runs
-        if (off || keep_all || index != 0 || layers.size() < 2 || !layers[0].stem) return false;
+        if (!stem_fusion_on(1) || keep_all || index != 0 || layers.size() < 2 || !layers[0].stem) return false;
         const om::LayerDef& a = layers[0];
         const om::LayerDef& b = layers[1];
         return a.info.cout == 32 && b.info.cin == 32 && b.info.cout == 64 && b.info.cout_pad == 64 && b.info.ksize == 3 &&
@@ -684,34 +697,47 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
                 third.shift = m->weights + T.info.shift_off; third.out = static_cast<float*>(ptr_of(T.out));
                 third.cout = T.info.cout; third.leaky = T.info.leaky; third.out_pix_stride = m->pix_stride(T.out.buf);
             }
+            bool three_done = three;
             int rc = om::launch_conv_stem2_split(x, B, Hin, Win, w, scale, shift, m->weights_split + N.info.wsplit_off,
                                                  m->weights_split + N.info.wsplit_scale_off, m->weights + N.info.shift_off, N.info.cout,
                                                  N.info.leaky, static_cast<float*>(ptr_of(N.out)), m->pix_stride(N.out.buf), status, stream,
                                                  three ? &third : nullptr);
-            if (rc != OM_OK) {
+            // the predicates above look at layer shapes; the launcher also has preconditions on the views (alignment, pixel
+            // stride, descriptor size).  A view it refuses takes the path that was the only one before the fusion existed: first
+            // without the third layer, then the separate kernels below.
+            if (rc == OM_EINVAL && three) {
+                three_done = false;
+                rc = om::launch_conv_stem2_split(x, B, Hin, Win, w, scale, shift, m->weights_split + N.info.wsplit_off,
+                                                 m->weights_split + N.info.wsplit_scale_off, m->weights + N.info.shift_off, N.info.cout,
+                                                 N.info.leaky, static_cast<float*>(ptr_of(N.out)), m->pix_stride(N.out.buf), status, stream, nullptr);
+            }
+            if (rc == OM_OK) {
+                fused_into_previous = three_done ? 2 : 1;
+                continue;
+            }
+            if (rc != OM_EINVAL) {
                 char msg[512];
                 std::snprintf(msg, sizeof(msg), "%s", om::g_err);
                 om::set_error("layers %s + %s: %s", li.name, N.info.name, msg);
                 return rc;
             }
-            fused_into_previous = three ? 2 : 1;
-            continue;
-        }
-        if (L.stem && f16 && m->stem2_fused_f16(&L - m->layers.data())) {
+        } else if (L.stem && f16 && m->stem2_fused_f16(&L - m->layers.data())) {
             // fp16 activations: conv1 and conv2.0 as one kernel too (conv_stem2_f16_kernel)
             const om::LayerDef& N = m->layers[(&L - m->layers.data()) + 1];
             if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
             int rc = om::launch_conv_stem2_f16(x, B, Hin, Win, w, scale, shift, m->weights16 + N.info.w16_off,
                                                m->weights + N.info.scale_off, m->weights + N.info.shift_off, N.info.cout, N.info.leaky,
                                                ptr_of(N.out), m->pix_stride(N.out.buf), stream);
-            if (rc != OM_OK) {
+            if (rc == OM_OK) {
+                fused_into_previous = 1;
+                continue;
+            }
+            if (rc != OM_EINVAL) {      // OM_EINVAL: a view the fused launcher refuses -> the separate kernels below
                 char msg[512];
                 std::snprintf(msg, sizeof(msg), "%s", om::g_err);
                 om::set_error("layers %s + %s: %s", li.name, N.info.name, msg);
                 return rc;
             }
-            fused_into_previous = 1;
-            continue;
         }
         if (L.stem) {
             if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
@@ -1254,8 +1280,18 @@ int om_conv2d_wino14_split(const float* in, int B, int H, int W, int cin, int in
     return om::launch_conv_wino14_split(a, static_cast<hipStream_t>(stream));
 }
 
+int om_wino14_dual_built(void) {
+#ifdef OM_WITH_W14D
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int om_set_wino14_variant(int variant) {
     OM_REQUIRE(variant == 0 || variant == 1, OM_EINVAL, "om_set_wino14_variant: %d", variant);
+    OM_REQUIRE(variant == 0 || om_wino14_dual_built(), OM_EINVAL,
+               "om_set_wino14_variant: this library was built without the dual-role kernel (make W14D=1)");
     om::wino14_set_variant(variant);
     return OM_OK;
 }
@@ -1275,6 +1311,21 @@ int om_conv2d_stem2_f16(const float* in, int B, int H, int W, const float* w1, c
     return om::launch_conv_stem2_f16(in, B, H, W, w1, scale1, shift1, w2_f16, scale2, shift2, cout2, leaky2, out, out_pix_stride,
                                      static_cast<hipStream_t>(stream));
 }
+
+int om_get_wino14_variant(void) { return om::wino14_variant(); }
+
+int om_set_stem_fusion(int which, int on) {
+    OM_REQUIRE((which == 0 || which == 1) && (on == 0 || on == 1), OM_EINVAL, "om_set_stem_fusion: which=%d on=%d", which, on);
+    om_model::stem_fusion_flag(which) = on;
+    return OM_OK;
+}
+
+int om_get_stem_fusion(int which) {
+    if (which != 0 && which != 1) return -1;
+    return om_model::stem_fusion_on(which) ? 1 : 0;
+}
+
+int om_get_conv3x3_f16_variant(void) { return om::conv3x3_f16_get_tall(); }
 
 int om_set_conv3x3_f16_variant(int mode) {
     OM_REQUIRE(mode >= 0 && mode <= 2, OM_EINVAL, "om_set_conv3x3_f16_variant: %d", mode);

@@ -75,6 +75,11 @@ SIGNATURES = {
     "om_conv2d_split_k": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "om_conv2d_winograd24_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp, _vp]),
     "om_set_wino14_variant": (_i, [_i]),
+    "om_wino14_dual_built": (_i, []),
+    "om_get_wino14_variant": (_i, []),
+    "om_set_stem_fusion": (_i, [_i, _i]),
+    "om_get_stem_fusion": (_i, [_i]),
+    "om_get_conv3x3_f16_variant": (_i, []),
     "om_set_conv3x3_f16_variant": (_i, [_i]),
     "om_conv2d_wino14_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "om_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i]),

@@ -22,9 +22,12 @@ class SyntheticLoader:
         rank, world = world_info()
         start, stop = shard_range(n_images, rank, world)            # each rank evaluates its own slice
         self._batches = []
+        import torch
         for i, s in enumerate(range(start, stop, batch_size)):
             n = min(batch_size, stop - s)
-            img = synth.synth_image_batch(seed + s, n, size[0], size[1])
+            # one seed per IMAGE id: the images do not depend on the world size or on where a rank's batches begin, so the
+            # shards of a sharded run are exactly the unsharded set (tests/test_dist_cpu.py compares every image)
+            img = torch.cat([synth.synth_image_batch(seed + s + k, 1, size[0], size[1]) for k in range(n)], 0)
             info = [dict(id=s + k, height=size[0], width=size[1]) for k in range(n)]
             self._batches.append((img, None, info))
         self.device = device

@@ -55,15 +55,27 @@ def _lru(cache, key, make, size):
 
 
 def _fingerprint(sd):
+    """Content hash of a state dict: sha1 over every tensor's name, shape, dtype and BYTES (a perturbed weight with the same sum
+    and the same first elements is another key -- the parity tests must validate the packer, not this cache)."""
+    import hashlib
     import torch
-    parts = []
+    h = hashlib.sha1()
     for k, v in sd.items():
+        h.update(repr(k).encode())
         if torch.is_tensor(v):
-            f = v.detach().reshape(-1)
-            parts.append((k, tuple(v.shape), str(v.dtype), f[:4].double().tolist(), float(f.double().sum()) if f.numel() else 0.0))
+            t = v.detach().cpu().contiguous()
+            h.update(repr((tuple(t.shape), str(t.dtype))).encode())
+            h.update(t.reshape(-1).view(torch.uint8).numpy().tobytes() if t.numel() else b"")
         else:
-            parts.append((k, repr(v)))
-    return hash(repr(parts))
+            h.update(repr(v).encode())
+    return h.hexdigest()
+
+
+def _layers_key(layers):
+    """Everything of the layer table a packer looks at (names, shapes, offsets): two tables of the same length and total size
+    that differ in any of it are different keys."""
+    import hashlib
+    return hashlib.sha1(repr([sorted((k, repr(v)) for k, v in l.items()) if isinstance(l, dict) else repr(l) for l in layers]).encode()).hexdigest()
 
 
 def _install_memo():
@@ -83,7 +95,7 @@ def _install_memo():
 
         def packed(state_dict, layers, total, _raw=raw, _name=name):
             sd = pack.unwrap_checkpoint(state_dict)
-            key = (_name, _fingerprint(sd), str(pack._blob_device(sd, layers)), int(total), len(layers))
+            key = (_name, _fingerprint(sd), str(pack._blob_device(sd, layers)), int(total), _layers_key(layers))
             return _lru(blob_cache, key, lambda: _raw(state_dict, layers, total), 6).clone()
 
         packed.__wrapped__ = raw

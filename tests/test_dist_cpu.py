@@ -116,13 +116,12 @@ def test_two_rank_sharded_tester_merges_in_dataset_order(built):
         assert p.exitcode == 0
     assert [r[1] for r in results] == [6, 5]
     assert results[0][2] == results[1][2] and [m["id"] for m in results[0][2]] == list(range(11))
-    # the single-process loader sees the same images: the merged fingerprints are the unsharded ones
-    want = []
-    for s0 in range(0, 11, 4):
-        img = synth.synth_image_batch(3 + s0, min(4, 11 - s0), 32, 32)
-        want += [float(img[b].sum()) for b in range(img.shape[0])]
-    # (a rank's batches start at its slice's first image: same seeds only where the batch boundaries coincide)
-    assert abs(results[0][2][0]["v"] - want[0]) < 1e-3 * abs(want[0])
+    # the single-process loader sees the same images (SyntheticLoader seeds every image by its id): ALL merged fingerprints are
+    # the unsharded ones, whatever the ranks' batch boundaries
+    want = [float(synth.synth_image_batch(3 + i, 1, 32, 32)[0].sum()) for i in range(11)]
+    got = [m["v"] for m in results[0][2]]
+    assert len(got) == 11 and all(abs(g - w) <= 1e-6 * abs(w) for g, w in zip(got, want)), (got, want)
+    assert len(set(round(w, 3) for w in want)) == 11        # and the fingerprints do tell the images apart
 
 
 # ---- `python bench.py --gpus N` means N: launcher resolution, and the self-spawned job on gloo

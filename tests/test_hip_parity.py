@@ -92,18 +92,23 @@ def _borderline_flips(got_mask, want_mask, ctx, j, tol_rel=1e-4):
     return int(diff[0].size), float(d.max() / scale)
 
 
+FALLBACK_MARGIN, FALLBACK_PIXELS = 1e-6, 4
+_FALLBACK_TALLY = {}
+
+
 def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol=5e-5, nms_post=100, margin_ctx=None):
     """HIP forward + HIP postprocess against the reference's forward + postprocess.  The two forwards differ by ~1e-6 of the
     head tensors' scale (another summation order), i.e. scores differ by up to a few 1e-5 relative, so the comparison is
     exact EXCEPT where the reference's own answer hinges on a gap smaller than that:
       * detections are matched one to one irrespective of position: same class, box within 1e-4, and mask IoU >= 1 - 1e-4
-        (north_star) -- or, since ONE boundary pixel is already more than 1e-4 of a mask smaller than 10^4 pixels, every
-        differing pixel must be BORDERLINE: its decision margin (_borderline_flips, evaluated in the oracle's arithmetic on the
-        heads under test) at most 1e-5 of the orientation field's scale -- forty times the largest margin ever observed,
-        2.3e-7 (profiles/r03_composed_flips.txt), and a tenth of what the head tensors are held to -- and at most 0.1 % of the
-        mask's pixels + 2 may differ (observed: at most 3 pixels of a 13 500-pixel mask; round 3 allowed 1e-4 and 0.5 % + 2,
-        three orders wider than anything seen).  Without margin_ctx only images under 200 pixels fall back to
-        "IoU >= 0.999 or at most 2 pixels".  The observed flips are printed per image (pytest -s) and appended to
+        (north_star).  ONE boundary pixel is already more than 1e-4 of a mask smaller than 10^4 pixels, so a mask that misses
+        that bar may still pass through the FALLBACK: every differing pixel BORDERLINE -- its decision margin
+        (_borderline_flips, evaluated in the oracle's arithmetic on the heads under test) at most FALLBACK_MARGIN = 1e-6 of the
+        orientation field's scale, four times the largest margin ever observed (2.3e-7, profiles/r03_composed_flips.txt) -- and
+        at most FALLBACK_PIXELS = 4 pixels of the mask differing (observed: at most 3).  How many masks took the fallback is
+        counted per test, printed, logged, and bounded: more than 2 % of a test's masks (and more than 2) fails (VERDICT round 5,
+        task 5; rounds 3-5 allowed 1e-5 and 0.1 % + 2 pixels with no count).  Without margin_ctx only images under 200 pixels
+        fall back to "IoU >= 0.999 or at most 2 pixels".  The observed flips are printed per image (pytest -s) and appended to
         gpurun_out/composed_flips.txt when that directory exists;
       * position by position the scores agree within score_tol: detections may only trade places with near-ties;
       * when the list is cut at nms_post, a detection within score_tol of the last score may be replaced by its runner-up.
@@ -125,7 +130,7 @@ def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol
     small = min(want_mask.shape[1:]) < 200
     used = np.zeros(K, dtype=bool)
     unmatched, notes = [], []
-    flips, worst_iou, worst_margin = 0, 1.0, 0.0
+    flips, worst_iou, worst_margin, most_flips, n_fallback = 0, 1.0, 0.0, 0, 0
     for i in range(K):
         cand = np.nonzero((~used) & (got_cls == want_cls[i]) & (np.abs(got_bbox - want_bbox[i]).max(1) <= 1e-4))[0]
         hit = None
@@ -133,14 +138,16 @@ def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol
             iou = _mask_iou(got_mask[j], want_mask[i])
             nflip = int(np.count_nonzero(got_mask[j].astype(bool) != want_mask[i].astype(bool)))
             margin = 0.0
+            fell_back = False
             ok = iou >= 1 - 1e-4
             if not ok and margin_ctx is not None:
                 nflip, margin = _borderline_flips(got_mask[j], want_mask[i], margin_ctx, ctx_of[j])
-                ok = margin <= 1e-5 and nflip <= 2 + 0.001 * np.count_nonzero(want_mask[i])
+                ok = margin <= FALLBACK_MARGIN and nflip <= FALLBACK_PIXELS
+                fell_back = ok
             elif not ok and small:
                 ok = iou >= 0.999 or nflip <= 2
             if ok:
-                hit = (j, iou, nflip, margin)
+                hit = (j, iou, nflip, margin, fell_back)
                 break
             notes.append((i, int(j), round(iou, 6), nflip, margin))
         if hit:
@@ -148,14 +155,22 @@ def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol
             flips += hit[2]
             worst_iou = min(worst_iou, hit[1])
             worst_margin = max(worst_margin, hit[3])
+            most_flips = max(most_flips, hit[2])
+            n_fallback += int(hit[4])
         else:
             unmatched.append(i)
-    line = ("composed %s: %d detections, %d differing mask pixels in all, worst mask IoU %.6f, largest decision margin of a "
-            "differing pixel %.2e of the field's scale, %d unmatched %s" % (tag, K, flips, worst_iou, worst_margin, len(unmatched), notes[:6]))
+    # per test (PYTEST_CURRENT_TEST): masks compared so far and how many of them needed the fallback
+    tally = _FALLBACK_TALLY.setdefault(os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], [0, 0])
+    tally[0] += K; tally[1] += n_fallback
+    line = ("composed %s: %d detections, %d differing mask pixels in all (at most %d in one mask), worst mask IoU %.6f, largest "
+            "decision margin of a differing pixel %.2e of the field's scale, %d masks through the borderline fallback (this test so "
+            "far: %d of %d), %d unmatched %s" % (tag, K, flips, most_flips, worst_iou, worst_margin, n_fallback, tally[1], tally[0],
+                                                 len(unmatched), notes[:6]))
     print(line)
     if os.path.isdir("gpurun_out"):
         with open(os.path.join("gpurun_out", "composed_flips.txt"), "a") as fh:
             fh.write(line + "\n")
+    assert tally[1] <= max(2, 0.02 * tally[0]), (tag, "too many masks needed the borderline fallback", tally)
     at_cut = [i for i in unmatched if K == nms_post and ws[i] <= ws.min() * (1 + score_tol)]
     assert len(unmatched) == len(at_cut) <= 1, (tag, "detections without a counterpart", unmatched, ws[unmatched], notes[:6])
     # a candidate-ordered list (no top-k anywhere) has no freedom at all
@@ -733,6 +748,9 @@ def test_wino14_dual_equals_twelve_wave(dev, case):
     from orienmask_amd.pack import winograd14_weights_split
     B, H, W, cin, cout, leaky, use_res = case
     L = omlib.load()
+    if not L.om_wino14_dual_built():
+        assert L.om_set_wino14_variant(1) != 0          # loud, not silently the other kernel
+        pytest.skip("the default library does not contain the dual-role kernel (make -C orienmask_amd/csrc W14D=1)")
     g = torch.Generator().manual_seed(sum(case) + 5)
     x = torch.randn(B, H, W, cin, generator=g)
     w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
@@ -996,14 +1014,28 @@ def test_forward_matches_reference_golden(dev, fname, precision):
     _check_forward_fixture(out, g, fname, precision, dev, size, batch)
 
 
-def test_forward_matches_oracle_and_layouts(dev):
-    """Full head tensors vs the oracle on a non-square input; also pins the returned layouts."""
+_ORACLE_CACHE = {}
+
+
+def _oracle_once(key, fn):
+    """The CPU oracle's tensors for a seeded case, computed once per session (the same case runs in several precisions)."""
+    if key not in _ORACLE_CACHE:
+        with torch.no_grad():
+            _ORACLE_CACHE[key] = fn()
+    return _ORACLE_CACHE[key]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32_split"])
+def test_forward_matches_oracle_and_layouts(dev, precision):
+    """Full head tensors vs the oracle on a non-square input, with fp32 operands and in the plugin's default precision; also pins
+    the returned layouts."""
     sd = synth.synth_state_dict(5, obj_bias=-16.0, head_gain=4.0)
     x = synth.synth_image_batch(6, 3, 128, 192)
-    net = _hip_model(sd, dev)
+    net = _hip_model(sd, dev, precision)
     with torch.no_grad():
         out = net(x.to(dev))
-    ref = R.forward(sd, x)
+    assert out.flags() == 0
+    ref = _oracle_once(("fwd", 5, 6, 3, 128, 192), lambda: R.forward(sd, x))
     for (gb, go), (rb, ro) in zip(out, ref):
         assert gb.shape == rb.shape and go.shape == ro.shape
         assert gb.stride(1) == 1                      # channels-last box heads
@@ -1696,6 +1728,7 @@ def test_conv_f16_layer_matches_torch(dev, case, variant):
     from orienmask_amd.pack import conv_weights_f16
     B, H, W, cin, cout, k, stride, leaky, use_res, out_f32 = case
     L = omlib.load()
+    previous = L.om_get_conv3x3_f16_variant()       # OM_C3_TALL of the environment, or the default: restored below
     omlib.check(L.om_set_conv3x3_f16_variant(variant), "om_set_conv3x3_f16_variant")
     g = torch.Generator().manual_seed(sum(case) + 11)
     x = torch.randn(B, cin, H, W, generator=g).half()
@@ -1719,10 +1752,12 @@ def test_conv_f16_layer_matches_torch(dev, case, variant):
     rd = res.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None
     ostride = 256 if out_f32 else cout
     out = torch.full((B, Ho, Wo, ostride), float("nan"), device=dev, dtype=torch.float32 if out_f32 else torch.float16)
-    rc = L.om_conv2d_f16(_p(xd), B, H, W, cin, cin, _p(wd), _p(sd_), _p(hd), cout, k, stride, leaky,
-                         _p(rd) if use_res else None, cout if use_res else 0, _p(out), ostride, out_f32,
-                         omlib.current_stream_ptr(dev))
-    L.om_set_conv3x3_f16_variant(1)
+    try:
+        rc = L.om_conv2d_f16(_p(xd), B, H, W, cin, cin, _p(wd), _p(sd_), _p(hd), cout, k, stride, leaky,
+                             _p(rd) if use_res else None, cout if use_res else 0, _p(out), ostride, out_f32,
+                             omlib.current_stream_ptr(dev))
+    finally:
+        L.om_set_conv3x3_f16_variant(previous)
     omlib.check(rc, "om_conv2d_f16")
     got = out[..., :cout].cpu().permute(0, 3, 1, 2).double()
     assert torch.isfinite(got).all()
@@ -1829,19 +1864,26 @@ def test_forward_f16_matches_oracle(dev, batch, size):
     print("fp16 forward vs oracle.forward_f16: worst rel err %.3e" % worst)
 
 
-def test_forward_bs6_uses_f24_and_matches_oracle(dev):
-    """From 1700 1/32-scale cells on (bs >= 6 at 544x544) the stride-1 3x3 layers run Winograd F(2x4,3x3); below, F(2x2,3x3).
-    Head tensors of a 6-image batch against the oracle, and the switch itself as om_layer_tile reports it."""
+@pytest.mark.parametrize("precision", ["f32", "f32_split"])
+def test_forward_bs6_uses_f24_and_matches_oracle(dev, precision):
+    """With fp32 operands, from 1700 1/32-scale cells on (bs >= 6 at 544x544) the stride-1 3x3 layers run Winograd F(2x4,3x3);
+    below, F(2x2,3x3); in the default split-operand precision they run the fused F(4,3) kernel at every batch size.  Head tensors
+    of a 6-image batch against the oracle, and the kernel choice itself as om_layer_tile reports it."""
     sd = synth.synth_state_dict(9, obj_bias=-16.0, head_gain=4.0)
     x = synth.synth_image_batch(26, 6, 544, 544)
-    net = _hip_model(sd, dev)
+    net = _hip_model(sd, dev, precision)
     with torch.no_grad():
         out = net(x.to(dev))
     torch.cuda.synchronize()
+    assert out.flags() == 0
     k6 = dict(net.layer_kernels(6, 544, 544)); k2 = dict(net.layer_kernels(2, 544, 544))
-    assert k6["orien_head.2"].startswith("wino24_gemm") and k2["orien_head.2"].startswith("wino_gemm")
-    assert k6["backbone.conv6.2.conv.1"].startswith("wino24_gemm") and k2["backbone.conv6.2.conv.1"].startswith("wino_gemm")
-    ref = R.forward(sd, x)
+    if precision == "f32":
+        assert k6["orien_head.2"].startswith("wino24_gemm") and k2["orien_head.2"].startswith("wino_gemm")
+        assert k6["backbone.conv6.2.conv.1"].startswith("wino24_gemm") and k2["backbone.conv6.2.conv.1"].startswith("wino_gemm")
+    else:
+        for k in (k6, k2):
+            assert k["orien_head.2"].startswith("wino14_split") and k["backbone.conv6.2.conv.1"].startswith("wino14_split")
+    ref = _oracle_once(("fwd", 9, 26, 6, 544, 544), lambda: R.forward(sd, x))
     for (gb, go), (rb, ro) in zip(out, ref):
         assert _rel_err(gb.cpu(), rb) < REL_TOL and _rel_err(go.cpu(), ro) < REL_TOL
 
@@ -1945,20 +1987,21 @@ def test_bench_workload_bs32_detections(dev):
                                    ("bench workload end to end", b), margin_ctx=_margin_ctx(oracle_post, heads, i))
 
 
-def test_backbone_features_bs8_match_oracle(dev):
+@pytest.mark.parametrize("precision", ["f32", "f32_split"])
+def test_backbone_features_bs8_match_oracle(dev, precision):
     """BASELINE configs[1]: DarkNet-53 only, random weights, bs=8 at 544x544 -- x4 / x8 / x16 / x32 as the HIP kernels
-    left them in the workspace vs the CPU oracle's backbone, <= 1e-4 of each tensor's scale."""
+    left them in the workspace vs the CPU oracle's backbone, <= 1e-4 of each tensor's scale; with fp32 operands and in the
+    plugin's / the bench's default precision (split operands)."""
     sd = synth.synth_state_dict(8, obj_bias=-16.0, head_gain=4.0)
     x = synth.synth_image_batch(25, 8, 544, 544)
-    net = _hip_model(sd, dev)
+    net = _hip_model(sd, dev, precision)
     with pytest.raises(omlib.OrienMaskHipError):
         net(torch.zeros(1, 3, 64, 64, device=dev)); net.layer_output("backbone.conv3.2.conv.1", (1, 3, 64, 64))
     net.keep_activations(True)          # activations share memory by live range unless asked to stay
     with torch.no_grad():
         net(x.to(dev))
     torch.cuda.synchronize()
-    with torch.no_grad():
-        x32, x16, x8, x4 = R.backbone(sd, x)
+    x32, x16, x8, x4 = _oracle_once(("backbone", 8, 25, 8, 544, 544), lambda: R.backbone(sd, x))
     for name, want in (("backbone.conv3.2.conv.1", x4), ("backbone.conv4.8.conv.1", x8), ("backbone.conv5.8.conv.1", x16),
                        ("backbone.conv6.4.conv.1", x32)):
         got = net.layer_output(name, x.shape).cpu()
@@ -2611,6 +2654,8 @@ def test_bench_line_with_the_rccl_path_on_one_gpu(dev):
     assert line["solo_reference"]["value"] > 0 and 0.8 < line["scaling_efficiency"] < 1.25
     assert line["weight_broadcast"]["blobs"] == 2 and line["weight_broadcast"]["gbs"] > 0
     rf = line["roofline"]
-    assert list(rf)[:9] == ["bound", "achieved", "peak", "unit", "frac", "traffic", "frac_counts", "achieved_algorithmic", "algorithmic_frac"]
-    assert rf["kernel"].startswith("wino14_split_kernel") and 0 < rf["algorithmic_frac"] < rf["frac"] < 1
+    assert list(rf)[:9] == ["bound", "achieved", "peak", "unit", "frac", "traffic", "frac_counts", "achieved_executed", "executed_frac"]
+    # `frac` counts ALGORITHMIC (direct-convolution) flops; the fused F(4,3) kernel with split operands executes 1.5x as many
+    assert rf["kernel"].startswith("wino14_split_kernel") and 0 < rf["frac"] < rf["executed_frac"] < 1
+    assert abs(rf["executed_frac"] / rf["frac"] - 1.5) < 0.01 and abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-3
     assert rf["one_batch_in_flight_images_per_s"] == line["one_batch_in_flight"]["value"]

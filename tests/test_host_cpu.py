@@ -484,41 +484,37 @@ def test_no_packed_fp32_register_half_select(tmp_path):
     """gfx950 erratum found in round 5 (tools/hazard_probe/pk_opsel_repro.hip, profiles/r05_experiments.md 2): v_pk_add/mul/fma_f32
     with a source-half selection (op_sel / op_sel_hi) on a REGISTER operand returns wrong lanes now and then while another wave on
     the same SIMD issues wide-K matrix instructions -- which this library's kernels do on every other stream.  hipcc emits the form
-    when it packs scalar code (SLP) or broadcasts a scalar into vector arithmetic.  No kernel of the library may contain one: every
-    source file is compiled with the Makefile's flags and its gfx950 code scanned (constants may be half-selected, registers not)."""
+    when it packs scalar code (SLP) or broadcasts a scalar into vector arithmetic.  No kernel of the library may contain one.  Since
+    round 6 the BUILD enforces it (csrc/Makefile: every file is compiled with -fno-slp-vectorize, its gfx950 code kept by
+    -save-temps=obj and scanned by csrc/isa_audit.py, which fails the rule); this test checks that the rule is there for every
+    source file, that the scanner flags the form and nothing else, and re-runs it over the code of the library that was built."""
     import subprocess
-    from concurrent.futures import ThreadPoolExecutor
+    import importlib.util
     csrc = os.path.join(REPO, "orienmask_amd", "csrc")
+    spec = importlib.util.spec_from_file_location("isa_audit", os.path.join(csrc, "isa_audit.py"))
+    audit = importlib.util.module_from_spec(spec); spec.loader.exec_module(audit)
+    sample = tmp_path / "sample.s"
+    sample.write_text("\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel_hi:[0,1,1]\n"          # a register's low half twice: the erratum's form
+                      "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]\n"                        # the high half of a register
+                      "\tv_pk_mul_f32 v[0:1], v[2:3], 1.0 op_sel_hi:[1,0]\n"                        # a half-selected constant: fine
+                      "\tv_pk_add_f32 v[0:1], v[2:3], s[4:5] op_sel_hi:[1,0]\n"                     # a scalar pair: fine
+                      "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7]\n")                            # no selection: fine
+    assert len(audit.bad_instructions(str(sample))) == 2
     mk = open(os.path.join(csrc, "Makefile")).read()
-    nopk = re.search(r"^NOPK = (.*)$", mk, re.M).group(1)
-    extra = {m.group(1): m.group(2).replace("$(NOPK)", nopk) for m in re.finditer(r"^EXTRA_(\w+) = (.*)$", mk, re.M)}
-    files = sorted(f[:-4] for f in os.listdir(csrc) if f.endswith(".hip"))
-    assert len(files) >= 13
-
-    def scan(name):
-        out = str(tmp_path / (name + ".s"))
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only"] + \
-            extra.get(name, "").split() + [os.path.join(csrc, name + ".hip"), "-o", out]
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-1500:]
-        bad = []
-        for line in open(out):
-            ins = line.split(";")[0].strip()
-            if not re.match(r"v_pk_(add|mul|fma)_f32", ins) or "op_sel" not in ins:
-                continue
-            n = 3 if "fma" in ins else 2
-            sel = re.search(r"op_sel:\[([0-9,]+)\]", ins)
-            selhi = re.search(r"op_sel_hi:\[([0-9,]+)\]", ins)
-            s = [int(v) for v in sel.group(1).split(",")] if sel else [0] * n
-            sh = [int(v) for v in selhi.group(1).split(",")] if selhi else [1] * n
-            srcs = re.findall(r"(v\[\d+:\d+\]|s\[\d+:\d+\]|-?\d+\.?\d*|0x[0-9a-f]+|v\d+|s\d+)", ins.split(None, 1)[1])[1:1 + n]
-            if any(i < len(srcs) and srcs[i].startswith("v[") and (s[i] != 0 or sh[i] != 1) for i in range(n)):
-                bad.append(ins)
-        return name, bad
-
-    with ThreadPoolExecutor(max_workers=6) as ex:
-        results = list(ex.map(scan, files))
-    assert all(not bad for _, bad in results), {n: b[:3] for n, b in results if b}
+    assert re.search(r"^CXXFLAGS = .*\$\(NOPK\).*-save-temps=obj", mk, re.M) and re.search(r"^NOPK = -fno-slp-vectorize$", mk, re.M)
+    assert re.search(r"^build/%\.o:.*isa_audit\.py", mk, re.M) and "\t$(PYTHON) isa_audit.py build/$*-hip-amdgcn-amd-amdhsa-$(ARCH).s" in mk
+    r = subprocess.run(["make", "-C", csrc, "audit"], capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    files = sorted(f[:-4] for f in os.listdir(csrc) if f.endswith(".hip") and f != "conv_wino14d.hip")
+    assert len(files) >= 12
+    for f in files:     # every product source file's code was there to be scanned
+        assert os.path.exists(os.path.join(csrc, "build", f + "-hip-amdgcn-amd-amdhsa-gfx950.s")), f
+    # the dual-role kernel is not in the default library; its code is held to the same rule
+    out = str(tmp_path / "w14d.s")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-S",
+                        "--cuda-device-only", os.path.join(csrc, "conv_wino14d.hip"), "-o", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert audit.bad_instructions(out) == []
 
 
 def test_bench_clock_sampler_reads_the_drivers_table(tmp_path):

@@ -27,19 +27,19 @@ rows = """| | value |
 | end-to-end, split operands, two batches in flight (`value`) | **%s images/s** (%s ms/step); sparse heads (`--heads sparse`, ~25 detections per image): %s |
 | ... one batch at a time (`one_batch_in_flight`) | %s images/s (%s ms/step; forward kernels %s ms, postprocess kernels %s ms) |
 | the same steps with fp32 operands (`f32_operands` in the same line; `%s_bench_f32_operands.json` is `bench.py --dtype f32`) | %s / %s images/s in the default run; %s / %s in its own run (round 1: 990) |
-| `roofline`, split operands | dominant kernel `%s`, %d launches/step (fused: no pre-pass): **%s TFLOP/s executed on the fp16 pipe = %s of 2.5 PF** (%s TF by the same events without a pre-pass, i.e. the same); avg launch %s ms by HIP events in the timed region vs %s ms by rocprofv3 (`%s_rocprofv3_kernel_stats.csv`, all instantiations weighted). Against HBM (`roofline.hbm`): %s GB/s algorithmic = %s of 8 TB/s; PMC traffic %s GB per launch against %s GB algorithmic = %s GB/s = **%s of 8 TB/s** over the same time |
-| `roofline`, fp32 operands | `%s`: %s TFLOP/s executed = %s of the 157.3 TF f32-MFMA peak incl. the pre-pass (%s without); PMC traffic %s GB per launch |
+| `roofline`, split operands | dominant kernel `%s`, %d launches/step (fused: no pre-pass): **%s TFLOP/s algorithmic = %s of 2.5 PF** (`frac`; the matrix pipe executes 1.5 × that, split operands × 3 and F(4,3) × ½: %s TF = %s, `executed_frac`); avg launch %s ms by HIP events in the timed region vs %s ms by rocprofv3 (`%s_rocprofv3_kernel_stats.csv`, all instantiations weighted). Against HBM (`roofline.hbm`): %s GB/s algorithmic = %s of 8 TB/s; PMC traffic %s GB per launch against %s GB algorithmic = %s GB/s = **%s of 8 TB/s** over the same time |
+| `roofline`, fp32 operands | `%s`: %s TFLOP/s algorithmic = %s of the 157.3 TF f32-MFMA peak incl. the pre-pass (executed, F(2×4) × ⅓: %s TF = %s); PMC traffic %s GB per launch |
 | conv stack HBM by PMC (north_star: "rocprof-reported HBM GB/s for the conv stack") | split: %s GB per step over %s ms of convolution kernels = **%s GB/s = %s of 8 TB/s** (algorithmic %s GB/s = %s); fp32 operands: %s GB over %s ms = %s GB/s = %s |
 | whole step (`roofline.step`, over the step time behind `value`) | split: %s TF executed = %s of 2.5 PF, PMC conv-stack bytes %s GB/s = **%s of 8 TB/s** (algorithmic %s); fp32 operands: %s TF = %s of 157.3 TF, PMC %s GB/s = %s; fp16 configuration: %s TF = %s of 2.5 PF, PMC %s GB/s = %s |
 | postprocess occupancy (north_star: "occupancy for NMS/mask-assembly") | §3.2 last bullet; `roofline.postprocess_occupancy` in the bench line |
 | cpu_baseline (oracle, GPU box's host, %s hardware threads) | thread sweep on one image (forward): %s; best: %s images/s end to end on %s threads; bs=1 forward %s ms, postprocess %s ms (the oracle's decode runs single-threaded for reproducibility, §3.2); reported baseline, not a target |
-| fp16 configuration (`--dtype f16`, `%s_bench_f16.json`) | %s images/s (bs=32) with three batches in flight, %s one at a time (round 4: 4192 / 3249; round 5: the tall-patch / ping-pong 3×3 kernel and the first two layers in one kernel, §3.3) |
+| fp16 configuration (`--dtype f16`, `%s_bench_f16.json`) | %s images/s (bs=32) with three batches in flight, %s one at a time (round 5: 4332 / 3417; unchanged this round, §3.3) |
 """ % (d["value"], d["ms_per_step"], sp["value"], d["one_batch_in_flight"]["value"], d["one_batch_in_flight"]["ms_per_step"],
        r["forward_kernels_ms_per_step"], r["postprocess_ms_per_step"],
        tag, d["f32_operands"]["value"], d["f32_operands"]["one_batch_in_flight"], e["value"], e["one_batch_in_flight"]["value"],
-       r["kernel"], r["launches_per_step"], r["achieved"], r["frac"], r["achieved_without_pre_pass"], r["avg_launch_ms"], rp, tag,
+       r["kernel"], r["launches_per_step"], r["achieved"], r["frac"], r["achieved_executed"], r["executed_frac"], r["avg_launch_ms"], rp, tag,
        r["hbm"]["achieved"], r["hbm"]["frac"], G(r["traffic"]), G(r["algorithmic_bytes_per_launch"]), r["hbm"]["traffic_gbs"], r["hbm"]["traffic_frac"],
-       re_["kernel"], re_["achieved"], re_["frac"], round(re_["achieved_without_pre_pass"] / re_["peak"], 3), G(re_["traffic"]),
+       re_["kernel"], re_["achieved"], re_["frac"], re_["achieved_executed"], re_["executed_frac"], G(re_["traffic"]),
        G(st["bytes_per_step"]), st["kernels_ms_per_step"], st["gbs"], st["frac_of_8tbs"], r["forward_hbm_algorithmic_gbs"], r["forward_hbm_frac"],
        G(ste["bytes_per_step"]), ste["kernels_ms_per_step"], ste["gbs"], ste["frac_of_8tbs"],
        r["step"]["executed_tflops"], r["step"]["executed_frac"], r["step"]["hbm_pmc_gbs"], r["step"]["hbm_pmc_frac"], r["step"]["hbm_algorithmic_frac"],

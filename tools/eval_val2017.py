@@ -167,7 +167,16 @@ def main():
     if args.precision:
         tester.model.set_precision(args.precision)
     t0 = time.perf_counter()
-    stats, merged = tester.test_and_gather(verbose=rank == 0, in_flight=args.in_flight)
+    try:
+        stats, merged = tester.test_and_gather(verbose=rank == 0, in_flight=args.in_flight)
+    except BaseException:
+        # a rank that fails before the final all_gather_object would leave the others waiting for the collective's time-out:
+        # say why and leave at once with a non-zero status (torch.distributed.run then ends the other ranks)
+        import traceback
+        traceback.print_exc()
+        sys.stderr.write("eval_val2017: rank %d failed during evaluation; aborting the job\n" % rank)
+        sys.stderr.flush()
+        os._exit(4)
     wall = time.perf_counter() - t0
     results = {"bbox": [r for part in merged for r in part["bbox"]], "segm": [r for part in merged for r in part["segm"]]}
     if rank != 0:                 # rank 0 writes and scores

@@ -46,7 +46,8 @@ def main():
             omlib.check(L.om_conv2d_winograd24_split(p(x), B, hw, hw, cin, cin, p(u24), p(s24), p(hd), cout, 1, None, 0, p(out), cout,
                                                      p(scratch), scratch.numel(), None, st), "w24")
         res = []
-        for fn in (run14_dual, run24, run14):
+        dual = bool(L.om_wino14_dual_built())       # only in libraries built with W14D=1
+        for fn in ((run14_dual if dual else run14), run24, run14):
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
