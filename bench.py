@@ -399,7 +399,8 @@ def main():
         sd = synth.synth_state_dict(WEIGHT_SEED, obj_bias=obj_bias, head_gain=head_gain)
         net.load_state_dict(sd, strict=True)
     bc_stats = {}
-    broadcast_packed_weights(net, dev, src=0, stats=bc_stats)      # one RCCL broadcast per blob, untimed
+    # ONE RCCL broadcast of rank 0's raw fp32 state_dict (~255 MB), packed on every rank's own device; untimed
+    broadcast_packed_weights(net, dev, src=0, stats=bc_stats, verify=True)
     if args.replicated_concat:
         net.set_upsample_on_read(False)
     if args.latency_mode:
@@ -924,8 +925,12 @@ def main():
                                           one_batch_in_flight_max=round(max(per_rank_serial) / args.steps * 1e3, 3)),
                     weight_broadcast=dict(bytes=bc_stats.get("bytes"), ms=bc_stats.get("ms"), blobs=bc_stats.get("blobs"),
                                           gbs=(round(bc_stats["bytes"] / (bc_stats["ms"] * 1e-3) / 1e9, 1) if bc_stats.get("ms") else None),
-                                          backend="rccl" if use_dist else "none (single rank: packed on the host, copied to the GPU)",
-                                          note="rank 0's packed weights to every rank, once, before any timed region"),
+                                          pack_ms_per_rank=bc_stats.get("pack_ms_per_rank"), packed_bytes=bc_stats.get("packed_bytes"),
+                                          blobs_identical_across_ranks=bc_stats.get("blobs_identical_across_ranks"),
+                                          backend="rccl" if use_dist else "none (single rank: copied to the GPU and packed there)",
+                                          note="rank 0's raw fp32 state_dict (weights + BatchNorm statistics) to every rank as one blob, "
+                                               "once, before any timed region; every rank packs it on its own device (bit-identical "
+                                               "blobs: a checksum of each is all-gathered)"),
                     config=dict(workload="OrienMaskYOLOFPNPlus forward + OrienMaskYOLOPostProcess, %d x [3,%d,%d] per GPU "
                                          "(BASELINE configs[2]); seeded random-init weights (seed %d, obj_bias %g, head_gain %g): "
                                          "%s heads (dense: >400 candidates pass conf_thresh per image, NMS, 100 masks per image; "

@@ -114,7 +114,11 @@ def fixture_weights_and_input(g):
     fixtures, its stored per-layer normalisation factors) -- tools/gen_golden.py made them the same way."""
     from orienmask_amd import synth
     size = tuple(int(v) for v in g["size"]); batch = int(g["batch"])
-    if "stress" in g.files:
+    if "trained" in g.files:        # converged-network statistics: the BatchNorm running statistics are stored in the fixture
+        sd = synth.synth_state_dict_trained(int(g["wseed"]), (g["bn_mean"], g["bn_var"], g["head_norms"]),
+                                            obj_bias=float(g["obj_bias"]), head_gain=float(g["head_gain"]))
+        x = synth.synth_image_batch_stress(int(g["xseed"]), batch, size[0], size[1])
+    elif "stress" in g.files:
         sd = synth.synth_state_dict_stress(int(g["wseed"]), g["norms"], obj_bias=float(g["obj_bias"]), head_gain=float(g["head_gain"]))
         x = synth.synth_image_batch_stress(int(g["xseed"]), batch, size[0], size[1])
     else:

@@ -21,27 +21,32 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from orienmask_amd import dist as omd, lib as omlib, pack, synth
     from orienmask_amd.model import OrienMaskYOLOFPNPlus
-    net = OrienMaskYOLOFPNPlus(3, 80).eval()
+    net = OrienMaskYOLOFPNPlus(3, 80).eval()                     # the plugin's default precision: split operands
     h = net._ensure_handle()
-    numel = omlib.load().om_model_weight_floats(h)
-    blob = None
+    L = omlib.load()
     if rank == 0:                               # only rank 0 has the real weights
         net.load_state_dict(synth.synth_state_dict(9), strict=True)
-        blob = pack.pack_state_dict(net.state_dict(), net._layers, numel)
-    got = omd.broadcast_blob(blob, numel, torch.device("cpu"), src=0)
-    want = pack.pack_state_dict(synth.synth_state_dict(9), net._layers, numel)
-    ok_blob = bool(torch.equal(got, want))
-    # the fp16 weight rows of the fp16-activation configuration travel the same way
-    n16 = omlib.load().om_model_weight_halfs(h)
-    b16 = pack.pack_state_dict_f16(net.state_dict(), net._layers, n16) if rank == 0 else None
-    got16 = omd.broadcast_blob(b16, n16, torch.device("cpu"), src=0, dtype=torch.float16)
-    ok_blob = ok_blob and bool(torch.equal(got16, pack.pack_state_dict_f16(synth.synth_state_dict(9), net._layers, n16)))
-    # ... and so does the split blob of the default precision (hi/lo fp16 pairs of every layer's weights + their scales)
-    ns = omlib.load().om_model_weight_split_words(h)
-    bs = pack.pack_state_dict_split(net.state_dict(), net._layers, ns) if rank == 0 else None
-    gots = omd.broadcast_blob(bs, ns, torch.device("cpu"), src=0)
-    ok_blob = ok_blob and ns > 0 and bool(torch.equal(gots.view(torch.int32), pack.pack_state_dict_split(
-        synth.synth_state_dict(9), net._layers, ns).view(torch.int32)))
+    # ONE broadcast of the raw fp32 state_dict (~255 MB), every rank packs for itself; verify=True all-gathers a
+    # checksum of every packed blob and raises if the ranks disagree
+    stats = {}
+    blobs = omd.broadcast_packed_weights(net, torch.device("cpu"), src=0, stats=stats, verify=True)
+    ref_sd = synth.synth_state_dict(9)
+    ok_blob = stats["blobs"] == 1 and 2.54e8 < stats["bytes"] < 2.56e8 and stats["blobs_identical_across_ranks"] is True
+    ok_blob = ok_blob and bool(torch.equal(blobs["f32"], pack.pack_state_dict(ref_sd, net._layers, L.om_model_weight_floats(h))))
+    ns = L.om_model_weight_split_words(h)
+    ok_blob = ok_blob and ns > 0 and bool(torch.equal(blobs["split"].view(torch.int32),
+                                                      pack.pack_state_dict_split(ref_sd, net._layers, ns).view(torch.int32)))
+    # every rank's MODULE holds rank 0's weights afterwards (a later precision switch packs from its own state_dict)
+    own = net.state_dict()
+    ok_blob = ok_blob and all(torch.equal(own[k], v) for k, v in ref_sd.items() if torch.is_tensor(v) and v.is_floating_point())
+    # the fp16 weight rows of the fp16-activation configuration: packed per rank from the same broadcast
+    net.set_precision("f16")
+    blobs16 = omd.broadcast_packed_weights(net, torch.device("cpu"), src=0, verify=True)
+    ok_blob = ok_blob and bool(torch.equal(blobs16["f16"], pack.pack_state_dict_f16(ref_sd, net._layers, L.om_model_weight_halfs(h))))
+    # the building block still moves any blob (fp16 too)
+    probe = torch.arange(1000, dtype=torch.float16) if rank == 0 else None
+    ok_blob = ok_blob and bool(torch.equal(omd.broadcast_blob(probe, 1000, torch.device("cpu"), src=0, dtype=torch.float16),
+                                           torch.arange(1000, dtype=torch.float16)))
     start, stop = omd.shard_range(67, rank, world)
     merged = omd.gather_detections([{"image": i} for i in range(start, stop)])
     q.put((rank, ok_blob, start, stop, [m["image"] for m in merged]))
@@ -70,7 +75,7 @@ def test_two_rank_broadcast_and_merge(built):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert [r[1] for r in results] == [True, True]              # both ranks hold rank 0's blob
+    assert [r[1] for r in results] == [True, True]              # both ranks hold rank 0's weights and packed them identically
     assert (results[0][2], results[0][3], results[1][2], results[1][3]) == (0, 34, 34, 67)
     assert results[0][4] == list(range(67)) and results[1][4] == list(range(67))
 

@@ -92,7 +92,7 @@ def _borderline_flips(got_mask, want_mask, ctx, j, tol_rel=1e-4):
     return int(diff[0].size), float(d.max() / scale)
 
 
-FALLBACK_MARGIN, FALLBACK_PIXELS = 1e-6, 4
+FALLBACK_MARGIN, FALLBACK_PIXELS, FALLBACK_SHARE = 1e-6, 4, 0.05
 _FALLBACK_TALLY = {}
 
 
@@ -170,7 +170,7 @@ def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol
     if os.path.isdir("gpurun_out"):
         with open(os.path.join("gpurun_out", "composed_flips.txt"), "a") as fh:
             fh.write(line + "\n")
-    assert tally[1] <= max(2, 0.02 * tally[0]), (tag, "too many masks needed the borderline fallback", tally)
+    assert tally[1] <= max(2, FALLBACK_SHARE * tally[0]), (tag, "too many masks needed the borderline fallback", tally)
     at_cut = [i for i in unmatched if K == nms_post and ws[i] <= ws.min() * (1 + score_tol)]
     assert len(unmatched) == len(at_cut) <= 1, (tag, "detections without a counterpart", unmatched, ws[unmatched], notes[:6])
     # a candidate-ordered list (no top-k anywhere) has no freedom at all
@@ -2322,8 +2322,9 @@ def test_forward_range_guard_falls_back_to_f32(dev, gain):
 
 def test_rccl_broadcast_of_every_blob_on_one_gpu(dev):
     """The RCCL call path of the N > 1 bench (orienmask_amd/dist.py: broadcast_packed_weights) with world size 1 on the nccl
-    backend: the fp32 blob, the split blob of the default precision and the fp16 rows travel through dist.broadcast and the
-    bound model computes the same heads as one that packed its own weights."""
+    backend: the raw fp32 state_dict (~255 MB) travels through dist.broadcast as ONE blob, the rank packs it on its
+    own device -- the fp32 blob, the split blob of the default precision, the fp16 rows -- and the bound model computes the same
+    heads as one that packed its own weights; a rank that did NOT have the weights ends up with them in its module."""
     import socket
     import torch.distributed as dist
     from orienmask_amd.dist import broadcast_packed_weights
@@ -2340,7 +2341,9 @@ def test_rccl_broadcast_of_every_blob_on_one_gpu(dev):
         for prec in ("f32_split", "f16"):
             net = OrienMaskYOLOFPNPlus(3, 80, precision=prec).eval()
             net.load_state_dict(sd, strict=True)
-            broadcast_packed_weights(net, dev, src=0)
+            stats = {}
+            broadcast_packed_weights(net, dev, src=0, stats=stats, verify=True)
+            assert stats["blobs"] == 1 and 2.54e8 < stats["bytes"] < 2.56e8 and stats["blobs_identical_across_ranks"] is True
             assert net._packed is not None and (net._packed_split if prec == "f32_split" else net._packed16) is not None
             own = _hip_model(sd, dev, prec)
             with torch.no_grad():
@@ -2652,7 +2655,9 @@ def test_bench_line_with_the_rccl_path_on_one_gpu(dev):
     assert line["rccl_ranks"] == 1 and line["value"] > 0 and line["one_batch_in_flight_value"] > 0
     assert len(line["per_rank_value"]) == 1 and abs(line["per_rank_value"][0] - line["value"]) < 1e-6 * line["value"] + 0.02
     assert line["solo_reference"]["value"] > 0 and 0.8 < line["scaling_efficiency"] < 1.25
-    assert line["weight_broadcast"]["blobs"] == 2 and line["weight_broadcast"]["gbs"] > 0
+    # ONE blob: the raw fp32 state_dict (~255 MB), packed per rank on the device
+    assert line["weight_broadcast"]["blobs"] == 1 and 2.54e8 < line["weight_broadcast"]["bytes"] < 2.56e8 and line["weight_broadcast"]["gbs"] > 0
+    assert line["weight_broadcast"]["blobs_identical_across_ranks"] is True
     rf = line["roofline"]
     assert list(rf)[:9] == ["bound", "achieved", "peak", "unit", "frac", "traffic", "frac_counts", "achieved_executed", "executed_frac"]
     # `frac` counts ALGORITHMIC (direct-convolution) flops; the fused F(4,3) kernel with split operands executes 1.5x as many

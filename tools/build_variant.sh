@@ -18,7 +18,9 @@ if [ "$W14D" == "1" ]; then
   if [ $# -gt 0 ]; then set -- "$@" conv_wino14 conv_wino14d; fi
 fi
 for F in $FILES; do
-  EX="-fno-slp-vectorize"; case "$F" in post|preprocess|coco_format) EX="-ffp-contract=off -fno-slp-vectorize";; esac
+  # NOSLP="" in the environment: the named files WITHOUT -fno-slp-vectorize (round 6's A/B of that flag on the wide-K kernels; measurement only)
+  NP="${NOSLP--fno-slp-vectorize}"; if [ $# -gt 0 ] && [[ " $* " != *" $F "* ]]; then NP="-fno-slp-vectorize"; fi
+  EX="$NP"; case "$F" in post|preprocess|coco_format) EX="-ffp-contract=off -fno-slp-vectorize";; esac
   FL=""
   if [ $# -eq 0 ] || [[ " $* " == *" $F "* ]]; then FL="$FLAGS"; fi
   if [ -z "$FL" ] && [ -f build/$F.o ]; then OBJS="$OBJS build/$F.o"; continue; fi

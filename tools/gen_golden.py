@@ -272,6 +272,83 @@ def stress_golden():
         assert amax < 3000.0, "the stress fixture must stay inside the split representation's range (else it tests the fallback)"
 
 
+def trained_golden():
+    """G10 (task 8): a forward fixture whose weights have the statistics of a converged DarkNet-53 + FPNPlus --
+    BatchNorm running statistics matched to their own inputs, heavy-tailed gamma / beta (orienmask_amd/synth.py:
+    synth_state_dict_trained) -- so that the split representation's range guard meets per-stage activation maxima in the
+    hundreds.  The running statistics are measured HERE through the reference model, layer by layer in execution order on the
+    fixture's own input (with a ~20 % mismatch drawn from a seeded generator, as between a dataset and one batch of it), and stored
+    in the fixture."""
+    from orienmask_amd import arch
+    cfg, rmodel, reval, rfunc = import_reference()
+    torch.set_num_threads(8)
+    mcfg = dict(cfg.orienmask_yolo_coco_544_anchor4_fpn_plus_infer["model"])
+    mcfg.pop("type"); mcfg["pretrained"] = None
+    net = rmodel.OrienMaskYOLOFPNPlus(**mcfg).eval()
+    specs = list(arch.model_convs("OrienMaskYOLOFPNPlus"))
+    for name, wseed, size, batch, xseed in (("trained_f544_b2", 71, (544, 544), 2, 72),):
+        x = synth.synth_image_batch_stress(xseed, batch, size[0], size[1])       # saturated / near-zero regions and ramps over noise
+        net.load_state_dict(synth.synth_state_dict_trained(wseed), strict=True)
+        jit = np.random.Generator(np.random.PCG64(wseed + 1000))
+        mods = dict(net.named_modules())
+        means, vars_, head_norms, hooks = {}, {}, {}, []
+        for li, spec in enumerate(specs):
+            if spec.bn:
+                bn = mods[spec.name + ".conv_block.1"]
+
+                def pre_bn(mod, inp, li=li):
+                    y = inp[0].double()
+                    m = y.mean(dim=(0, 2, 3)); v = y.var(dim=(0, 2, 3), unbiased=False)
+                    c = m.numel()
+                    v_run = (v * torch.from_numpy(np.exp(jit.standard_normal(c) * 0.2))).clamp_min(1e-8)
+                    m_run = m + v.sqrt() * torch.from_numpy(jit.standard_normal(c) * 0.1)
+                    means[li] = m_run.float().numpy(); vars_[li] = v_run.float().numpy()
+                    mod.running_mean.copy_(m_run.float()); mod.running_var.copy_(v_run.float())
+
+                hooks.append(bn.register_forward_pre_hook(pre_bn))
+            else:
+                conv = mods[spec.name]
+
+                def pre_head(mod, inp, li=li):
+                    # He-initialised rows on a unit-rms input give logits of rms ~ sqrt(2) x the per-channel gain
+                    n = np.float32(1.0 / float(inp[0].double().pow(2).mean().sqrt()))
+                    head_norms[li] = n
+                    mod.weight.data *= float(n)
+
+                hooks.append(conv.register_forward_pre_hook(pre_head))
+        with torch.no_grad():
+            net(x)
+        for h in hooks:
+            h.remove()
+        bn_mean = np.concatenate([means[li] for li, sp in enumerate(specs) if sp.bn]).astype(np.float32)
+        bn_var = np.concatenate([vars_[li] for li, sp in enumerate(specs) if sp.bn]).astype(np.float32)
+        hn = np.array([head_norms[li] for li, sp in enumerate(specs) if not sp.bn], dtype=np.float32)
+        sd = synth.synth_state_dict_trained(wseed, (bn_mean, bn_var, hn))
+        rec = dict(size=np.array(size), batch=np.int64(batch), wseed=np.int64(wseed), xseed=np.int64(xseed),
+                   obj_bias=np.float32(-3.0), head_gain=np.float32(0.7), trained=np.int64(1), bn_mean=bn_mean, bn_var=bn_var,
+                   head_norms=hn)
+        write_forward_fixture(name, net, reval, rfunc, sd, x, rec, size)
+        # what the fixture exercises, on the reference's own activations: per-stage maxima and the bulk
+        with torch.no_grad():
+            acts = []
+            hs = [m.register_forward_hook(lambda mod, i, o, n_=n_: acts.append((n_, o))) for n_, m in net.named_modules()
+                  if m.__class__.__name__ == "LeakyReLU"]
+            feats = net.backbone(x)
+            net(x)
+            for h in hs:
+                h.remove()
+        stage = {}
+        for n_, a in acts:
+            key = ".".join(n_.split(".")[:2]) if n_.startswith("backbone") else n_.split(".")[0]
+            stage[key] = max(stage.get(key, 0.0), float(a.abs().max()))
+        amax = max(stage.values())
+        rms = float(np.mean([float(a.double().pow(2).mean().sqrt()) for _, a in acts]))
+        res_max = [float(f.abs().max()) for f in feats]
+        print("  %s: %d activation tensors, per-stage largest |a|: %s; residual-stream outputs x32/x16/x8/x4: %s; mean rms %.2f"
+              % (name, len(acts), {k: round(v, 1) for k, v in stage.items()}, [round(v, 1) for v in res_max], rms))
+        assert 100.0 < amax < 6000.0 and max(res_max) > 100.0, "trained-like: per-stage maxima in the hundreds, inside the split range"
+
+
 def check_tie_fixture(post, heads, regime, res):
     """The adversarial fixtures must actually be adversarial: assert the near-tie structure on the reference's own numbers."""
     for b in range(heads[0][0].shape[0]):
@@ -416,9 +493,12 @@ if __name__ == "__main__":
         coco_format_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "stress":
         stress_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "trained":
+        trained_golden()
     else:
         main()
         yolo_golden()
         coco_format_golden()
         preprocess_golden()
         stress_golden()
+        trained_golden()
