@@ -92,7 +92,7 @@ def _borderline_flips(got_mask, want_mask, ctx, j, tol_rel=1e-4):
     return int(diff[0].size), float(d.max() / scale)
 
 
-FALLBACK_MARGIN, FALLBACK_PIXELS, FALLBACK_SHARE = 1e-6, 4, 0.05
+FALLBACK_MARGIN, FALLBACK_PIXELS, FALLBACK_SHARE = 1e-6, 4, 0.02
 _FALLBACK_TALLY = {}
 
 
@@ -105,9 +105,10 @@ def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol
         that bar may still pass through the FALLBACK: every differing pixel BORDERLINE -- its decision margin
         (_borderline_flips, evaluated in the oracle's arithmetic on the heads under test) at most FALLBACK_MARGIN = 1e-6 of the
         orientation field's scale, four times the largest margin ever observed (2.3e-7, profiles/r03_composed_flips.txt) -- and
-        at most FALLBACK_PIXELS = 4 pixels of the mask differing (observed: at most 3).  How many masks took the fallback is
-        counted per test, printed, logged, and bounded: more than 2 % of a test's masks (and more than 2) fails (VERDICT round 5,
-        task 5; rounds 3-5 allowed 1e-5 and 0.1 % + 2 pixels with no count).  Without margin_ctx only images under 200 pixels
+        at most FALLBACK_PIXELS = 4 pixels of the mask differing (observed: at most 2).  How many masks took the fallback is
+        counted per test -- per DISTINCT box: a candidate box is one detection per passing class, all with the same mask --
+        printed, logged, and bounded: more than FALLBACK_SHARE = 2 % of a test's distinct boxes (and more than 2) fails (VERDICT
+        round 5, task 5; rounds 3-5 allowed 1e-5 and 0.1 % + 2 pixels with no count).  Without margin_ctx only images under 200 pixels
         fall back to "IoU >= 0.999 or at most 2 pixels".  The observed flips are printed per image (pytest -s) and appended to
         gpurun_out/composed_flips.txt when that directory exists;
       * position by position the scores agree within score_tol: detections may only trade places with near-ties;
@@ -131,8 +132,11 @@ def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol
     used = np.zeros(K, dtype=bool)
     unmatched, notes = [], []
     flips, worst_iou, worst_margin, most_flips, n_fallback = 0, 1.0, 0.0, 0, 0
+    boxes, fallback_boxes = set(), set()        # distinct boxes: one candidate box is a detection per class that passes, with ONE mask
     for i in range(K):
-        cand = np.nonzero((~used) & (got_cls == want_cls[i]) & (np.abs(got_bbox - want_bbox[i]).max(1) <= 1e-4))[0]
+        # box within 1e-4 of its own largest coordinate (>= 1: normalised units), _check_detections' measure per detection
+        box_tol = 1e-4 * max(1.0, float(np.abs(want_bbox[i, :4]).max()))
+        cand = np.nonzero((~used) & (got_cls == want_cls[i]) & (np.abs(got_bbox - want_bbox[i]).max(1) <= box_tol))[0]
         hit = None
         for j in cand:
             iou = _mask_iou(got_mask[j], want_mask[i])
@@ -157,15 +161,21 @@ def _check_detections_composed(r, want_bbox, want_cls, want_mask, tag, score_tol
             worst_margin = max(worst_margin, hit[3])
             most_flips = max(most_flips, hit[2])
             n_fallback += int(hit[4])
+            boxes.add(want_bbox[i, :4].tobytes())
+            if hit[4]:
+                fallback_boxes.add(want_bbox[i, :4].tobytes())
         else:
             unmatched.append(i)
-    # per test (PYTEST_CURRENT_TEST): masks compared so far and how many of them needed the fallback
+    # per test (PYTEST_CURRENT_TEST): distinct masks compared so far and how many of them needed the fallback.  Counted per distinct
+    # BOX: a candidate box is one detection per class that passes (postprocess.py:102 lists (candidate, class) pairs) and all of
+    # them carry the same mask, so one borderline pixel shows up in up to 80 detections
     tally = _FALLBACK_TALLY.setdefault(os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], [0, 0])
-    tally[0] += K; tally[1] += n_fallback
-    line = ("composed %s: %d detections, %d differing mask pixels in all (at most %d in one mask), worst mask IoU %.6f, largest "
-            "decision margin of a differing pixel %.2e of the field's scale, %d masks through the borderline fallback (this test so "
-            "far: %d of %d), %d unmatched %s" % (tag, K, flips, most_flips, worst_iou, worst_margin, n_fallback, tally[1], tally[0],
-                                                 len(unmatched), notes[:6]))
+    tally[0] += len(boxes); tally[1] += len(fallback_boxes)
+    line = ("composed %s: %d detections of %d distinct boxes, %d differing mask pixels in all (at most %d in one mask), worst mask IoU "
+            "%.6f, largest decision margin of a differing pixel %.2e of the field's scale, %d masks of %d distinct boxes through the "
+            "borderline fallback (this test so far: %d of %d distinct boxes), %d unmatched %s"
+            % (tag, K, len(boxes), flips, most_flips, worst_iou, worst_margin, n_fallback, len(fallback_boxes), tally[1], tally[0],
+               len(unmatched), notes[:6]))
     print(line)
     if os.path.isdir("gpurun_out"):
         with open(os.path.join("gpurun_out", "composed_flips.txt"), "a") as fh:

@@ -8,19 +8,18 @@ B=$R/ab/build_$NAME
 mkdir -p $B
 cd $R/orienmask_amd/csrc
 OBJS=""
-# the Makefile's flags: -fno-slp-vectorize on every file; W14D=1 in the environment adds the dual-role kernel (conv_wino14d.hip)
+# the Makefile's flags; W14D=1 in the environment adds the dual-role kernel (conv_wino14d.hip)
 FILES="conv_igemm conv_igemm_f16 conv3x3_f16 conv_wino conv_wino24 conv_wino14 conv_igemm_split conv_stem conv_stem2 preprocess coco_format post"
 MODEL=build/om_model.o
 if [ "$W14D" == "1" ]; then
   FILES="$FILES conv_wino14d"; FLAGS="$FLAGS -DOM_WITH_W14D=1"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize -DOM_WITH_W14D=1 -x hip -c om_model.cpp -o $B/om_model.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DOM_WITH_W14D=1 -x hip -c om_model.cpp -o $B/om_model.o
   MODEL=$B/om_model.o
   if [ $# -gt 0 ]; then set -- "$@" conv_wino14 conv_wino14d; fi
 fi
 for F in $FILES; do
-  # NOSLP="" in the environment: the named files WITHOUT -fno-slp-vectorize (round 6's A/B of that flag on the wide-K kernels; measurement only)
-  NP="${NOSLP--fno-slp-vectorize}"; if [ $# -gt 0 ] && [[ " $* " != *" $F "* ]]; then NP="-fno-slp-vectorize"; fi
-  EX="$NP"; case "$F" in post|preprocess|coco_format) EX="-ffp-contract=off -fno-slp-vectorize";; esac
+  EX=""; case "$F" in post|preprocess|coco_format) EX="-ffp-contract=off -fno-slp-vectorize";; conv_stem|conv_wino|conv_wino24) EX="-fno-slp-vectorize";; esac
+  if [ -n "$NOSLP_ALL" ]; then case "$F" in post|preprocess|coco_format) ;; *) EX="-fno-slp-vectorize";; esac; fi     # round 6's A/B: the flag on every file
   FL=""
   if [ $# -eq 0 ] || [[ " $* " == *" $F "* ]]; then FL="$FLAGS"; fi
   if [ -z "$FL" ] && [ -f build/$F.o ]; then OBJS="$OBJS build/$F.o"; continue; fi
