@@ -5,8 +5,13 @@
  * torch-ROCm tensor.data_ptr()); the library never allocates device memory on the hot path
  * and launches only on the stream it is handed.  All functions return 0 on success or a
  * negative OM_E* code; om_last_error() holds the message (thread-local).  No exceptions
- * cross this boundary; the library has no mutable global state besides that thread-local message (the unit-test
- * entries at the end own a hipMalloc'ed tile-queue word each).
+ * cross this boundary; the library has no mutable global state besides that thread-local message, the process-wide
+ * kernel-choice switches (om_set_*_variant, om_set_stem_fusion: A/B runs and tests) and the unit-test entries at the end, which
+ * own a hipMalloc'ed tile-queue word each.
+ * Threading: forwards of one om_model may be enqueued from several host threads when every thread uses its own stream and its
+ * own workspace.  The caller serialises (a) stream captures of one model (they share one second stream), (b) om_profile_* and
+ * (c) more than 64 caller streams with an attached postprocess at once.  The reference's plugin surface is single-threaded
+ * under the GIL and never leaves this contract.
  *
  * What each entry point replaces in the reference (/root/reference):
  *   om_model_* / om_forward        OrienMaskYOLOFPNPlus.__init__/forward

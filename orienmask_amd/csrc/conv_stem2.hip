@@ -130,7 +130,13 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv_stem2_split_kernel(const S
     // the image patch of a tile travels through registers: requested before the PREVIOUS tile's matrix phase, so that its round
     // trip to HBM runs under that phase -- and the requests are older than that tile's output stores (one in-order counter: a
     // wait for a load behind a store would wait for the store's round trip too)
-    constexpr int NSTAGE = (S2_P_FLOATS + S2_THREADS - 1) / S2_THREADS;
+    // Round 6, with the third layer: waves 4-7 are idle while waves 0-3 multiply it, so THEY own the patch (twice the registers each,
+    // nothing requested by waves 0-3: their offsets are out of range) and store the next tile's into LDS during that phase -- the
+    // patch area is dead from the end of conv1 on -- instead of all eight waves at the top of the next tile (1 100 of a tile's
+    // 17 500 cycles, tools/stem2_trace.py).
+    constexpr int S2_PATCH_THREADS = THIRD ? S2_THREADS / 2 : S2_THREADS;
+    constexpr int NSTAGE = (S2_P_FLOATS + S2_PATCH_THREADS - 1) / S2_PATCH_THREADS;
+    const int ptid = THIRD ? tid - S2_THREADS / 2 : tid;        // < 0: not a patch thread
     float stage[NSTAGE];
     auto request_patch = [&](int tile) {
         const int b = tile / (p.tiles_x * p.tiles_y);
@@ -140,15 +146,24 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv_stem2_split_kernel(const S
         const auto rs_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.img + (size_t)b * 3 * p.H * p.W), 0, 3 * p.H * p.W * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NSTAGE; ++i) {
-            const int e = tid + i * S2_THREADS;
+            const int e = ptid + i * S2_PATCH_THREADS;
             const int c = e / (S2_PR * S2_PC), r = e - c * (S2_PR * S2_PC);
             const int py = r / S2_PC, px = r - py * S2_PC;
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;          // patch row 0 / column 0: one above / left of conv1's first
-            const bool ok = tile < p.total_tiles && e < S2_P_FLOATS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const bool ok = tile < p.total_tiles && ptid >= 0 && e < S2_P_FLOATS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             stage[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_img, ok ? ((c * p.H + gy) * p.W + gx) * 4 : (int)0x80000000, 0, 0));
         }
     };
+    auto store_patch = [&]() {
+        if (ptid < 0) return;
+#pragma unroll
+        for (int i = 0; i < NSTAGE; ++i) {
+            const int e = ptid + i * S2_PATCH_THREADS;
+            if (e < S2_P_FLOATS) sP[e] = stage[i];
+        }
+    };
     request_patch(blockIdx.x);
+    if constexpr (THIRD) store_patch();         // the first tile's; every later tile's during the third layer of the tile before it
     for (int tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
         const int b = tile / (p.tiles_x * p.tiles_y);
         const int tr = tile - b * (p.tiles_x * p.tiles_y);
@@ -160,11 +175,7 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv_stem2_split_kernel(const S
         asm volatile("s_memtime %0" : "=s"(t0)::"memory");
 #endif
         // ---- 1. the image patch: rows y0 - 1 .., columns x0 - 1 ..
-#pragma unroll
-        for (int i = 0; i < NSTAGE; ++i) {
-            const int e = tid + i * S2_THREADS;
-            if (e < S2_P_FLOATS) sP[e] = stage[i];
-        }
+        if constexpr (!THIRD) store_patch();
         __syncthreads();
 #ifdef OM_S2_TRACE
         asm volatile("s_memtime %0" : "=s"(t1)::"memory");
@@ -334,6 +345,7 @@ __global__ __launch_bounds__(S2_THREADS, 2) void conv_stem2_split_kernel(const S
 #endif
         if constexpr (THIRD) {
             __syncthreads();        // the activation rows are complete
+            if (wave >= 4) store_patch();       // the next tile's patch (requested before conv2.0: landed long ago) beside the third layer
             if (wave < 4) {
                 // 32 outputs x 32 channels x K = 64 per wave, conv_igemm_split_kernel's arithmetic: per 16 channels the lane's two
                 // chunks {4 fk .., 8 + 4 fk ..} split in registers (split8), three matrix instructions in its order

@@ -320,7 +320,15 @@ struct om_model {
                                   // om_model_attach_postprocess, outside any capture: nothing may be created inside one, and a caller
                                   // stream's own side stream and events may be in use by an eager step at the same time)
     unsigned long long side_clock = 0;
-    std::mutex side_mutex;        // sides / capture_side / post are read and changed under it (forwards from several host threads)
+    // THREADING CONTRACT of one om_model (include/orienmask_hip.h says the same): forwards may be ENQUEUED from several host threads as
+    // long as every thread uses its own caller stream and its own workspace; `sides` / `capture_side` / `post` are looked up and
+    // changed under side_mutex, and a thread then works on a COPY of its stream's entry.  What the mutex does not cover, and the
+    // caller must therefore serialise: (1) stream CAPTURES -- all captures share capture_side's one stream and event pair, so one
+    // capture at a time per model; (2) profiling (om_profile_*: ev_pool / ev_used / prof_forwards are plain members) -- single-threaded,
+    // which is how bench.py and the tests use it; (3) more than 64 caller streams with an attached postprocess in flight at once --
+    // the 65th takes over the least recently used entry, whose side stream must have joined (it has, unless 64 forwards are still
+    // being enqueued concurrently).  The Python plugin is single-threaded under the GIL and stays inside this contract.
+    std::mutex side_mutex;
     int head_last = -2;      // graph index of the last bbox_head* layer (-1: none; -2: not looked up yet)
     void find_head_last() {
         head_last = -1;
