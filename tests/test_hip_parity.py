@@ -1110,6 +1110,36 @@ def test_forward_split_is_batch_invariant(dev):
                 assert torch.equal(fb[idx], pb) and torch.equal(fo[idx], po), idx
 
 
+@pytest.mark.parametrize("precision,which", [("f32_split", 0), ("f16", 1)])
+def test_stem_fusion_switch_is_bit_identical(dev, precision, which):
+    """om_set_stem_fusion (round 6; before: environment variables read once): with the fusion of the first layers off -- the third
+    layer outside the split-operand first-two-layers kernel, or the fp16 configuration's first two layers as separate launches --
+    om_forward runs the kernels that were the only path before the fusions existed and produces the same bits; the layer table
+    reports the kernel that runs; the previous setting is restored."""
+    L = omlib.load()
+    sd = synth.synth_state_dict(12, obj_bias=-16.0, head_gain=4.0)
+    x = synth.synth_image_batch(33, 2, 160, 224).to(dev)
+    net = _hip_model(sd, dev, precision)
+    was = L.om_get_stem_fusion(which)
+    assert was in (0, 1) and L.om_get_stem_fusion(2) == -1 and L.om_set_stem_fusion(2, 1) != 0
+    name = "backbone.conv2.1.conv.0" if which == 0 else "backbone.conv2.0"
+    try:
+        omlib.check(L.om_set_stem_fusion(which, 1), "om_set_stem_fusion")
+        with torch.no_grad():
+            fused = [(b.clone(), o.clone()) for b, o in net(x)]
+        k_on = dict(net.layer_kernels(2, 160, 224))[name]
+        omlib.check(L.om_set_stem_fusion(which, 0), "om_set_stem_fusion")
+        assert L.om_get_stem_fusion(which) == 0
+        with torch.no_grad():
+            plain = net(x)
+        k_off = dict(net.layer_kernels(2, 160, 224))[name]
+        for (fb, fo), (pb, po) in zip(fused, plain):
+            assert torch.equal(fb, pb) and torch.equal(fo, po)
+        assert k_on == "(in the previous layer's kernel)" and k_off.startswith("conv_igemm"), (k_on, k_off)
+    finally:
+        L.om_set_stem_fusion(which, was)
+
+
 def test_forward_across_the_winograd_switch(dev):
     """The same image in a batch of 2 (F(2x2,3x3)) and in a batch of 7 (F(2x4,3x3)): not bit-identical, but far inside the
     parity budget, and the composed detections agree in every index."""

@@ -532,3 +532,19 @@ def test_bench_clock_sampler_reads_the_drivers_table(tmp_path):
     assert out is not None and out["mean"] == 1987.0 and out["samples"] >= 1
     s.path = None
     assert s.start().stop() is None
+
+
+def test_blob_checksum_tells_blobs_apart():
+    """orienmask_amd.dist.blob_checksum (round 6: every rank packs the broadcast weights itself and the ranks all-gather a checksum of
+    each packed blob): equal bytes -> equal checksums; one changed word, two swapped words or a changed fp16 half -> another."""
+    import torch
+    from orienmask_amd.dist import blob_checksum
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(100003, generator=g)
+    assert blob_checksum(a) == blob_checksum(a.clone())
+    b = a.clone(); b[5] = b[5] + 1e-3
+    c = a.clone(); c[[10, 11]] = c[[11, 10]]
+    assert blob_checksum(b) != blob_checksum(a) and blob_checksum(c) != blob_checksum(a)
+    h = torch.randn(4099, generator=g).half()
+    h2 = h.clone(); h2[77] = h2[77] + 1
+    assert blob_checksum(h) == blob_checksum(h.clone()) and blob_checksum(h2) != blob_checksum(h)
