@@ -822,7 +822,9 @@ def main():
         roofline = dict(bound="mfma", achieved=round(achieved_alg, 2), peak=peak_tf, unit="TFLOP/s",
                         frac=round(achieved_alg / peak_tf, 4), traffic=traffic,
                         frac_counts="ALGORITHMIC (direct-convolution) flops / time / peak; executed_frac counts what the matrix pipe "
-                                    "executes for them (split operands x3, F(4,3) x1/2)",
+                                    "executes for them (split operands x3, F(4,3) x1/2)" +
+                                    ("" if (split or f16) else "; with fp32 operands the Winograd F(2x4) kernel executes 1/3 of the "
+                                     "algorithmic flops, so `frac` may exceed 1 here -- executed_frac is this mode's fraction of the pipe"),
                         achieved_executed=round(executed, 2), executed_frac=round(executed / peak_tf, 4),
                         kernel=dom, launches_per_step=d["launches"], avg_launch_ms=round(dom_main_ms / d["launches"], 4),
                         kernel_ms_per_step=round(dom_timed_ms, 3),
@@ -924,7 +926,7 @@ def main():
                                           one_batch_in_flight_min=round(min(per_rank_serial) / args.steps * 1e3, 3),
                                           one_batch_in_flight_max=round(max(per_rank_serial) / args.steps * 1e3, 3)),
                     weight_broadcast=dict(bytes=bc_stats.get("bytes"), ms=bc_stats.get("ms"), blobs=bc_stats.get("blobs"),
-                                          gbs=(round(bc_stats["bytes"] / (bc_stats["ms"] * 1e-3) / 1e9, 1) if bc_stats.get("ms") else None),
+                                          gbs=(round(bc_stats["bytes"] / (bc_stats["ms"] * 1e-3) / 1e9, 1) if (use_dist and bc_stats.get("ms")) else None),
                                           pack_ms_per_rank=bc_stats.get("pack_ms_per_rank"), packed_bytes=bc_stats.get("packed_bytes"),
                                           blobs_identical_across_ranks=bc_stats.get("blobs_identical_across_ranks"),
                                           backend="rccl" if use_dist else "none (single rank: copied to the GPU and packed there)",
