@@ -327,7 +327,9 @@ int om_get_wino14_variant(void);
 int om_wino14_dual_built(void);
 /* A/B switches of the two first-layers fusions (process-wide; default on; OM_NO_STEM3=1 / OM_NO_STEM2_F16=1 in the environment
  * turn them off before the first use): which = 0 the third layer (backbone.conv2.1.conv.0) inside the split-operand
- * first-two-layers kernel, which = 1 the fp16 first-two-layers kernel.  Off -> the separate kernels, bit-identical results.  A
+ * first-two-layers kernel, which = 1 the fp16 first-two-layers kernel.  Off -> the separate kernels: bit-identical results for
+ * which = 0; for which = 1 conv1's fp32 sums are formed in another order before their one rounding to fp16 (a few per cent of the
+ * activations move by one fp16 step: inside the fp16 configuration's tolerance, not bit-identical).  A
  * view the fused launcher cannot take (alignment, pixel stride, descriptor size) runs the separate kernels by itself. */
 int om_set_stem_fusion(int which, int on);
 int om_get_stem_fusion(int which);      /* 1 on, 0 off, -1 bad argument */

@@ -1114,8 +1114,9 @@ def test_forward_split_is_batch_invariant(dev):
 def test_stem_fusion_switch_is_bit_identical(dev, precision, which):
     """om_set_stem_fusion (round 6; before: environment variables read once): with the fusion of the first layers off -- the third
     layer outside the split-operand first-two-layers kernel, or the fp16 configuration's first two layers as separate launches --
-    om_forward runs the kernels that were the only path before the fusions existed and produces the same bits; the layer table
-    reports the kernel that runs; the previous setting is restored."""
+    om_forward runs the kernels that were the only path before the fusions existed: the same bits in split-operand mode, the fp16
+    configuration's own tolerance there (conv1's fp32 sums in another order before their one rounding); the layer table reports the
+    kernel that runs; the previous setting is restored."""
     L = omlib.load()
     sd = synth.synth_state_dict(12, obj_bias=-16.0, head_gain=4.0)
     x = synth.synth_image_batch(33, 2, 160, 224).to(dev)
@@ -1134,7 +1135,12 @@ def test_stem_fusion_switch_is_bit_identical(dev, precision, which):
             plain = net(x)
         k_off = dict(net.layer_kernels(2, 160, 224))[name]
         for (fb, fo), (pb, po) in zip(fused, plain):
-            assert torch.equal(fb, pb) and torch.equal(fo, po)
+            if which == 0:      # the third layer inside or behind the kernel: the same arithmetic, the same bits
+                assert torch.equal(fb, pb) and torch.equal(fo, po)
+            else:               # fp16 configuration: the fused kernel sums conv1 on the matrix pipe, the separate one on the vector
+                                # ALUs -- fp32 sums in another order, each rounded ONCE to fp16 (test_stem2_f16_matches_two_kernels:
+                                # > 97 % of conv2.0's outputs identical, the rest one fp16 step apart): the configuration's own bar
+                assert _rel_err(fb.cpu(), pb.cpu()) < 5e-3 and _rel_err(fo.cpu(), po.cpu()) < 5e-3
         assert k_on == "(in the previous layer's kernel)" and k_off.startswith("conv_igemm"), (k_on, k_off)
     finally:
         L.om_set_stem_fusion(which, was)
