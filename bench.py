@@ -871,12 +871,9 @@ def main():
                                  "layers at 136^2 / 68^2 by HBM") if split else
                                 "fp32 FLOPs on the f32-input matrix cores; the HBM bound is several x further away")
         if sclk_serial:
-            # the dominant kernel's events come from the one-batch-at-a-time region: its clock is that region's
-            clk = sclk_serial["mean"]
+            # data, not a roofline: the shader clock this GPU held during the timed regions (the peaks are quoted at 2400 MHz)
             roofline["sclk_mhz"] = dict(one_batch_in_flight=sclk_serial, batches_in_flight=sclk_flight, idle_before=sclk_idle, nominal=2400,
                                         source="sysfs pp_dpm_sclk of this GPU, sampled every 4 ms during the timed regions")
-            roofline["peak_at_measured_clock"] = round(peak_tf * clk / 2400.0, 1)
-            roofline["executed_frac_at_measured_clock"] = round(executed / (peak_tf * clk / 2400.0), 4)
         front = ["bound", "achieved", "peak", "unit", "frac", "traffic", "frac_counts", "achieved_executed", "executed_frac", "kernel",
                  "launches_per_step", "avg_launch_ms", "kernel_ms_per_step", "algorithmic_bytes_per_launch", "traffic_over_algorithmic",
                  "one_batch_in_flight_images_per_s", "one_batch_in_flight_ms_per_step", "forward_kernels_ms_per_step",
