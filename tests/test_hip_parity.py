@@ -760,7 +760,7 @@ def test_wino14_dual_equals_twelve_wave(dev, case):
     L = omlib.load()
     if not L.om_wino14_dual_built():
         assert L.om_set_wino14_variant(1) != 0          # loud, not silently the other kernel
-        pytest.skip("the default library does not contain the dual-role kernel (make -C orienmask_amd/csrc W14D=1)")
+        pytest.skip("the default library does not contain the dual-role kernel (run the session with W14D=1 in the environment)")
     g = torch.Generator().manual_seed(sum(case) + 5)
     x = torch.randn(B, H, W, cin, generator=g)
     w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
