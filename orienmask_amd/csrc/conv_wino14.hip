@@ -581,6 +581,150 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
     }
 }
 
+#ifdef W14_BIG_PROBE
+#ifndef OM_MEASUREMENT_BUILD
+#error "W14_BIG_PROBE is a measurement kernel (wrong numerics): build it with tools/build_variant.sh only"
+#endif
+// ---- measurement only (round 6; round 4's probe of profiles/r04_w14_bigtile_probe.txt completed by what it left out): what a
+// CONSUMER-ONLY 128 x 128 tile costs when the transformed input V is not made in the workgroup but arrives like the weights do --
+// by LDS-DMA from a tensor some other kernel wrote (the producing 1x1 layer's epilogue, or a pre-pass) -- AND the epilogue runs.
+// Eight waves of 64 entries x 32 output channels x six planes (192 accumulators, two waves per SIMD); per 16-channel chunk 54 KiB
+// of V (six planes x 144 entries x 64 B, rows of Ct entries gathered from a [chunk][plane][padded row][tile column][64 B] layout:
+// whole lines) into the other V buffer, one plane per group, and 144 KiB of weights through a two-slot ring of 24-KiB groups.
+// V's BYTES are whatever the input tensor holds at those offsets (the caller allocates it 2x as large: tools/wino14_bench.py with
+// OM_W14_PROBE_INPUT=1), so the numerics are wrong by construction; requests, LDS traffic, matrix work and stores are the real ones.
+constexpr int W14B_UGRP = 2 * W14_UGRP;      // one plane's three kernel rows x 128 output channels
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void wino14_big_probe_kernel(const Wino14Params p) {
+    __shared__ f32x4 smem[2 * W14_VBUF + 2 * W14B_UGRP + 1];
+    f32x4* const s_u = smem + 2 * W14_VBUF;
+    int* const s_ticket = reinterpret_cast<int*>(smem + 2 * W14_VBUF + 2 * W14B_UGRP);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm2 = wave >> 2, wn4 = wave & 3;
+    const int fi = lane & 31, fk = lane >> 5;
+    const int ngroups = 6 * p.nch;
+    const int n_tiles2 = p.n_tiles >> 1, total2 = (p.total_tiles / p.n_tiles) * n_tiles2;
+    const int TW = (p.W + 3) / 4;
+    const int ecount = (p.R + 2) * p.Ct;
+    const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.u), 0, p.u_bytes, 0x00020000);
+    const auto rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    // weights: 24 pieces of 1 KiB per group: wave w requests pieces w, w + 8, w + 16 (0-11: the first 64-channel half, 12-23 the second)
+    const int drow = lane >> 2, dcol = lane & 3;
+    int dvo[3], dhalf[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int piece = wave + 8 * i;
+        dhalf[i] = piece >= 12;
+        const int row = 16 * (piece - 12 * dhalf[i]) + drow;
+        dvo[i] = row * 64 + ((dcol ^ ((row >> 2) & 3)) * 16);
+    }
+    const int swB = (fi >> 2) & 3;
+    const int brow = (wn4 >> 1) * (W14_UGRP) + (32 * (wn4 & 1) + fi) * 4;       // half, then row of the tap's 64 rows
+    const int boff_hi = brow + (fk ^ swB), boff_lo = brow + ((2 + fk) ^ swB);
+    int aoff_hi[3], aoff_lo[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int e = 64 * wm2 + fi + ky * p.Ct;
+        const int sw = (e >> 2) & 3;
+        aoff_hi[ky] = e * 4 + (fk ^ sw);
+        aoff_lo[ky] = e * 4 + ((2 + fk) ^ sw);
+    }
+    auto issue_group = [&](int tn2, int g) {
+        if (g >= ngroups) return;
+        const int slot = g & 1;
+        const int c = g / 6, j = g - 6 * c;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int t64 = 2 * tn2 + dhalf[i];
+            const int soff = ((t64 * p.nch + c) * 6 + w14_plane(j)) * (W14_UGRP * 16);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lds_ptr_t)(s_u + slot * W14B_UGRP + (wave + 8 * i) * 64), 16, dvo[i], soff, 0, 0);
+        }
+    };
+    // V: a plane of a chunk is 144 entries x 64 B = nine 1-KiB pieces; wave w requests piece w, wave 0 also piece 8.  Entry e of the
+    // block = padded row g0 - 1 + e / Ct, tile column t0 + e % Ct; a row of Ct entries is contiguous in the source.
+    int vsrc[2];
+    auto setup_v = [&](const Wino14Tile& tl) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = 16 * (wave + 8 * i) + drow;
+            const int rr = e / p.Ct, t = e - rr * p.Ct;
+            const int sw = (e >> 2) & 3;
+            const bool ok = e < ecount && tl.g0 - 1 + rr >= 0 && tl.g0 - 1 + rr < p.gtot && tl.t0 + t < TW;
+            vsrc[i] = ok ? (((tl.g0 - 1 + rr) * TW + tl.t0 + t) * 64 + ((dcol ^ sw) * 16)) : (int)0x80000000;
+        }
+    };
+    auto issue_v_plane = [&](int c, int pl, int vb) {       // plane pl of chunk c into V buffer vb
+        if (c >= p.nch) return;
+        const int soff = (c * 6 + pl) * (p.gtot * TW * 64);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr_t)(smem + vb * W14_VBUF + pl * W14_VPLANE + wave * 64), 16, vsrc[0], soff, 0, 0);
+        if (wave == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr_t)(smem + vb * W14_VBUF + pl * W14_VPLANE + 8 * 64), 16, vsrc[1], soff, 0, 0);
+    };
+    f32x16 acc[2][6];
+    for (;;) {
+        if (tid == 0) s_ticket[0] = atomicAdd(p.ticket + 8, 1);
+        __syncthreads();
+        const int tile = __builtin_amdgcn_readfirstlane(s_ticket[0]);
+        __syncthreads();            // (also: every wave is done with the previous tile's epilogue transposes in V buffer 1)
+        if (tile >= total2) break;
+        const int tn2 = tile % n_tiles2, tm = tile / n_tiles2;
+        Wino14Tile tl;
+        tl.g0 = (tm / p.ncb) * p.R; tl.t0 = (tm % p.ncb) * p.Ct; tl.tile_n = 2 * tn2 + (wn4 >> 1); tl.n0 = tl.tile_n * W14_BN;
+        setup_v(tl);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][j][r] = 0.f;
+        issue_group(tn2, 0);
+#pragma unroll
+        for (int pl = 0; pl < 6; ++pl) issue_v_plane(0, pl, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int g = 0;
+        for (int c = 0; c < p.nch; ++c) {
+            const f32x4* sV = smem + (c & 1) * W14_VBUF;
+            auto group = [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int pl = w14_plane(j);
+                const int slot = g & 1;
+                issue_group(tn2, g + 1);
+                issue_v_plane(c + 1, pl, (c & 1) ^ 1);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const f32x4 bh = s_u[slot * W14B_UGRP + ky * (W14_BN * 4) + boff_hi];
+                    const f32x4 bl = s_u[slot * W14B_UGRP + ky * (W14_BN * 4) + boff_lo];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const f32x4 ah = sV[pl * W14_VPLANE + aoff_hi[ky] + 128 * b];
+                        const f32x4 al = sV[pl * W14_VPLANE + aoff_lo[ky] + 128 * b];
+                        const f16x8 ahh = __builtin_bit_cast(f16x8, ah), all = __builtin_bit_cast(f16x8, al);
+                        const f16x8 bhh = __builtin_bit_cast(f16x8, bh), bll = __builtin_bit_cast(f16x8, bl);
+                        acc[b][pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhh, all, acc[b][pl], 0, 0, 0);
+                        acc[b][pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bll, ahh, acc[b][pl], 0, 0, 0);
+                        acc[b][pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhh, ahh, acc[b][pl], 0, 0, 0);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                ++g;
+            };
+            group(std::integral_constant<int, 0>{});
+            group(std::integral_constant<int, 1>{});
+            group(std::integral_constant<int, 2>{});
+            group(std::integral_constant<int, 3>{});
+            group(std::integral_constant<int, 4>{});
+            group(std::integral_constant<int, 5>{});
+        }
+        // the real epilogue, once per 32 x 32 sub-tile of the wave (entries 64 wm2 + 32 b ..)
+        wino14_epilogue<MODE>(p, acc[0], tl, smem + W14_VBUF + wave * 256, 2 * wm2, wn4 & 1, lane, [] {});
+        wino14_epilogue<MODE>(p, acc[1], tl, smem + W14_VBUF + wave * 256, 2 * wm2 + 1, wn4 & 1, lane, [] {});
+    }
+}
+#endif
+
 // Block shape for a layer: Ct tile columns (a divisor-like split of ceil(W / 4)) x R padded rows with R * Ct <= 128 and
 // (R + 2) * Ct <= 160, picked for the largest share of useful rows in the 128-row matrix tile.
 void wino14_geometry(int B, int H, int W, int* R, int* Ct, int* ncb, int* nrb) {
@@ -663,6 +807,14 @@ int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream) {
     if (wino14_variant() == 1 && wino14_dual_supported(p)) return launch_wino14_dual(p, a.res != nullptr, stream);
 #endif
     const long long grid = total < 256 ? total : 256;        // one 768-thread workgroup per CU (156 KiB of LDS)
+#ifdef W14_BIG_PROBE
+    if (p.n_tiles % 2 == 0 && p.fast_io) {
+        if (a.res) hipLaunchKernelGGL(wino14_big_probe_kernel<1>, dim3(256), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL(wino14_big_probe_kernel<0>, dim3(256), dim3(512), 0, stream, p);
+        OM_CHECK_HIP(hipGetLastError());
+        return OM_OK;
+    }
+#endif
     if (!p.fast_io) hipLaunchKernelGGL(wino14_split_kernel<2>, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);
     else if (a.res) hipLaunchKernelGGL(wino14_split_kernel<1>, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);
     else hipLaunchKernelGGL(wino14_split_kernel<0>, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);

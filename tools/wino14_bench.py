@@ -22,7 +22,10 @@ def main():
     tot14 = tot24 = tot12 = 0.0
     shapes = SHAPES if not os.environ.get("OM_SHAPES") else [SHAPES[int(i)] for i in os.environ["OM_SHAPES"].split(",")]
     for hw, cin, cout, n in shapes:
-        x = torch.randn(B, hw, hw, cin, device=dev)
+        # OM_W14_PROBE_INPUT=1 (with a -DW14_BIG_PROBE=1 build, conv_wino14.hip): the input tensor allocated twice as large (pixel stride
+        # 2 cin) -- the probe reads a transformed input of 1.5x the activation's bytes from it
+        ps = 2 * cin if os.environ.get("OM_W14_PROBE_INPUT") else cin
+        x = torch.randn(B, hw, hw, ps, device=dev)
         if os.environ.get("ZERO_X"):        # the same instruction stream on zeros: what the clock under load costs (profiles/r05_experiments.md section 4)
             x.zero_()
         w = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
@@ -40,7 +43,7 @@ def main():
             L.om_set_wino14_variant(1); run14(); L.om_set_wino14_variant(0)
 
         def run14():
-            omlib.check(L.om_conv2d_wino14_split(p(x), B, hw, hw, cin, cin, p(u14), p(s14), p(hd), cout, 1, None, 0, p(out), cout, None, st), "w14")
+            omlib.check(L.om_conv2d_wino14_split(p(x), B, hw, hw, cin, ps, p(u14), p(s14), p(hd), cout, 1, None, 0, p(out), cout, None, st), "w14")
 
         def run24():
             omlib.check(L.om_conv2d_winograd24_split(p(x), B, hw, hw, cin, cin, p(u24), p(s24), p(hd), cout, 1, None, 0, p(out), cout,
