@@ -749,6 +749,12 @@ def main():
             # fp16 configuration: every activation and weight element is 2 bytes (the fp32 heads are < 1 % of the bytes)
             red = 1.0 if k.startswith("conv_stem2") else reduction(k)      # conv1's own products run on the vector ALUs
             acc(k, ms / n_fw, wk["flops"], wk["flops"] / red, wk["bytes"] / (2 if f16 else 1), pre / n_fw)
+            if pre > 0 and k.startswith("wino14_wide"):
+                # the two-kernel wide form of the fused 3x3 kernel (round 6): its pre-pass reads the layer's input and writes the
+                # transformed input, 1.5x the activation over the padded rows and whole tile columns
+                hw = H // arch.layer_div(specs[name])
+                pre_kernel[k] = "wino14_v_kernel"
+                acc("wino14_v_kernel", pre / n_fw, 0.0, 0.0, 4.0 * B * specs[name].cin * (hw * hw + 1.5 * (hw + 2) * 4 * ((hw + 3) // 4)))
             if pre > 0 and (k.startswith("wino_gemm") or k.startswith("wino24_gemm")):
                 vx = 3.0 if k.startswith("wino24") else 4.0       # transformed input: 3x / 4x the activation, plus reading it
                 pk = "wino24_input_kernel" if k.startswith("wino24") else "wino_input_kernel"

@@ -316,6 +316,19 @@ int om_conv2d_winograd24_split(const float* in, int B, int H, int W, int cin, in
 int om_conv2d_wino14_split(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* u14_split,
                            const float* scale_split, const float* shift, int cout, int leaky, const float* res,
                            int res_pix_stride, float* out, int out_pix_stride, int32_t* status_dev, om_stream stream);
+/* The same layer as TWO kernels with a 128 x 128 tile (round 6; conv_wino14.hip: wino14_v_kernel writes the transformed input
+ * V = [cin/16][6][B (H + 2)][ceil(W / 4)] entries of 64 bytes into `scratch`, wino14_wide_kernel reads it by LDS-DMA: eight waves of
+ * 64 entries x 32 channels x six planes, the fused kernel's epilogue): the same products in the same order, BIT-IDENTICAL outputs.
+ * cout_pad must be a multiple of 128 and cout of 4, the views 16-byte aligned.  om_forward (precision mode 1) runs the layers with
+ * at least 512 input channels this way -- where 2.5 x the input through HBM for the pre-pass is small next to the layer's work --
+ * unless om_set_wino14_wide(0) / OM_NO_W14_WIDE=1 (process-wide A/B switch; default on). */
+size_t om_conv2d_wino14_wide_scratch_bytes(int B, int H, int W, int cin);
+int om_conv2d_wino14_wide(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* u14_split,
+                          const float* scale_split, const float* shift, int cout, int leaky, const float* res,
+                          int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
+                          int32_t* status_dev, om_stream stream);
+int om_set_wino14_wide(int on);
+int om_get_wino14_wide(void);
 /* Which kernel runs that layer (process-wide; the outputs are bit-identical): 0 (default; environment OM_W14_VARIANT) the
  * twelve-wave kernel (conv_wino14.hip) everywhere; 1 the four-dual-role-wave kernel of round 5 (conv_wino14d.hip: one wave per
  * SIMD, accumulators owned by name) wherever it applies -- an even number >= 2 of 16-channel chunks, 16-byte aligned views.

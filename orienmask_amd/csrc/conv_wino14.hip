@@ -581,21 +581,96 @@ __global__ __launch_bounds__(W14_THREADS, 3) void wino14_split_kernel(const Wino
     }
 }
 
-#ifdef W14_BIG_PROBE
-#ifndef OM_MEASUREMENT_BUILD
-#error "W14_BIG_PROBE is a measurement kernel (wrong numerics): build it with tools/build_variant.sh only"
-#endif
-// ---- measurement only (round 6; round 4's probe of profiles/r04_w14_bigtile_probe.txt completed by what it left out): what a
-// CONSUMER-ONLY 128 x 128 tile costs when the transformed input V is not made in the workgroup but arrives like the weights do --
-// by LDS-DMA from a tensor some other kernel wrote (the producing 1x1 layer's epilogue, or a pre-pass) -- AND the epilogue runs.
-// Eight waves of 64 entries x 32 output channels x six planes (192 accumulators, two waves per SIMD); per 16-channel chunk 54 KiB
-// of V (six planes x 144 entries x 64 B, rows of Ct entries gathered from a [chunk][plane][padded row][tile column][64 B] layout:
-// whole lines) into the other V buffer, one plane per group, and 144 KiB of weights through a two-slot ring of 24-KiB groups.
-// V's BYTES are whatever the input tensor holds at those offsets (the caller allocates it 2x as large: tools/wino14_bench.py with
-// OM_W14_PROBE_INPUT=1), so the numerics are wrong by construction; requests, LDS traffic, matrix work and stores are the real ones.
-constexpr int W14B_UGRP = 2 * W14_UGRP;      // one plane's three kernel rows x 128 output channels
+// =================================================================================================================================
+// Round 6: the same layer as TWO kernels with a 128 x 128 tile -- for the layers whose input is small next to their weights (the
+// 512 -> 1024 layers at 1/32 scale).  What bounds the fused kernel above is its ingest and instruction count per matrix instruction
+// (DESIGN.md 3.9); the only tile with more products per ingested byte that HIP source can express is eight waves of 64 entries x 32
+// output channels x six planes (192 accumulators, two waves per SIMD), which leaves no registers for producer waves: the transformed
+// input V must be made elsewhere and arrive like the weights do, by LDS-DMA.  Measured with V's traffic and the real epilogue
+// (profiles/r06_w14_bigtile_probe.txt) that tile is 13-20 % faster than the fused kernel BEFORE V is paid for; a pre-pass that
+// writes V costs 2.5 x the layer's input through HBM, which only the 17^2 layers (18.9 MB of input for 87 GFLOP) can afford.
+//   wino14_v_kernel        V[c][j][G][t] = the fused kernel's producers' arithmetic (same formulas, same fused multiply-adds, same
+//                          hi/lo split), one 64-byte entry [8 hi | 8 hi | 8 lo | 8 lo] per (16-channel chunk c, plane j, padded row
+//                          G = b (H + 2) + y + 1, tile column t); rows outside the image are never written (the consumer reads them
+//                          as zero entries through its buffer descriptor)
+//   wino14_wide_kernel     per chunk: V's six planes x 144 entries (54 KiB, rows of Ct entries gathered: whole lines) into the other
+//                          V buffer, one plane per group; weights through a two-slot ring of 24-KiB groups (one plane's three kernel
+//                          rows x 128 output channels); 18 matrix instructions per wave and group; the fused kernel's epilogue on
+//                          both 32 x 32 sub-tiles of a wave.  Same products in the same order as the fused kernel: BIT-IDENTICAL
+//                          outputs (tests/test_hip_parity.py::test_wino14_wide_equals_fused).
+constexpr int W14B_UGRP = 2 * W14_UGRP;      // one plane's three kernel rows x 128 output channels: 24 KiB
+
+struct Wino14VParams {
+    const float* in;
+    _Float16* v;
+    int B, H, W, in_ps, in_bytes, nch, TW, gtot;
+    long long items;        // B * H * TW * nch * 2 (channel octets)
+};
+
+__device__ __forceinline__ f32x4 w14_point(const f32x4 (&d)[6], int j) {
+    const f32x4 c4 = 4.f, cm4 = -4.f, c2 = 2.f, cm2 = -2.f, cm5 = -5.f;
+    switch (j) {        // the producers' `point` (wino14_split_kernel), operation for operation
+        case 0: return __builtin_elementwise_fma(d[2], cm5, __builtin_elementwise_fma(d[0], c4, d[4]));
+        case 1: return __builtin_elementwise_fma(d[1] + d[2], cm4, d[3] + d[4]);
+        case 2: return __builtin_elementwise_fma(d[1] - d[2], c4, d[4] - d[3]);
+        case 3: return __builtin_elementwise_fma(d[3] - d[1], c2, d[4] - d[2]);
+        case 4: return __builtin_elementwise_fma(d[3] - d[1], cm2, d[4] - d[2]);
+        default: return __builtin_elementwise_fma(d[3], cm5, __builtin_elementwise_fma(d[1], c4, d[5]));
+    }
+}
+
+__global__ __launch_bounds__(256) void wino14_v_kernel(const Wino14VParams p) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= p.items) return;
+    // id = ((row * nch + c) * TW + t) * 2 + o: the two octets of an entry and neighbouring entries of a row are adjacent lanes
+    const int o = (int)(id & 1);
+    long long r = id >> 1;
+    const int t = (int)(r % p.TW); r /= p.TW;
+    const int c = (int)(r % p.nch); r /= p.nch;
+    const int b = (int)(r / p.H), y = (int)(r - (long long)b * p.H);
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    f32x4 d[2][6];
+#pragma unroll
+    for (int x = 0; x < 6; ++x) {
+        const int px = 4 * t - 1 + x;
+        const bool ok = (unsigned)px < (unsigned)p.W;
+        const int off = ok ? (((b * p.H + y) * p.W + px) * p.in_ps + 16 * c + 8 * o) * 4 : (int)0x80000000;
+        d[0][x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+        d[1][x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? off + 16 : off, 0, 0));
+    }
+    const long long G = (long long)b * (p.H + 2) + y + 1;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f16x8 h, l;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x4 v = w14_point(d[q], j);
+            const f16x4 hh = __builtin_convertvector(v, f16x4);
+            f32x4 rem;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rem[k] = __builtin_fmaf((float)hh[k], -1.0f, v[k]);      // exact: what v_fma_mix_f32 computes in the producers
+            const f16x4 ll = __builtin_convertvector(rem, f16x4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { h[4 * q + k] = hh[k]; l[4 * q + k] = ll[k]; }
+        }
+        _Float16* e = p.v + ((((long long)c * 6 + j) * p.gtot + G) * p.TW + t) * 32;
+        *reinterpret_cast<f16x8*>(e + 8 * o) = h;
+        *reinterpret_cast<f16x8*>(e + 16 + 8 * o) = l;
+    }
+}
+
+struct Wino14WideParams {
+    Wino14Params k;         // the fused kernel's parameters (epilogue, weights, geometry); k.in / k.in_bytes are not used
+    const _Float16* v;
+    int v_bytes, TW;
+};
+
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void wino14_big_probe_kernel(const Wino14Params p) {
+__global__ __launch_bounds__(512, 2) void wino14_wide_kernel(const Wino14WideParams pw) {
+    const Wino14Params& p = pw.k;
+    // two V buffers (chunk parity) + two weight slots of 24 KiB.  (Measured against it and not kept: ONE V buffer refilled plane by
+    // plane behind the group that read it + a four-slot weight ring requested three groups ahead -- bit-identical, 0.238 against
+    // 0.224-0.230 ms on 17^2 512 -> 1024: the weights' landing time is not what a group waits for.)
     __shared__ f32x4 smem[2 * W14_VBUF + 2 * W14B_UGRP + 1];
     f32x4* const s_u = smem + 2 * W14_VBUF;
     int* const s_ticket = reinterpret_cast<int*>(smem + 2 * W14_VBUF + 2 * W14B_UGRP);
@@ -605,10 +680,10 @@ __global__ __launch_bounds__(512, 2) void wino14_big_probe_kernel(const Wino14Pa
     const int fi = lane & 31, fk = lane >> 5;
     const int ngroups = 6 * p.nch;
     const int n_tiles2 = p.n_tiles >> 1, total2 = (p.total_tiles / p.n_tiles) * n_tiles2;
-    const int TW = (p.W + 3) / 4;
+    const int TW = pw.TW, hp2 = p.H + 2;
     const int ecount = (p.R + 2) * p.Ct;
     const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.u), 0, p.u_bytes, 0x00020000);
-    const auto rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    const auto rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(pw.v), 0, pw.v_bytes, 0x00020000);
     // weights: 24 pieces of 1 KiB per group: wave w requests pieces w, w + 8, w + 16 (0-11: the first 64-channel half, 12-23 the second)
     const int drow = lane >> 2, dcol = lane & 3;
     int dvo[3], dhalf[3];
@@ -617,7 +692,7 @@ __global__ __launch_bounds__(512, 2) void wino14_big_probe_kernel(const Wino14Pa
         const int piece = wave + 8 * i;
         dhalf[i] = piece >= 12;
         const int row = 16 * (piece - 12 * dhalf[i]) + drow;
-        dvo[i] = row * 64 + ((dcol ^ ((row >> 2) & 3)) * 16);
+        dvo[i] = row * 64 + ((dcol ^ ((row >> 2) & 3)) * 16);      // swizzle on the SOURCE chunk: the LDS image stays lane-linear
     }
     const int swB = (fi >> 2) & 3;
     const int brow = (wn4 >> 1) * (W14_UGRP) + (32 * (wn4 & 1) + fi) * 4;       // half, then row of the tap's 64 rows
@@ -642,7 +717,8 @@ __global__ __launch_bounds__(512, 2) void wino14_big_probe_kernel(const Wino14Pa
         }
     };
     // V: a plane of a chunk is 144 entries x 64 B = nine 1-KiB pieces; wave w requests piece w, wave 0 also piece 8.  Entry e of the
-    // block = padded row g0 - 1 + e / Ct, tile column t0 + e % Ct; a row of Ct entries is contiguous in the source.
+    // block = padded row g0 - 1 + e / Ct, tile column t0 + e % Ct; rows outside an image, columns beyond the row's tiles and entries
+    // beyond the block get an out-of-range offset: the DMA writes zeros (the fused kernel's zero entries).
     int vsrc[2];
     auto setup_v = [&](const Wino14Tile& tl) {
 #pragma unroll
@@ -650,8 +726,11 @@ __global__ __launch_bounds__(512, 2) void wino14_big_probe_kernel(const Wino14Pa
             const int e = 16 * (wave + 8 * i) + drow;
             const int rr = e / p.Ct, t = e - rr * p.Ct;
             const int sw = (e >> 2) & 3;
-            const bool ok = e < ecount && tl.g0 - 1 + rr >= 0 && tl.g0 - 1 + rr < p.gtot && tl.t0 + t < TW;
-            vsrc[i] = ok ? (((tl.g0 - 1 + rr) * TW + tl.t0 + t) * 64 + ((dcol ^ sw) * 16)) : (int)0x80000000;
+            const int g = tl.g0 - 1 + rr;
+            const int b = g / hp2;
+            const int y = g - b * hp2 - 1;
+            const bool ok = e < ecount && g >= 0 && g < p.gtot && y >= 0 && y < p.H && tl.t0 + t < TW;
+            vsrc[i] = ok ? ((g * TW + tl.t0 + t) * 64 + ((dcol ^ sw) * 16)) : (int)0x80000000;
         }
     };
     auto issue_v_plane = [&](int c, int pl, int vb) {       // plane pl of chunk c into V buffer vb
@@ -668,7 +747,7 @@ __global__ __launch_bounds__(512, 2) void wino14_big_probe_kernel(const Wino14Pa
         const int tile = __builtin_amdgcn_readfirstlane(s_ticket[0]);
         __syncthreads();            // (also: every wave is done with the previous tile's epilogue transposes in V buffer 1)
         if (tile >= total2) break;
-        const int tn2 = tile % n_tiles2, tm = tile / n_tiles2;
+        const int tn2 = tile % n_tiles2, tm = tile / n_tiles2;      // N fastest: the N-tile siblings read the same V block from L2
         Wino14Tile tl;
         tl.g0 = (tm / p.ncb) * p.R; tl.t0 = (tm % p.ncb) * p.Ct; tl.tile_n = 2 * tn2 + (wn4 >> 1); tl.n0 = tl.tile_n * W14_BN;
         setup_v(tl);
@@ -690,8 +769,8 @@ __global__ __launch_bounds__(512, 2) void wino14_big_probe_kernel(const Wino14Pa
                 constexpr int j = decltype(jc)::value;
                 constexpr int pl = w14_plane(j);
                 const int slot = g & 1;
-                issue_group(tn2, g + 1);
-                issue_v_plane(c + 1, pl, (c & 1) ^ 1);
+                issue_group(tn2, g + 1);                    // the other slot: every wave left group g - 1 at the barrier just passed
+                issue_v_plane(c + 1, pl, (c & 1) ^ 1);      // the other V buffer: chunk c - 1 is done with
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const f32x4 bh = s_u[slot * W14B_UGRP + ky * (W14_BN * 4) + boff_hi];
@@ -702,12 +781,13 @@ __global__ __launch_bounds__(512, 2) void wino14_big_probe_kernel(const Wino14Pa
                         const f32x4 al = sV[pl * W14_VPLANE + aoff_lo[ky] + 128 * b];
                         const f16x8 ahh = __builtin_bit_cast(f16x8, ah), all = __builtin_bit_cast(f16x8, al);
                         const f16x8 bhh = __builtin_bit_cast(f16x8, bh), bll = __builtin_bit_cast(f16x8, bl);
+                        // the fused kernel's three products in its order: bit-identical sums
                         acc[b][pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhh, all, acc[b][pl], 0, 0, 0);
                         acc[b][pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bll, ahh, acc[b][pl], 0, 0, 0);
                         acc[b][pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhh, ahh, acc[b][pl], 0, 0, 0);
                     }
                 }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the next group's weights and this group's V plane
                 __builtin_amdgcn_s_barrier();
                 ++g;
             };
@@ -718,12 +798,11 @@ __global__ __launch_bounds__(512, 2) void wino14_big_probe_kernel(const Wino14Pa
             group(std::integral_constant<int, 4>{});
             group(std::integral_constant<int, 5>{});
         }
-        // the real epilogue, once per 32 x 32 sub-tile of the wave (entries 64 wm2 + 32 b ..)
+        // the fused kernel's epilogue, once per 32 x 32 sub-tile of the wave (entries 64 wm2 + 32 b ..)
         wino14_epilogue<MODE>(p, acc[0], tl, smem + W14_VBUF + wave * 256, 2 * wm2, wn4 & 1, lane, [] {});
         wino14_epilogue<MODE>(p, acc[1], tl, smem + W14_VBUF + wave * 256, 2 * wm2 + 1, wn4 & 1, lane, [] {});
     }
 }
-#endif
 
 // Block shape for a layer: Ct tile columns (a divisor-like split of ceil(W / 4)) x R padded rows with R * Ct <= 128 and
 // (R + 2) * Ct <= 160, picked for the largest share of useful rows in the 128-row matrix tile.
@@ -758,8 +837,8 @@ void wino14_set_variant(int v) { g_w14_variant = v; }
 
 size_t wino14_weight_halfs(int cout_pad, int cin) { return (size_t)18 * cout_pad * cin * 2; }
 
-// a.w: the packed F(4,3) weights (include/orienmask_hip.h: om_layer_info.wsplit_off for wino layers); a.scale: scale * 2^-e
-int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream) {
+// the fused kernel's parameters from a layer's arguments (shared by the two-kernel wide form)
+static int wino14_fill_params(const ConvArgs& a, Wino14Params& p) {
     OM_REQUIRE(a.in && a.w && a.scale && a.shift && a.out && a.ticket, OM_EINVAL, "wino14: null pointer");
     OM_REQUIRE(a.ks == 3 && a.stride == 1 && a.out_mode == 0, OM_EINVAL, "wino14: 3x3 stride-1 NHWC layers only");
     OM_REQUIRE(a.cin % 16 == 0 && a.cin >= 16 && a.cout_pad % 64 == 0, OM_EINVAL, "wino14: cin=%d cout_pad=%d", a.cin, a.cout_pad);
@@ -768,7 +847,6 @@ int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream) {
                OM_EINVAL, "wino14: operands must be 16-byte aligned");
     const long long in_bytes = ((long long)a.B * a.H * a.W - 1) * a.in_pix_stride * 4 + (long long)a.cin * 4;
     OM_REQUIRE(in_bytes < 0x7FFFFFF0ll, OM_EINVAL, "wino14: input view of %lld bytes exceeds a buffer descriptor", in_bytes);
-    Wino14Params p;
     p.in = a.in; p.u = reinterpret_cast<const _Float16*>(a.w); p.scale = a.scale; p.shift = a.shift; p.res = a.res; p.out = a.out;
     p.ticket = a.ticket; p.status = a.status;
     p.B = a.B; p.H = a.H; p.W = a.W; p.in_ps = a.in_pix_stride; p.in_bytes = (int)in_bytes;
@@ -800,6 +878,14 @@ int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream) {
     p.trace = g_w14_trace;
     OM_REQUIRE(p.trace, OM_EINVAL, "wino14 trace build: om_debug_w14_trace() first");
 #endif
+    return OM_OK;
+}
+
+// a.w: the packed F(4,3) weights (include/orienmask_hip.h: om_layer_info.wsplit_off for wino layers); a.scale: scale * 2^-e
+int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream) {
+    Wino14Params p;
+    if (int rc = wino14_fill_params(a, p)) return rc;
+    const long long total = p.total_tiles;
     // round 5: the four-dual-role-wave form (conv_wino14d.hip) on request only (om_set_wino14_variant(1) / OM_W14_VARIANT=1): bit-identical,
     // but measured 8-25 % slower than this file's twelve-wave kernel on every layer shape (profiles/r05_experiments.md 1).  Since round 6
     // it is only in libraries built with `make W14D=1` (the default library holds no kernel the forward cannot reach).
@@ -807,17 +893,53 @@ int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream) {
     if (wino14_variant() == 1 && wino14_dual_supported(p)) return launch_wino14_dual(p, a.res != nullptr, stream);
 #endif
     const long long grid = total < 256 ? total : 256;        // one 768-thread workgroup per CU (156 KiB of LDS)
-#ifdef W14_BIG_PROBE
-    if (p.n_tiles % 2 == 0 && p.fast_io) {
-        if (a.res) hipLaunchKernelGGL(wino14_big_probe_kernel<1>, dim3(256), dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL(wino14_big_probe_kernel<0>, dim3(256), dim3(512), 0, stream, p);
-        OM_CHECK_HIP(hipGetLastError());
-        return OM_OK;
-    }
-#endif
     if (!p.fast_io) hipLaunchKernelGGL(wino14_split_kernel<2>, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);
     else if (a.res) hipLaunchKernelGGL(wino14_split_kernel<1>, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);
     else hipLaunchKernelGGL(wino14_split_kernel<0>, dim3((unsigned)grid), dim3(W14_THREADS), 0, stream, p);
+    OM_CHECK_HIP(hipGetLastError());
+    return OM_OK;
+}
+
+// ---- the two-kernel wide form (wino14_v_kernel + wino14_wide_kernel)
+// floats of scratch for V: [cin / 16][6][B (H + 2)][ceil(W / 4)] entries of 64 bytes
+size_t wino14_wide_scratch_floats(int B, int H, int W, int cin) {
+    return (size_t)(cin / 16) * 6 * B * (H + 2) * ((W + 3) / 4) * 16;
+}
+
+// can this layer run it?  Whole pairs of 64-channel N tiles, the epilogue's buffer-descriptor form, V below 2 GiB.
+bool wino14_wide_supported(const ConvArgs& a) {
+    if (a.ks != 3 || a.stride != 1 || a.out_mode != 0 || a.cin % 16 || a.cout_pad % 128 || a.cout % 4 || a.out_pix_stride % 4) return false;
+    if ((reinterpret_cast<uintptr_t>(a.out) & 15) || (a.res && ((a.res_pix_stride % 4) || (reinterpret_cast<uintptr_t>(a.res) & 15)))) return false;
+    return wino14_wide_scratch_floats(a.B, a.H, a.W, a.cin) * 4 < 0x7FFFFFF0ull;
+}
+
+// which layers take it (om_forward's choice; the unit entry om_conv2d_wino14_wide runs it on any supported layer): the pre-pass moves
+// 2.5 x the layer's input through HBM, the wide tile saves 13-20 % of the fused kernel's time -- it pays where the input is small next
+// to the layer's work, i.e. from 512 input channels on (the 512 -> 1024 layers at 1/32 scale: 47 MB of pre-pass traffic for 87 GFLOP;
+// profiles/r06_experiments.md section 1)
+bool wino14_wide_pays(const ConvArgs& a) { return a.cin >= 512 && wino14_wide_supported(a); }
+
+int launch_conv_wino14_wide(const ConvArgs& a, float* scratch, hipStream_t stream) {
+    OM_REQUIRE(scratch && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0, OM_EINVAL, "wino14 wide: scratch must be 16-byte aligned");
+    OM_REQUIRE(wino14_wide_supported(a), OM_EINVAL, "wino14 wide: cout_pad=%d must be a multiple of 128 and the views 16-byte aligned", a.cout_pad);
+    Wino14WideParams pw;
+    if (int rc = wino14_fill_params(a, pw.k)) return rc;
+    OM_REQUIRE(pw.k.fast_io && pw.k.n_tiles % 2 == 0, OM_EINVAL, "wino14 wide: views not in the epilogue's buffer-descriptor form");
+    const int TW = (a.W + 3) / 4;
+    pw.TW = TW;
+    pw.v = reinterpret_cast<const _Float16*>(scratch);
+    pw.v_bytes = (int)(wino14_wide_scratch_floats(a.B, a.H, a.W, a.cin) * 4);
+    Wino14VParams pv;
+    pv.in = a.in; pv.v = reinterpret_cast<_Float16*>(scratch);
+    pv.B = a.B; pv.H = a.H; pv.W = a.W; pv.in_ps = a.in_pix_stride; pv.in_bytes = pw.k.in_bytes; pv.nch = pw.k.nch; pv.TW = TW; pv.gtot = pw.k.gtot;
+    pv.items = (long long)a.B * a.H * TW * pv.nch * 2;
+    hipLaunchKernelGGL(wino14_v_kernel, dim3((unsigned)((pv.items + 255) / 256)), dim3(256), 0, stream, pv);
+    OM_CHECK_HIP(hipGetLastError());
+    if (a.mid_event) OM_CHECK_HIP(hipEventRecord(a.mid_event, stream));      // profiling: pre-pass | wide kernel
+    const long long total2 = (long long)(pw.k.total_tiles / pw.k.n_tiles) * (pw.k.n_tiles / 2);
+    const unsigned grid = (unsigned)(total2 < 256 ? total2 : 256);
+    if (a.res) hipLaunchKernelGGL(wino14_wide_kernel<1>, dim3(grid), dim3(512), 0, stream, pw);
+    else hipLaunchKernelGGL(wino14_wide_kernel<0>, dim3(grid), dim3(512), 0, stream, pw);
     OM_CHECK_HIP(hipGetLastError());
     return OM_OK;
 }

@@ -121,6 +121,12 @@ int launch_conv_winograd24(const ConvArgs& a, float* scratch, hipStream_t stream
 size_t wino24_scratch_floats(int B, int H, int W, int C);
 // fused F(4,3)-along-the-rows form with split operands (conv_wino14.hip): a.w = packed hi/lo weights [n_tiles][cin/16][6][3][64][32]
 int launch_conv_wino14_split(const ConvArgs& a, hipStream_t stream);
+// the same layer as two kernels with a 128 x 128 tile (conv_wino14.hip, round 6): V = the transformed input, written by a pre-pass into
+// `scratch` (wino14_wide_scratch_floats floats), read by LDS-DMA; bit-identical to the fused kernel
+size_t wino14_wide_scratch_floats(int B, int H, int W, int cin);
+bool wino14_wide_supported(const ConvArgs& a);
+bool wino14_wide_pays(const ConvArgs& a);
+int launch_conv_wino14_wide(const ConvArgs& a, float* scratch, hipStream_t stream);
 // backbone.conv1 + backbone.conv2.0 as one kernel with split operands (conv_stem2.hip): image NCHW -> conv2.0's NHWC output
 // conv1 + conv2.0 of the fp16-activation configuration as one kernel (conv_stem2.hip: conv_stem2_f16_kernel)
 int launch_conv_stem2_f16(const float* in_nchw, int B, int H, int W, const float* w1, const float* scale1, const float* shift1,

@@ -63,6 +63,18 @@ struct LayerDef {
 
 }  // namespace om
 
+// process-wide A/B switch (default on; om_set_wino14_wide, or OM_NO_W14_WIDE=1 in the environment read once): om_forward runs the
+// stride-1 3x3 layers with at least 512 input channels of precision mode 1 in the two-kernel wide form (conv_wino14.hip:
+// wino14_v_kernel + wino14_wide_kernel); off: the fused kernel everywhere.  Bit-identical either way.
+static int g_wino14_wide = -1;
+static bool wino14_wide_on() {
+    if (g_wino14_wide < 0) {
+        const char* e = std::getenv("OM_NO_W14_WIDE");
+        g_wino14_wide = (e && e[0] == '1') ? 0 : 1;
+    }
+    return g_wino14_wide != 0;
+}
+
 struct om_model {
     int num_anchors = 0, num_classes = 0;
     int variant = 0;     // 0: OrienMaskYOLOFPNPlus, 1: OrienMaskYOLO (single route8 into a 192-channel neck4)
@@ -412,9 +424,25 @@ struct om_model {
     };
     bool keep_all = false;
 
+    // split-operand mode: the layers that run the two-kernel wide form of the fused 3x3 kernel (conv_wino14.hip, round 6): from 512
+    // input channels on (where the pre-pass's 2.5 x the input through HBM is small next to the layer's work), whole pairs of N tiles
+    // ... and only where the fused kernel's 128 x 64 tiles outnumber the CUs: while ONE round of them covers the layer, a round of half
+    // as many 128 x 128 tiles takes longer (17^2 512 -> 1024: 0.14 against 0.21 ms per round; at bs = 32 the fused kernel needs 1.56
+    // rounds = 0.26-0.28 ms, the wide form one round + the pre-pass = 0.22-0.23 ms)
+    bool wide_3x3_layer(const om::LayerDef& L, int B, int H, int W) const {
+        if (!(precision == 1 && wino14_wide_on() && L.info.wino_off >= 0 && L.info.wino_planes == 24 && L.info.ksize == 3 &&
+              L.info.stride == 1 && L.out_mode == 0 && L.info.cin >= 512 && L.info.cout_pad % 128 == 0 && L.info.cout % 4 == 0) ||
+            direct_3x3_layer(L, B, H, W))
+            return false;
+        int R = 0, Ct = 0, ncb = 0, nrb = 0;
+        om::wino14_geometry(B, H / L.in_div, W / L.in_div, &R, &Ct, &ncb, &nrb);
+        return (long long)nrb * ncb * (L.info.cout_pad / 64) > 256;
+    }
+
     size_t layer_scratch_floats(const om::LayerDef& L, int B, int H, int W) const {
         if (L.info.wino_off < 0) return 0;
-        if (precision == 1 && L.info.wino_planes == 24) return 0;      // conv_wino14.hip transforms its input on chip
+        if (precision == 1 && L.info.wino_planes == 24)      // conv_wino14.hip transforms its input on chip, but for the wide form's V
+            return wide_3x3_layer(L, B, H, W) ? om::wino14_wide_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin) : 0;
         return (L.info.wino_planes == 24 && use_f24(B, H, W)) ? om::wino24_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin)
                                                                : om::wino_scratch_floats(B, H / L.in_div, W / L.in_div, L.info.cin);
     }
@@ -814,8 +842,12 @@ static int forward_impl(om_model* m, const float* x, int B, int H, int W, float*
                     a.w = m->weights_split + li.wsplit_off;
                     a.scale = m->weights_split + li.wsplit_scale_off;
                     a.split = 1;
-                    if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
-                    rc = om::launch_conv_wino14_split(a, stream);
+                    if (m->wide_3x3_layer(L, B, H, W) && om::wino14_wide_supported(a)) {
+                        rc = om::launch_conv_wino14_wide(a, wino_scratch, stream);      // (records ev_mid between its two kernels)
+                    } else {
+                        if (ev_mid) OM_CHECK_HIP(hipEventRecord(ev_mid, stream));
+                        rc = om::launch_conv_wino14_split(a, stream);
+                    }
                 } else if (li.wino_planes == 24 && m->use_f24(B, H, W)) {
                     a.w = m->weights + li.wino_off;
                     rc = om::launch_conv_winograd24(a, wino_scratch, stream);
@@ -999,6 +1031,7 @@ int om_layer_tile(const om_model* m, int index, int B, int H, int W, int* bm, in
         return OM_OK;
     }
     if (L.info.wino_off >= 0 && om::wino_enabled() && L.info.wino_planes == 24 && m->precision == 1) {
+        if (m->wide_3x3_layer(L, B, H, W)) { *algo = 12; *bm = 128; *bn = 128; return OM_OK; }      // two kernels: V pre-pass + 128 x 128 tile
         *algo = 8; *bm = 128; *bn = 64;
         return OM_OK;
     }
@@ -1287,6 +1320,38 @@ int om_conv2d_wino14_split(const float* in, int B, int H, int W, int cin, int in
     a.ticket = g_ticket;
     return om::launch_conv_wino14_split(a, static_cast<hipStream_t>(stream));
 }
+
+size_t om_conv2d_wino14_wide_scratch_bytes(int B, int H, int W, int cin) {
+    if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cin % 16) return 0;
+    return om::align_up(om::wino14_wide_scratch_floats(B, H, W, cin) * sizeof(float), 256);
+}
+
+int om_conv2d_wino14_wide(const float* in, int B, int H, int W, int cin, int in_pix_stride, const void* u14_split,
+                          const float* scale_split, const float* shift, int cout, int leaky, const float* res,
+                          int res_pix_stride, float* out, int out_pix_stride, void* scratch, size_t scratch_bytes,
+                          int32_t* status_dev, om_stream stream) {
+    OM_REQUIRE(B > 0 && H > 0 && W > 0, OM_EINVAL, "om_conv2d_wino14_wide: bad shape");
+    OM_REQUIRE(scratch && scratch_bytes >= om_conv2d_wino14_wide_scratch_bytes(B, H, W, cin), OM_ENOMEM,
+               "om_conv2d_wino14_wide: scratch too small");
+    om::ConvArgs a;
+    a.in = in; a.w = static_cast<const float*>(u14_split); a.scale = scale_split; a.shift = shift; a.res = res; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.cin = cin; a.in_pix_stride = in_pix_stride;
+    a.Ho = H; a.Wo = W; a.cout = cout; a.cout_pad = om::round_up(cout, 64);
+    a.ks = 3; a.stride = 1; a.leaky = leaky; a.res_pix_stride = res_pix_stride;
+    a.out_pix_stride = out_pix_stride; a.out_mode = 0; a.up = 1; a.split = 1; a.status = status_dev;
+    static int* g_ticket = nullptr;      // unit-test entry only (see om_conv2d_mode)
+    if (!g_ticket) OM_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_ticket), om::SYNC_WORDS * sizeof(int)));
+    if (int rc = om::launch_zero_words(g_ticket, om::SYNC_WORDS, static_cast<hipStream_t>(stream))) return rc;
+    a.ticket = g_ticket;
+    return om::launch_conv_wino14_wide(a, static_cast<float*>(scratch), static_cast<hipStream_t>(stream));
+}
+
+int om_set_wino14_wide(int on) {
+    OM_REQUIRE(on == 0 || on == 1, OM_EINVAL, "om_set_wino14_wide: %d", on);
+    g_wino14_wide = on;
+    return OM_OK;
+}
+int om_get_wino14_wide(void) { return wino14_wide_on() ? 1 : 0; }
 
 int om_wino14_dual_built(void) {
 #ifdef OM_WITH_W14D

@@ -82,6 +82,10 @@ SIGNATURES = {
     "om_get_conv3x3_f16_variant": (_i, []),
     "om_set_conv3x3_f16_variant": (_i, [_i]),
     "om_conv2d_wino14_split": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "om_conv2d_wino14_wide_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "om_conv2d_wino14_wide": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp, _vp]),
+    "om_set_wino14_wide": (_i, [_i]),
+    "om_get_wino14_wide": (_i, []),
     "om_forward_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "om_forward_status_offset": (_sz, [_vp, _i, _i, _i]),
     "om_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -465,7 +465,7 @@ class OrienMaskYOLOFPNPlus(nn.Module):
                    3: "wino_fused_kernel<%d,%d>", 5: "wino24_gemm_kernel<%d,%d>", 6: "wino24_gemm_kernel<%d,%d,split>",
                    7: "conv_igemm_split_kernel<%d,%d>", 8: "wino14_split_kernel<%d,%d>",
                    9: "conv_stem2_split_kernel<%d,%d>", 10: "(in the previous layer's kernel)",
-                   11: "conv_igemm_split_kernel<%d,%d,gather>"}[algo.value]
+                   11: "conv_igemm_split_kernel<%d,%d,gather>", 12: "wino14_wide_kernel<%d,%d>"}[algo.value]
             out.append((l["name"], fmt % ((bm.value, bn.value) if algo.value not in (0, 10) else ())))
         return out
 

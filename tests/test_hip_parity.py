@@ -806,6 +806,107 @@ def test_wino14_dual_equals_twelve_wave(dev, case):
     assert err < 5e-6, (case, err)
 
 
+WINO14_WIDE_CASES = [
+    # B, H, W, cin, cout, leaky, residual
+    (3, 17, 17, 512, 1024, 1, True),     # the layers om_forward runs this way (conv6.*.conv.1: residual; blocks span images)
+    (2, 17, 17, 512, 1024, 1, False),    # neck32.1 / neck32.3 / bbox_head32.0
+    (2, 10, 13, 64, 128, 1, True),       # W not a multiple of 4, one pair of N tiles, four chunks
+    (1, 34, 34, 32, 256, 0, False),      # 9 tile columns, two chunks, no activation
+    (5, 6, 7, 16, 384, 1, True),         # ONE chunk (nothing to prefetch), three pairs of N tiles, tiny images
+    (2, 40, 72, 48, 128, 1, False),      # two column blocks per row (18 tile columns), an odd number of chunks
+]
+
+
+@pytest.mark.parametrize("case", WINO14_WIDE_CASES)
+def test_wino14_wide_equals_fused(dev, case):
+    """The two-kernel wide form of the stride-1 3x3 layer (round 6, conv_wino14.hip: wino14_v_kernel writes the transformed input,
+    wino14_wide_kernel multiplies 128 x 128 tiles reading it by LDS-DMA) against the fused kernel on the same inputs: the same
+    products in the same order, so BIT-IDENTICAL outputs -- twice in a row (nothing depends on what LDS or the scratch held), with
+    the scratch poisoned in between; the fused kernel itself is held to the float64 convolution by
+    test_wino14_split_layer_matches_torch (/root/reference/model/base.py:104-137)."""
+    from orienmask_amd.pack import winograd14_weights_split
+    B, H, W, cin, cout, leaky, use_res = case
+    L = omlib.load()
+    g = torch.Generator().manual_seed(sum(case) + 17)
+    x = torch.randn(B, H, W, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.2
+    res = torch.randn(B, H, W, cout, generator=g) if use_res else None
+    us, e = winograd14_weights_split(w, cout)
+    sps = (scale.double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), -e.double()[:cout])).float().to(dev)
+    hd, ud, xd = shift.to(dev), us.to(dev), x.to(dev)
+    rd = res.to(dev) if use_res else None
+    nbytes = L.om_conv2d_wino14_wide_scratch_bytes(B, H, W, cin)
+    assert nbytes >= (cin // 16) * 6 * B * (H + 2) * ((W + 3) // 4) * 64
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    st = omlib.current_stream_ptr(dev)
+
+    def run(wide):
+        out = torch.full((B, H, W, cout), float("nan"), device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        if wide:
+            rc = L.om_conv2d_wino14_wide(_p(xd), B, H, W, cin, cin, _p(ud), _p(sps), _p(hd), cout, leaky, _p(rd) if use_res else None,
+                                         cout if use_res else 0, _p(out), cout, _p(scratch), nbytes, _p(status), st)
+        else:
+            rc = L.om_conv2d_wino14_split(_p(xd), B, H, W, cin, cin, _p(ud), _p(sps), _p(hd), cout, leaky, _p(rd) if use_res else None,
+                                          cout if use_res else 0, _p(out), cout, _p(status), st)
+        omlib.check(rc, "wino14 wide" if wide else "wino14 fused")
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        return out.cpu()
+
+    ref = run(False)
+    assert torch.isfinite(ref).all()
+    scratch.fill_(0xFF)                  # NaN halves wherever the pre-pass does not write and the consumer still reads
+    a = run(True)
+    scratch.fill_(0x7C)                  # +inf halves
+    b = run(True)
+    assert torch.equal(a, ref), (case, (a - ref).abs().max())
+    assert torch.equal(b, ref), case
+    # what it refuses, it refuses loudly: a single 64-channel N tile, a scratch that is too small
+    out = torch.empty(B, H, W, 64, device=dev)
+    assert L.om_conv2d_wino14_wide(_p(xd), B, H, W, cin, cin, _p(ud), _p(sps), _p(hd), 64, leaky, None, 0, _p(out), 64, _p(scratch), nbytes,
+                                   None, st) != 0
+    assert L.om_conv2d_wino14_wide(_p(xd), B, H, W, cin, cin, _p(ud), _p(sps), _p(hd), cout, leaky, None, 0, _p(ref.to(dev)), cout,
+                                   _p(scratch), nbytes - 256, None, st) != 0
+
+
+def test_forward_wide_3x3_switch_is_bit_identical(dev):
+    """om_forward runs the stride-1 3x3 layers with at least 512 input channels (the 1/32-scale ones) in the two-kernel wide form
+    (om_set_wino14_wide, default on): the layer table says so, the workspace grows by their transformed input, and all six head
+    tensors are bit-identical to a forward with the switch off; the previous setting is restored."""
+    L = omlib.load()
+    sd = synth.synth_state_dict(13, obj_bias=-16.0, head_gain=4.0)
+    # 140 strips of 32 x 544: 140 x 3 padded rows of 5 tile columns at 1/32 scale = 17 row blocks x 16 N tiles = 272 tiles of the fused
+    # kernel -- more than the 256 CUs, which is where om_forward switches (a batch of 3 such images stays with the fused kernel)
+    x = synth.synth_image_batch(34, 140, 32, 544).to(dev)
+    net = _hip_model(sd, dev, "f32_split")
+    was = L.om_get_wino14_wide()
+    try:
+        omlib.check(L.om_set_wino14_wide(1), "om_set_wino14_wide")
+        assert not any(v.startswith("wino14_wide_kernel") for _, v in net.layer_kernels(3, 32, 544))
+        k_on = dict(net.layer_kernels(140, 32, 544))
+        with torch.no_grad():
+            pred = net(x)
+            on = [(b.clone(), o.clone()) for b, o in pred]
+        assert pred.flags() == 0
+        omlib.check(L.om_set_wino14_wide(0), "om_set_wino14_wide")
+        net._workspace.clear(); net._slot_workspaces.clear()          # the layout differs (no V scratch)
+        k_off = dict(net.layer_kernels(140, 32, 544))
+        with torch.no_grad():
+            off = net(x)
+        for (a, b_), (c, d) in zip(on, off):
+            assert torch.equal(a, c) and torch.equal(b_, d)
+    finally:
+        L.om_set_wino14_wide(was)
+        net._workspace.clear(); net._slot_workspaces.clear()
+    wide = sorted(k for k, v in k_on.items() if v.startswith("wino14_wide_kernel"))
+    assert wide == sorted(["backbone.conv6.%d.conv.1" % i for i in range(1, 5)] + ["neck32.1", "neck32.3", "bbox_head32.0"]), wide
+    assert all(k_off[k].startswith("wino14_split_kernel") for k in wide)
+    assert k_on["backbone.conv5.3.conv.1"].startswith("wino14_split_kernel")       # 256 input channels: the fused kernel
+
+
 @pytest.mark.parametrize("gain,finite", [(100.0, True), (3.0e4, False)])
 def test_split_operand_range(dev, gain, finite):
     """The documented range of split operands (include/orienmask_hip.h: om_model_set_precision): activations 100x larger than a

@@ -48,8 +48,29 @@ def main():
         def run24():
             omlib.check(L.om_conv2d_winograd24_split(p(x), B, hw, hw, cin, cin, p(u24), p(s24), p(hd), cout, 1, None, 0, p(out), cout,
                                                      p(scratch), scratch.numel(), None, st), "w24")
+        wide_ok = cout % 128 == 0
+        nb = L.om_conv2d_wino14_wide_scratch_bytes(B, hw, hw, cin)
+        vscratch = torch.empty(nb if wide_ok else 16, dtype=torch.uint8, device=dev)
+
+        def run14_wide():       # the two-kernel wide form (round 6): V pre-pass + 128 x 128 tiles
+            omlib.check(L.om_conv2d_wino14_wide(p(x), B, hw, hw, cin, ps, p(u14), p(s14), p(hd), cout, 1, None, 0, p(out), cout, p(vscratch), nb, None, st), "w14 wide")
         res = []
         dual = bool(L.om_wino14_dual_built())       # only in libraries built with W14D=1
+        if os.environ.get("OM_W14_WIDE"):           # first column: the wide form instead of the dual-role kernel
+            for fn in ((run14_wide if wide_ok else run14), run14):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(10):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                res.append(a.elapsed_time(b) / 10)
+            print("%3dx%-3d %4d->%-4d x%2d  two-kernel wide form %.3f ms   fused twelve-wave %.3f ms" % (hw, hw, cin, cout, n, res[0], res[1]), flush=True)
+            tot14 += n * res[0]; tot12 += n * res[1]
+            continue
         for fn in ((run14_dual if dual else run14), run24, run14):
             for _ in range(3):
                 fn()
