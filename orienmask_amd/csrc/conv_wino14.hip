@@ -773,14 +773,22 @@ __global__ __launch_bounds__(512, 2) void wino14_wide_kernel(const Wino14WidePar
                 issue_v_plane(c + 1, pl, (c & 1) ^ 1);      // the other V buffer: chunk c - 1 is done with
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    const f32x4 bh = s_u[slot * W14B_UGRP + ky * (W14_BN * 4) + boff_hi];
-                    const f32x4 bl = s_u[slot * W14B_UGRP + ky * (W14_BN * 4) + boff_lo];
+                    // all six fragments of the step, ONE wait, six matrix instructions back to back (left to itself the compiler --
+                    // out of registers beside 192 accumulators -- reads a fragment, waits, multiplies, reads the next: an LDS round
+                    // trip in front of every one or two matrix instructions); the other wave of the SIMD multiplies meanwhile
+                    f32x4 fr[6];
+                    fr[0] = s_u[slot * W14B_UGRP + ky * (W14_BN * 4) + boff_hi];
+                    fr[1] = s_u[slot * W14B_UGRP + ky * (W14_BN * 4) + boff_lo];
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
-                        const f32x4 ah = sV[pl * W14_VPLANE + aoff_hi[ky] + 128 * b];
-                        const f32x4 al = sV[pl * W14_VPLANE + aoff_lo[ky] + 128 * b];
-                        const f16x8 ahh = __builtin_bit_cast(f16x8, ah), all = __builtin_bit_cast(f16x8, al);
-                        const f16x8 bhh = __builtin_bit_cast(f16x8, bh), bll = __builtin_bit_cast(f16x8, bl);
+                        fr[2 + 2 * b] = sV[pl * W14_VPLANE + aoff_hi[ky] + 128 * b];
+                        fr[3 + 2 * b] = sV[pl * W14_VPLANE + aoff_lo[ky] + 128 * b];
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[0]), "+v"(fr[1]), "+v"(fr[2]), "+v"(fr[3]), "+v"(fr[4]), "+v"(fr[5])::"memory");
+                    const f16x8 bhh = __builtin_bit_cast(f16x8, fr[0]), bll = __builtin_bit_cast(f16x8, fr[1]);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const f16x8 ahh = __builtin_bit_cast(f16x8, fr[2 + 2 * b]), all = __builtin_bit_cast(f16x8, fr[3 + 2 * b]);
                         // the fused kernel's three products in its order: bit-identical sums
                         acc[b][pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhh, all, acc[b][pl], 0, 0, 0);
                         acc[b][pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bll, ahh, acc[b][pl], 0, 0, 0);
