@@ -806,8 +806,28 @@ __global__ __launch_bounds__(512, 2) void wino14_wide_kernel(const Wino14WidePar
             group(std::integral_constant<int, 4>{});
             group(std::integral_constant<int, 5>{});
         }
-        // the fused kernel's epilogue, once per 32 x 32 sub-tile of the wave (entries 64 wm2 + 32 b ..)
+        // the fused kernel's epilogue, once per 32 x 32 sub-tile of the wave (entries 64 wm2 + 32 b ..).  With a residual the first
+        // call needs ~70 registers beside the 96 accumulators it reads, and the other sub-tile's 96 are still live: the compiler spilled
+        // 12-14 of them to scratch -- loads and stores in the one in-order counter the epilogue is built around (+0.024 ms per layer,
+        // profiles/r06_experiments.md section 1).  Two planes of the second sub-tile wait in LDS instead (every operand area is dead
+        // since the last group's barrier: V buffer 0 for waves 0-5, the weight slots for waves 6-7; lane-linear, 8 KiB per wave).
+        f32x4* const park = (wave < 6 ? smem + wave * 512 : s_u + (wave - 6) * 512) + lane;
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                park[(q) * 64] = f32x4{acc[1][4][4 * q], acc[1][4][4 * q + 1], acc[1][4][4 * q + 2], acc[1][4][4 * q + 3]};
+                park[(4 + q) * 64] = f32x4{acc[1][5][4 * q], acc[1][5][4 * q + 1], acc[1][5][4 * q + 2], acc[1][5][4 * q + 3]};
+            }
+        }
         wino14_epilogue<MODE>(p, acc[0], tl, smem + W14_VBUF + wave * 256, 2 * wm2, wn4 & 1, lane, [] {});
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a4 = park[(q) * 64], a5 = park[(4 + q) * 64];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { acc[1][4][4 * q + k] = a4[k]; acc[1][5][4 * q + k] = a5[k]; }
+            }
+        }
         wino14_epilogue<MODE>(p, acc[1], tl, smem + W14_VBUF + wave * 256, 2 * wm2 + 1, wn4 & 1, lane, [] {});
     }
 }
