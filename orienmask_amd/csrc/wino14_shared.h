@@ -18,7 +18,8 @@ typedef unsigned u32x4v __attribute__((__vector_size__(4 * sizeof(unsigned))));
 
 #ifndef OM_W14_ABLATE
 #define OM_W14_ABLATE 0        // measurement builds only (wrong numerics): 2 no fragment reads, 4 no per-group barrier, 8 no weight
-#endif                         // DMA, 16 no input loads / transform, 32 no epilogue stores, 1024 no matrix instructions
+#endif                         // DMA, 16 no input loads / transform, 32 no epilogue stores, 1024 no matrix instructions, 262144 the
+                               // input read at a channel-chunk-major layout's addresses (round 6, profiles/r06_experiments.md 1)
 #ifndef OM_W14_TRACE
 #define OM_W14_TRACE 0         // measurement builds only: s_memtime stamps of one tile's groups (tools/wino14_trace.py)
 #endif
