@@ -1839,6 +1839,26 @@ def test_graphed_pipeline_matches_eager(dev, batch, prec):
             pipe(xs[0])
 
 
+def test_graphed_pipeline_with_the_wide_3x3_form(dev):
+    """The two-kernel wide form of the 1/32-scale 3x3 layers (round 6: a pre-pass + a consumer kernel per layer, its transformed
+    input in a per-layer scratch of the workspace) inside a captured hipGraph: 140 strips of 32 x 544 (enough tiles for om_forward to
+    choose the form) replayed twice on fresh inputs == the eager call sequence of a second model instance, bit for bit."""
+    from orienmask_amd.graph import GraphedPipeline
+    sd = synth.synth_state_dict(3, obj_bias=-16.0, head_gain=4.0)
+    net, net_ref = _hip_model(sd, dev, "f32_split"), _hip_model(sd, dev, "f32_split")
+    assert any(v.startswith("wino14_wide_kernel") for _, v in net.layer_kernels(140, 32, 544))
+    post, post_ref = _hip_post((32, 544), dev), _hip_post((32, 544), dev)
+    xs = [synth.synth_image_batch(811 + i, 140, 32, 544).to(dev) for i in range(2)]
+    pipe = GraphedPipeline(net, post, xs[0])
+    got = [[{k: v.clone() for k, v in d.items()} for d in pipe(x)] for x in (xs[0], xs[1], xs[0])]
+    for x, g_list in zip((xs[0], xs[1], xs[0]), got):
+        with torch.no_grad():
+            want = post_ref(net_ref(x))
+        assert len(g_list) == len(want) == 140
+        for g, w in zip(g_list, want):
+            assert torch.equal(g["bbox"], w["bbox"]) and torch.equal(g["cls"], w["cls"]) and torch.equal(g["mask"], w["mask"])
+
+
 # ------------------------------------------------------------------------------------------------
 # fp16-activation configuration (BASELINE.json configs[4]).  The reference has no reduced-precision path: the
 # arithmetic is defined by oracle.forward_f16 (fp16 operands, fp32 sums, one rounding per layer) -- "parity
